@@ -1,0 +1,125 @@
+/*
+ * mrhyde_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the MrHyDE element-local assembly hot path
+ * (reference: dannys4/MrHyDE @ 2024_08_07).  It exists to CHECK the HIP
+ * product path (mrhyde_amd/csrc) and to serve as the timed CPU baseline
+ * ("port") in bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product never does.
+ *
+ * Parity status: pinned against the reference's own golden data --
+ *   regression/discretization/HGRAD/mrhyde.gold   (basis / basis_grad, dof &
+ *       quadrature-point ordering, Q1 quad + hex)
+ *   regression/thermal/{2D_verification,3D_verification,
+ *       2D_verification_highorder}/mrhyde.gold   (end-to-end L2 errors)
+ * Q2-hex (config 2) has no reference test: "parity unpinned" at the
+ * reference-test level for that order; it is bracketed by the Q1-hex and
+ * Q4-quad golds running the same code, plus analytic invariants.
+ *
+ * The reference path cannot be compiled here (needs Trilinos: Kokkos, Sacado,
+ * Intrepid2, Panzer, Tpetra -- none in the image), so there is no oracle/_ref.
+ *
+ * All citations are file:line under /root/reference.
+ */
+#ifndef MRHYDE_ORACLE_H
+#define MRHYDE_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference element tables ------------------------------------------
+ * src/interfaces/discretizationInterface.cpp:346-478 (getBasis/getQuadrature)
+ * HGRAD = Basis_HGRAD_{QUAD,HEX}_Cn_FEM on POINTTYPE_EQUISPACED: tensor
+ * Lagrange, dof index x-fastest, dof 0 at the (-1,-1[,-1]) corner.
+ * Cubature = tensor Gauss-Legendre, ceil((degree+1)/2) points per direction,
+ * point index x-fastest, each direction DESCENDING (+g first): pinned by
+ * regression/discretization/HGRAD/mrhyde.gold:37-52,89-104.                */
+int orc_gauss_npts(int degree);
+void orc_gauss_line(int n, double *pts, double *wts);
+void orc_lagrange_1d(int p, double x, double *val, double *der);
+int orc_ref_sizes(int dim, int order, int qdeg, int *nbasis, int *nq, int *nnodes);
+/* ip[nq][dim], wts[nq], basis[nbasis][nq], grad[nbasis][nq][dim],
+ * nodeval[nnodes][nq], nodegrad[nnodes][nq][dim] (geometry = C1 nodal basis
+ * in shards vertex order, as CellTools uses the cell topology's basis).     */
+int orc_ref_tables(int dim, int order, int qdeg, double *ip, double *wts,
+                   double *basis, double *grad, double *nodeval, double *nodegrad);
+
+/* ---- structured mesh + DOF map -----------------------------------------
+ * 2-D order 1 reproduces SimpleMeshManager_Rectangle bit for bit
+ * (src/tools/simplemeshmanager.hpp:639-675) with offsets {0,1,3,2}
+ * (src/interfaces/discretizationInterface.cpp:302).  Other cases follow the
+ * same rule: element LID list = vertices in shards order first, then the
+ * remaining tensor dofs in tensor order; global ids lexicographic on the
+ * (order*N+1)^dim dof grid; offsets[tensor dof] = position in the LID list.  */
+int orc_mesh_sizes(int dim, int order, const int *ncell, int *nverts, int *nelem, long long *ndof);
+int orc_mesh_structured(int dim, int order, const int *ncell, const double *lo, const double *hi,
+                        double *verts, int *cell2vert, int *lids, int *offsets,
+                        unsigned char *boundary_dof);
+
+/* ---- physical basis / integration data ---------------------------------
+ * src/interfaces/discretizationInterface.cpp:732-776, 898-981.
+ * nodes[E][nnodes][dim]; basis[E][n][q]; basis_grad[E][n][q][dim];
+ * wts[E][q]; ip[E][q][dim].                                                 */
+int orc_physical_basis(int dim, int order, int qdeg, int nelem, const double *nodes,
+                       double *basis, double *basis_grad, double *wts, double *ip);
+
+/* ---- CRS graph ----------------------------------------------------------
+ * src/interfaces/linearAlgebraInterface.cpp:218-229: every dof of an element
+ * couples to every dof of that element; columns sorted ascending per row.
+ * Call with colind == NULL to get rowptr (and nnz = rowptr[nrows]).          */
+int orc_build_graph(int nrows, int nelem, int n, const int *lids, int *rowptr, int *colind);
+
+/* ---- thermal assembly ---------------------------------------------------*/
+typedef struct orc_thermal_args {
+  int dim, order, qdeg;
+  int nelem, nrows, workset_size;
+  const double *nodes;          /* [E][nnodes][dim]                          */
+  const int *lids;              /* [E][n]                                    */
+  const int *offsets;           /* [n] (one variable "e")                     */
+  const unsigned char *fixed;   /* [nrows] isFixedDOF, may be NULL           */
+  const double *u;              /* [nrows] current (stage) solution          */
+  /* stored physical basis (Group::computeBasis, src/tools/group.cpp:134-243) */
+  const double *basis, *basis_grad, *wts, *ip;
+  /* transient data (src/tools/workset.cpp:559-623); ignored if !transient   */
+  int transient, nsteps, nstages, stage;
+  const double *u_prev;         /* [nrows][nsteps]                           */
+  const double *u_stage;        /* [nrows][nstages]                          */
+  const double *butcher_A;      /* [nstages][nstages]                        */
+  const double *butcher_b;      /* [nstages]                                 */
+  const double *bdf;            /* [nsteps+1]                                */
+  double dt;
+  /* coefficients ("thermal diffusion", "density", "specific heat",
+   * src/physics/thermal.cpp:52-63); *_ip != NULL overrides the constant      */
+  double diff, rho, cp;
+  const double *diff_ip;        /* [E][q] or NULL                            */
+  /* "thermal source": kind 0 = constant source_amp, 1 = per-ip array,
+   * 2 = source_amp * prod_d sin(source_freq[d] * x_d)                        */
+  int source_kind;
+  double source_amp, source_freq[3];
+  const double *source_ip;      /* [E][q]                                    */
+  int compute_jacobian;
+  int num_threads;              /* <=1: serial, deterministic                */
+  /* outputs, accumulated into (caller zeroes, solverManager.cpp:1528-1533)  */
+  const int *rowptr, *colind;
+  double *crs_vals;             /* may be NULL                               */
+  double *res;                  /* [nrows], receives -res.val(); may be NULL */
+  double *local_J;              /* [E][n][n] updateJac convention, or NULL   */
+  double *local_res;            /* [E][n]   updateRes convention, or NULL    */
+} orc_thermal_args;
+
+int orc_ad_width(int n);
+int orc_assemble_thermal(const orc_thermal_args *a);
+/* strong-Dirichlet rows: diagonal := 1 (assemblyManager.cpp:1166-1179)      */
+int orc_apply_dbc_diag(int nrows, const unsigned char *fixed, const int *rowptr,
+                       const int *colind, double *crs_vals);
+/* L2 error  sqrt(sum_e sum_pt (u_h - u_true)^2 wts)  with u_true =
+ * prod_d sin(freq[d] x_d)  (src/managers/postprocessManager.cpp:1255-1268)   */
+double orc_l2_error_sinprod(int dim, int order, int qdeg, int nelem, const int *lids,
+                            const int *offsets, const double *basis, const double *wts,
+                            const double *ip, const double *u, const double *freq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

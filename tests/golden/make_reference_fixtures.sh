@@ -1,0 +1,13 @@
+#!/bin/sh
+# Mirrors the reference's own golden DATA files (test outputs and input decks; no source code)
+# for the hot path into tests/golden/reference/.  Run in the build container, where
+# /root/reference exists; the GPU box only sees the committed copies.
+set -e
+R=/root/reference/regression
+D="$(dirname "$0")/reference"
+mkdir -p "$D"
+cp $R/discretization/HGRAD/mrhyde.gold                 $D/discretization_HGRAD.gold
+for c in 2D_verification 3D_verification 2D_verification_highorder 2D_verification_mpi; do
+  cp $R/thermal/$c/mrhyde.gold  $D/thermal_$c.gold
+  cp $R/thermal/$c/input.yaml   $D/thermal_$c.input.yaml
+done

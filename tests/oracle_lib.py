@@ -1,0 +1,224 @@
+"""ctypes binding of the CPU oracle (oracle/libmrhyde_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (mrhyde_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB_PATH = os.path.join(_ORACLE_DIR, "libmrhyde_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_ubyte)
+
+
+class ThermalArgs(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int), ("order", C.c_int), ("qdeg", C.c_int),
+        ("nelem", C.c_int), ("nrows", C.c_int), ("workset_size", C.c_int),
+        ("nodes", _dp), ("lids", _ip), ("offsets", _ip), ("fixed", _up), ("u", _dp),
+        ("basis", _dp), ("basis_grad", _dp), ("wts", _dp), ("ip", _dp),
+        ("transient", C.c_int), ("nsteps", C.c_int), ("nstages", C.c_int), ("stage", C.c_int),
+        ("u_prev", _dp), ("u_stage", _dp), ("butcher_A", _dp), ("butcher_b", _dp), ("bdf", _dp),
+        ("dt", C.c_double),
+        ("diff", C.c_double), ("rho", C.c_double), ("cp", C.c_double),
+        ("diff_ip", _dp),
+        ("source_kind", C.c_int), ("source_amp", C.c_double), ("source_freq", C.c_double * 3),
+        ("source_ip", _dp),
+        ("compute_jacobian", C.c_int), ("num_threads", C.c_int),
+        ("rowptr", _ip), ("colind", _ip),
+        ("crs_vals", _dp), ("res", _dp), ("local_J", _dp), ("local_res", _dp),
+    ]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_l2_error_sinprod.restype = C.c_double
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def _u(a):
+    return None if a is None else a.ctypes.data_as(_up)
+
+
+def gauss_line(n):
+    p = np.zeros(n)
+    w = np.zeros(n)
+    lib().orc_gauss_line(n, _d(p), _d(w))
+    return p, w
+
+
+def ref_sizes(dim, order, qdeg):
+    nb, nq, nn = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().orc_ref_sizes(dim, order, qdeg, C.byref(nb), C.byref(nq), C.byref(nn))
+    assert rc == 0
+    return nb.value, nq.value, nn.value
+
+
+def ref_tables(dim, order, qdeg):
+    nb, nq, nn = ref_sizes(dim, order, qdeg)
+    t = dict(ip=np.zeros((nq, dim)), wts=np.zeros(nq), basis=np.zeros((nb, nq)),
+             grad=np.zeros((nb, nq, dim)), nodeval=np.zeros((nn, nq)), nodegrad=np.zeros((nn, nq, dim)))
+    rc = lib().orc_ref_tables(dim, order, qdeg, _d(t["ip"]), _d(t["wts"]), _d(t["basis"]), _d(t["grad"]),
+                              _d(t["nodeval"]), _d(t["nodegrad"]))
+    assert rc == 0
+    return t
+
+
+def mesh_structured(dim, order, ncell, lo=None, hi=None):
+    ncell = np.asarray(ncell, dtype=np.int32)
+    lo = np.zeros(3) if lo is None else np.asarray(lo, dtype=np.float64)
+    hi = np.ones(3) if hi is None else np.asarray(hi, dtype=np.float64)
+    nv, ne, nd = C.c_int(), C.c_int(), C.c_longlong()
+    assert lib().orc_mesh_sizes(dim, order, _i(ncell), C.byref(nv), C.byref(ne), C.byref(nd)) == 0
+    n = (order + 1) ** dim
+    nn = 2 ** dim
+    m = dict(verts=np.zeros((nv.value, dim)), cell2vert=np.zeros((ne.value, nn), dtype=np.int32),
+             lids=np.zeros((ne.value, n), dtype=np.int32), offsets=np.zeros(n, dtype=np.int32),
+             boundary=np.zeros(nd.value, dtype=np.uint8), ndof=nd.value, nelem=ne.value)
+    rc = lib().orc_mesh_structured(dim, order, _i(ncell), _d(lo), _d(hi), _d(m["verts"]), _i(m["cell2vert"]),
+                                   _i(m["lids"]), _i(m["offsets"]), _u(m["boundary"]))
+    assert rc == 0
+    m["nodes"] = np.ascontiguousarray(m["verts"][m["cell2vert"]])
+    return m
+
+
+def physical_basis(dim, order, qdeg, nodes, want=("basis", "basis_grad", "wts", "ip")):
+    nb, nq, nn = ref_sizes(dim, order, qdeg)
+    E = nodes.shape[0]
+    out = dict(basis=np.zeros((E, nb, nq)) if "basis" in want else None,
+               basis_grad=np.zeros((E, nb, nq, dim)) if "basis_grad" in want else None,
+               wts=np.zeros((E, nq)) if "wts" in want else None,
+               ip=np.zeros((E, nq, dim)) if "ip" in want else None)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    rc = lib().orc_physical_basis(dim, order, qdeg, E, _d(nodes), _d(out["basis"]), _d(out["basis_grad"]),
+                                  _d(out["wts"]), _d(out["ip"]))
+    assert rc == 0
+    return out
+
+
+def build_graph(nrows, lids):
+    lids = np.ascontiguousarray(lids, dtype=np.int32)
+    E, n = lids.shape
+    rowptr = np.zeros(nrows + 1, dtype=np.int32)
+    assert lib().orc_build_graph(nrows, E, n, _i(lids), _i(rowptr), None) == 0
+    colind = np.zeros(rowptr[-1], dtype=np.int32)
+    assert lib().orc_build_graph(nrows, E, n, _i(lids), _i(rowptr), _i(colind)) == 0
+    return rowptr, colind
+
+
+def ad_width(n):
+    return lib().orc_ad_width(n)
+
+
+def assemble_thermal(dim, order, qdeg, nodes, lids, offsets, u, *, nrows=None, fixed=None, pb=None,
+                     workset_size=100, transient=None, diff=1.0, rho=1.0, cp=1.0, diff_ip=None,
+                     source=("const", 0.0), compute_jacobian=True, num_threads=1,
+                     rowptr=None, colind=None, want_crs=True, want_res=True, want_local=False):
+    """Run the oracle's assembleJacRes restatement.  Returns dict with crs_vals/res/local_J/local_res."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    lids = np.ascontiguousarray(lids, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    E, n = lids.shape
+    nrows = u.shape[0] if nrows is None else nrows
+    if pb is None:
+        pb = physical_basis(dim, order, qdeg, nodes)
+    a = ThermalArgs()
+    a.dim, a.order, a.qdeg = dim, order, qdeg
+    a.nelem, a.nrows, a.workset_size = E, nrows, workset_size
+    keep = [nodes, lids, offsets, u, pb]
+    a.nodes, a.lids, a.offsets, a.u = _d(nodes), _i(lids), _i(offsets), _d(u)
+    if fixed is not None:
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        keep.append(fixed)
+        a.fixed = _u(fixed)
+    a.basis, a.basis_grad, a.wts, a.ip = _d(pb["basis"]), _d(pb["basis_grad"]), _d(pb["wts"]), _d(pb["ip"])
+    if transient is not None:
+        t = {k: np.ascontiguousarray(v, dtype=np.float64) if isinstance(v, np.ndarray) else v
+             for k, v in transient.items()}
+        keep.append(t)
+        a.transient = 1
+        a.nsteps, a.nstages, a.stage = t["u_prev"].shape[1], t["u_stage"].shape[1], t["stage"]
+        a.u_prev, a.u_stage = _d(t["u_prev"]), _d(t["u_stage"])
+        a.butcher_A, a.butcher_b, a.bdf = _d(t["butcher_A"]), _d(t["butcher_b"]), _d(t["bdf"])
+        a.dt = t["dt"]
+    a.diff, a.rho, a.cp = diff, rho, cp
+    if diff_ip is not None:
+        diff_ip = np.ascontiguousarray(diff_ip, dtype=np.float64)
+        keep.append(diff_ip)
+        a.diff_ip = _d(diff_ip)
+    kind = source[0]
+    if kind == "const":
+        a.source_kind, a.source_amp = 0, float(source[1])
+    elif kind == "array":
+        s = np.ascontiguousarray(source[1], dtype=np.float64)
+        keep.append(s)
+        a.source_kind, a.source_ip = 1, _d(s)
+    elif kind == "sinprod":
+        a.source_kind, a.source_amp = 2, float(source[1])
+        fr = list(source[2]) + [0.0] * (3 - len(source[2]))
+        a.source_freq = (C.c_double * 3)(*fr)
+    else:
+        raise ValueError(kind)
+    a.compute_jacobian, a.num_threads = int(compute_jacobian), num_threads
+    out = {}
+    if want_crs or want_res:
+        if rowptr is None:
+            rowptr, colind = build_graph(nrows, lids)
+        keep += [rowptr, colind]
+        a.rowptr, a.colind = _i(rowptr), _i(colind)
+        out["rowptr"], out["colind"] = rowptr, colind
+    if want_crs:
+        out["crs_vals"] = np.zeros(rowptr[-1])
+        a.crs_vals = _d(out["crs_vals"])
+    if want_res:
+        out["res"] = np.zeros(nrows)
+        a.res = _d(out["res"])
+    if want_local:
+        out["local_J"] = np.zeros((E, n, n))
+        out["local_res"] = np.zeros((E, n))
+        a.local_J, a.local_res = _d(out["local_J"]), _d(out["local_res"])
+    rc = lib().orc_assemble_thermal(C.byref(a))
+    assert rc == 0, rc
+    return out
+
+
+def apply_dbc_diag(fixed, rowptr, colind, vals):
+    fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+    assert lib().orc_apply_dbc_diag(len(fixed), _u(fixed), _i(rowptr), _i(colind), _d(vals)) == 0
+
+
+def l2_error_sinprod(dim, order, qdeg, lids, offsets, pb, u, freq):
+    lids = np.ascontiguousarray(lids, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    fr = np.zeros(3)
+    fr[:dim] = freq
+    return lib().orc_l2_error_sinprod(dim, order, qdeg, lids.shape[0], _i(lids), _i(offsets), _d(pb["basis"]),
+                                      _d(pb["wts"]), _d(pb["ip"]), _d(u), _d(fr))

@@ -1,0 +1,150 @@
+"""Pins the CPU oracle against the reference's own golden data.
+
+Golden files are mirrored DATA from /root/reference/regression (see
+tests/golden/make_reference_fixtures.sh)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference")
+
+
+def _parse_hgrad_gold():
+    """-> list of 4 sections: (kind, {(dof,pt): value or tuple})"""
+    secs = []
+    cur = None
+    val_re = re.compile(r"^dof (\d+), point (\d+): ([-0-9.e]+)$")
+    grad_re = re.compile(r"^dof (\d+), point (\d+) grad: \(([-0-9.e,]+)\)$")
+    for line in open(os.path.join(GOLD, "discretization_HGRAD.gold")):
+        line = line.strip()
+        m, g = val_re.match(line), grad_re.match(line)
+        if m or g:
+            kind = "val" if m else "grad"
+            if cur is None or cur[0] != kind or (int((m or g).group(1)), int((m or g).group(2))) in cur[1]:
+                cur = (kind, {})
+                secs.append(cur)
+            if m:
+                cur[1][(int(m.group(1)), int(m.group(2)))] = float(m.group(3))
+            else:
+                cur[1][(int(g.group(1)), int(g.group(2)))] = tuple(float(x) for x in g.group(3).split(","))
+        elif line.startswith("description"):
+            pass
+    return secs
+
+
+def _sig6(x, ref):
+    """x reproduces ref to the 6 significant digits the reference prints (std::cout default)."""
+    return float("%.6g" % x) == pytest.approx(ref, rel=1e-12, abs=1e-300)
+
+
+def test_gauss_rules(oracle):
+    for n in range(1, 8):
+        p, w = oracle.gauss_line(n)
+        assert np.all(np.diff(p) < 0), "points must be descending (HGRAD gold)"
+        # exact for monomials up to degree 2n-1
+        for k in range(2 * n):
+            exact = 0.0 if k % 2 else 2.0 / (k + 1)
+            assert abs(np.dot(w, p ** k) - exact) < 5e-15
+    p, w = oracle.gauss_line(2)
+    assert abs(p[0] - 0.5773502691896257) < 2e-16 and abs(w[0] - 1) < 1e-15
+    p, w = oracle.gauss_line(3)
+    assert abs(p[0] - np.sqrt(0.6)) < 2e-16 and p[1] == 0.0 and abs(w[1] - 8 / 9) < 1e-15
+
+
+def test_hgrad_gold_quad_and_hex(oracle):
+    secs = _parse_hgrad_gold()
+    assert [s[0] for s in secs] == ["val", "grad", "val", "grad"]
+    assert [len(s[1]) for s in secs] == [16, 16, 64, 64]
+    for dim, (vsec, gsec) in ((2, secs[0:2]), (3, secs[2:4])):
+        m = oracle.mesh_structured(dim, 1, [1] * dim)
+        pb = oracle.physical_basis(dim, 1, 2, m["nodes"])
+        for (dof, pt), ref in vsec[1].items():
+            assert _sig6(pb["basis"][0, dof, pt], ref), (dim, dof, pt)
+        for (dof, pt), ref in gsec[1].items():
+            for d in range(dim):
+                assert _sig6(pb["basis_grad"][0, dof, pt, d], ref[d]), (dim, dof, pt, d)
+
+
+def test_simplemesh_map_bit_exact(oracle):
+    """SimpleMeshManager_Rectangle cell->node map (simplemeshmanager.hpp:659-675), offsets {0,1,3,2}."""
+    nx, ny = 5, 3
+    m = oracle.mesh_structured(2, 1, [nx, ny])
+    c = 0
+    for j in range(ny):
+        for i in range(nx):
+            exp = [j * (nx + 1) + i, j * (nx + 1) + i + 1, (j + 1) * (nx + 1) + i + 1, (j + 1) * (nx + 1) + i]
+            assert m["lids"][c].tolist() == exp
+            assert m["cell2vert"][c].tolist() == exp
+            c += 1
+    assert m["offsets"].tolist() == [0, 1, 3, 2]
+    k = 0
+    for j in range(ny + 1):
+        for i in range(nx + 1):
+            assert m["verts"][k, 0] == 0.0 + i * (1.0 / nx) and m["verts"][k, 1] == 0.0 + j * (1.0 / ny)
+            k += 1
+
+
+def _solve_thermal(oracle, dim, order, qdeg, ncell, amp, workset):
+    m = oracle.mesh_structured(dim, order, ncell)
+    pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+    fixed = m["boundary"]
+    u = np.zeros(m["ndof"])  # initial condition 0, Dirichlet 0 (lifted)
+    freq = [2 * np.pi] * dim
+    for _ in range(2):  # "max nonlinear iters: 2"
+        out = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed, pb=pb,
+                                      workset_size=workset, source=("sinprod", amp, freq))
+        oracle.apply_dbc_diag(fixed, out["rowptr"], out["colind"], out["crs_vals"])
+        J = sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]), shape=(m["ndof"],) * 2)
+        du = spla.spsolve(J.tocsc(), out["res"])
+        u = u + du
+        if np.max(np.abs(out["res"])) < 1e-11:
+            break
+    return oracle.l2_error_sinprod(dim, order, qdeg, m["lids"], m["offsets"], pb, u, freq), out
+
+
+def _gold_l2(name):
+    txt = open(os.path.join(GOLD, name)).read()
+    return float(re.search(r"L2 norm of the error for e = ([-0-9.e]+)", txt).group(1))
+
+
+def test_thermal_2d_verification_gold(oracle):
+    err, _ = _solve_thermal(oracle, 2, 1, 2, [40, 40], 8 * np.pi ** 2, 100)
+    assert "%.6g" % err == "%.6g" % _gold_l2("thermal_2D_verification.gold") == "0.00102776"
+    assert _gold_l2("thermal_2D_verification_mpi.gold") == _gold_l2("thermal_2D_verification.gold")
+
+
+def test_thermal_3d_verification_gold(oracle):
+    err, _ = _solve_thermal(oracle, 3, 1, 2, [10, 10, 10], 12 * np.pi ** 2, 100)
+    assert "%.6g" % err == "%.6g" % _gold_l2("thermal_3D_verification.gold") == "0.0116656"
+
+
+def test_thermal_2d_highorder_gold(oracle):
+    err, _ = _solve_thermal(oracle, 2, 4, 8, [10, 10], 8 * np.pi ** 2, 10)
+    assert "%.6g" % err == "%.6g" % _gold_l2("thermal_2D_verification_highorder.gold") == "8.59709e-07"
+
+
+def test_q2_hex_invariants(oracle):
+    """Config 2 (Q2 hex) has no reference test: analytic invariants on a perturbed mesh."""
+    rng = np.random.default_rng(3)
+    m = oracle.mesh_structured(3, 2, [3, 3, 3])
+    verts = m["verts"].copy()
+    interior = np.all((verts > 1e-12) & (verts < 1 - 1e-12), axis=1)
+    verts[interior] += 0.15 / 3 * rng.uniform(-1, 1, size=(interior.sum(), 3))
+    nodes = verts[m["cell2vert"]]
+    u = rng.uniform(-1, 1, m["ndof"])
+    out = oracle.assemble_thermal(3, 2, 4, nodes, m["lids"], m["offsets"], u, source=("const", 1.0), want_local=True)
+    J = sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]))
+    assert abs(J - J.T).max() < 1e-13                       # symmetric stiffness
+    assert np.abs(J @ np.ones(m["ndof"])).max() < 1e-13     # constants in the kernel
+    # residual = K u - f with f_i = int N_i  => sum_i(-res_i) = -(1^T K u) + |Omega| = 1
+    assert abs(out["res"].sum() - 1.0) < 1e-12
+    # local_J follows the same values element by element
+    E, n = m["lids"].shape
+    dense = np.zeros((m["ndof"],) * 2)
+    for e in range(E):
+        dense[np.ix_(m["lids"][e], m["lids"][e])] += out["local_J"][e]
+    assert np.abs(dense - J.toarray()).max() < 1e-13
