@@ -1,0 +1,179 @@
+/*
+ * mrhyde_amd.h -- C ABI of the MI355X-native element-local assembly path.
+ *
+ * Drop-in boundary for MrHyDE's AssemblyManager / Workset / PhysicsBase hot
+ * path.  Plain pointers and sizes only; every entry
+ * point returns an int status (0 = MHA_OK) and sets mha_last_error(); nothing
+ * throws across the boundary and nothing calls back into the caller.
+ *
+ * The reference has no FFI: its boundary is the C++ interface contract
+ *   AssemblyManager::assembleJacRes / assembleRes   src/managers/assemblyManager.hpp:173-239
+ *   Workset<EvalT> field views                       src/tools/workset.hpp:193-316
+ *   PhysicsBase<EvalT>::volumeResidual() etc.        src/physics/physicsBase.hpp:59-85
+ * Each entry point below cites the reference routine it replaces (file:line
+ * under the reference tree).  INTEGRATION.md shows the adapter a MrHyDE
+ * maintainer would add on the reference side.
+ *
+ * Conventions:
+ *  - "host" pointers are read during the call and may be freed afterwards;
+ *    "dev" pointers are HIP device pointers owned by the caller (the assembler
+ *    never owns res / J, as in the reference).
+ *  - LIDs are int32 (LO=int, src/preferences.hpp:40-47) and are consumed
+ *    bit-exact; scalars are double (ScalarT).
+ *  - the global residual receives -res.val(), the Jacobian +d res(row)/d u(col)
+ *    (assemblyManager.cpp:4094,4128); rows with isFixedDOF are skipped (:4075,:4120).
+ *  - one HIP stream per context; calls on one context are not thread-safe
+ *    (the reference processes worksets sequentially, assemblyManager.cpp:2355).
+ */
+#ifndef MRHYDE_AMD_H
+#define MRHYDE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHA_OK 0
+#define MHA_ERR_INVALID 1      /* bad argument / unsupported configuration      */
+#define MHA_ERR_STATE 2        /* call order violated (e.g. assemble before mesh) */
+#define MHA_ERR_DEVICE 3       /* HIP runtime error (no GPU, launch failure, ...)  */
+#define MHA_ERR_UNKNOWN_FIELD 4
+
+typedef struct mha_context mha_context; /* one element block on one GPU        */
+
+const char *mha_last_error(void);
+const char *mha_version(void);
+/* number of visible HIP devices, or 0 (never fails) */
+int mha_device_count(void);
+
+/* ---- block descriptor ---------------------------------------------------
+ * replaces: GroupMetaData + Workset construction for one block
+ *   src/tools/groupMetaData.hpp:23-129, src/managers/assemblyManager.cpp:272-712
+ *   DiscretizationInterface::getBasis/getQuadrature  discretizationInterface.cpp:346-478 */
+#define MHA_TOPO_QUAD4 4
+#define MHA_TOPO_HEX8 8
+#define MHA_BASIS_HGRAD 0
+#define MHA_MAX_VARS 8
+
+typedef struct mha_block_desc {
+  int dimension;                 /* 2 or 3                                      */
+  int topology;                  /* MHA_TOPO_QUAD4 / MHA_TOPO_HEX8              */
+  int num_vars;                  /* 1 for thermal ("e")                         */
+  int basis_type[MHA_MAX_VARS];  /* MHA_BASIS_HGRAD                             */
+  int basis_order[MHA_MAX_VARS]; /* Discretization: order                       */
+  int quadrature_degree;         /* Discretization: quadrature (0 => 2*max order,
+                                    discretizationInterface.cpp:166)             */
+  int workset_size;              /* Solver: workset size (100; <=0 => all,
+                                    assemblyManager.cpp:326-332)                 */
+  int device;                    /* HIP device ordinal                          */
+} mha_block_desc;
+
+int mha_block_create(const mha_block_desc *desc, mha_context **out);
+void mha_block_destroy(mha_context *ctx);
+/* hipStream_t passed as void*; NULL = the null stream */
+int mha_set_stream(mha_context *ctx, void *hip_stream);
+
+/* ---- mesh, maps, graph ---------------------------------------------------
+ * replaces: createGroups' LID/node copies (assemblyManager.cpp:656-688),
+ * wkset offsets (solverManager.cpp:856-982), createFixedDOFs (assemblyManager.cpp:185-265).
+ * nodes[E][nnodes][dim] f64 in the cell topology's (shards) vertex order;
+ * lids[E][n] int32; offsets[var][dof] flattened in variable order, values are
+ * positions in the element's LID list; is_fixed[nrows] u8 (may be NULL).        */
+int mha_set_mesh(mha_context *ctx, int num_elems, const double *nodes_host, const int32_t *lids_host,
+                 const int32_t *offsets_host, int num_rows, const uint8_t *is_fixed_host);
+/* overlapped CRS graph of the caller (Tpetra local graph: rowptr[nrows+1], colind sorted
+ * ascending per row).  Pass NULL/NULL to build it by the reference rule
+ * (linearAlgebraInterface.cpp:218-229).                                          */
+int mha_set_graph(mha_context *ctx, const int32_t *rowptr_host, const int32_t *colind_host);
+int mha_get_graph_sizes(mha_context *ctx, int *num_rows, int64_t *nnz);
+int mha_get_graph(mha_context *ctx, int32_t *rowptr_host, int32_t *colind_host);
+
+/* ---- physics module -------------------------------------------------------
+ * replaces: PhysicsImporter::import + thermal::defineFunctions
+ *   src/physics/physicsImporter.cpp:48-204, src/physics/thermal.cpp:24-66
+ * Coefficients are what FunctionManager::evaluate(name,"ip") would return
+ * (functionManager.cpp:543-760): a constant, or a per-(elem,ip) array.            */
+#define MHA_PHYSICS_THERMAL 1
+int mha_physics_select(mha_context *ctx, int physics_id);
+#define MHA_FUNC_CONSTANT 0
+#define MHA_FUNC_IP_ARRAY 1     /* dev pointer to [E][numip] f64                    */
+#define MHA_FUNC_SINPROD 2      /* amp * prod_d sin(freq[d]*x_d), evaluated at ip   */
+/* name in {"thermal source","thermal diffusion","specific heat","density"}         */
+int mha_set_function(mha_context *ctx, const char *name, int kind, double amp, const double *freq3,
+                     const double *ip_array_dev);
+
+/* ---- time integration state -----------------------------------------------
+ * replaces: Workset::setDeltat/setStage + butcher/BDF tables consumed by
+ * computeSolnTransientSeeded  src/tools/workset.cpp:559-623.  Steady = never call.  */
+int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int num_stages, int stage,
+                             double deltat, const double *butcher_A_host, const double *butcher_b_host,
+                             const double *bdf_wts_host);
+
+/* ---- assembly --------------------------------------------------------------
+ * replaces: AssemblyManager::assembleJacRes<EvalT>  assemblyManager.cpp:2150-2665
+ *   (volume loop: performGather :3598, updateWorkset :6512, volumeResidual,
+ *    scatter :4031) and assembleRes :2946-3151 (compute_jacobian = 0).
+ * u_dev[nrows]; u_prev_dev[nrows][num_steps], u_stage_dev[nrows][num_stages] (transient only);
+ * res_dev[nrows] and crs_vals_dev[nnz] are ACCUMULATED into (the caller zeroes them,
+ * solverManager.cpp:1528-1533).  crs_vals_dev may be NULL iff !compute_jacobian.
+ * path: MHA_PATH_AUTO picks the fastest valid kernel; the others force one.          */
+#define MHA_PATH_AUTO 0
+#define MHA_PATH_ELEMENT_ATOMIC 1 /* per-element kernel, atomic scatter (reference's
+                                     fused "assembly insert Jac" with useAtomics)     */
+#define MHA_PATH_ROW_OWNER 2      /* fused row-owner kernel, no global atomics           */
+#define MHA_PATH_LOCAL_THEN_SCATTER 3 /* updateJac/updateRes then scatterJac/scatterRes   */
+int mha_assemble_jacres(mha_context *ctx, int compute_jacobian, int path, const double *u_dev,
+                        const double *u_prev_dev, const double *u_stage_dev, double *res_dev,
+                        double *crs_vals_dev);
+/* replaces: updateJac / updateRes  assemblyManager.cpp:7412-7455, 7115-7152
+ * local_J_dev[E][n][n] += res(e,r).dx(c), local_res_dev[E][n] -= res(e,r).val()      */
+int mha_compute_local_jacres(mha_context *ctx, int compute_jacobian, const double *u_dev,
+                             const double *u_prev_dev, const double *u_stage_dev, double *local_J_dev,
+                             double *local_res_dev);
+/* replaces: scatterJac / scatterRes  assemblyManager.cpp:3882-3935, 3943-3978          */
+int mha_scatter_local(mha_context *ctx, const double *local_J_dev, const double *local_res_dev,
+                      double *res_dev, double *crs_vals_dev);
+/* replaces: dofConstraints -> updateJacDBC  assemblyManager.cpp:3158-3187, 1166-1179   */
+int mha_apply_dbc_diag(mha_context *ctx, double *crs_vals_dev);
+/* replaces: performGather  assemblyManager.cpp:3598-3643: out[E][n] (dof order = basis order) */
+int mha_gather(mha_context *ctx, const double *vec_dev, double *elem_vals_dev);
+
+/* ---- workset views -----------------------------------------------------------
+ * replaces: updateWorkset aliasing the group's stored views (assemblyManager.cpp:6512-6596)
+ * and Group::computeBasis -> getPhysicalVolumetricBasis / getPhysicalIntegrationData
+ *   src/tools/group.cpp:134-243, discretizationInterface.cpp:732-776, 898-1127.
+ * mha_workset_update evaluates the views for workset `index` (elements
+ * [index*ws, min((index+1)*ws, E))) on the device; mha_workset_view returns a
+ * device pointer + extents (LayoutRight) valid until the next update.
+ * names: "basis" (numElem,n,numip,1)  "basis_grad" (numElem,n,numip,dim)
+ *        "wts" (numElem,numip)  "x","y","z" (numElem,numip)  "LIDs" (numElem,n) int32
+ *        "offsets" (numvars, maxdof) int32
+ * unknown names: MHA_ERR_UNKNOWN_FIELD (the reference prints and continues,
+ * workset.cpp:1576-1577).                                                             */
+int mha_num_worksets(mha_context *ctx);
+int mha_workset_update(mha_context *ctx, int index);
+int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t extents[4], int *rank);
+
+/* ---- structured mesh helper (input generation, not part of the hot path) ------
+ * 2-D order 1 = SimpleMeshManager_Rectangle (src/tools/simplemeshmanager.hpp:639-675)
+ * with offsets {0,1,3,2} (discretizationInterface.cpp:302).                            */
+int mha_mesh_sizes(int dim, int order, const int *ncell, int *nverts, int *nelem, int64_t *ndof);
+int mha_mesh_structured(int dim, int order, const int *ncell, const double *lo, const double *hi,
+                        double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
+                        uint8_t *boundary_dof);
+
+/* ---- introspection for bench / tests ---------------------------------------------
+ * keys: "num_elems","num_rows","nnz","dofs_per_elem","num_ip","num_affine_elems",
+ *       "row_blocks","last_path"                                                       */
+int mha_get_info(mha_context *ctx, const char *key, int64_t *value);
+/* average device time (ms) of the last assembly's kernels, measured with HIP events on the
+ * context's stream; valid after mha_set_timing(ctx,1).                                  */
+int mha_set_timing(mha_context *ctx, int enable);
+int mha_get_last_kernel_ms(mha_context *ctx, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

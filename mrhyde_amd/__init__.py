@@ -1,0 +1,14 @@
+"""mrhyde_amd -- MI355X-native element-local assembly path of MrHyDE.
+
+The product is the C-ABI shared library built from mrhyde_amd/csrc (see
+include/mrhyde_amd.h).  This package is a thin ctypes binding used by the
+tests, bench.py and __graft_entry__.py: it only moves pointers across the
+boundary.  Device memory, streams and torch.distributed come from PyTorch
+(plumbing); every computation runs in the HIP kernels.  There is no CPU
+fallback: creating a Block without a GPU raises.
+"""
+from .api import (Block, MhaError, PATH_AUTO, PATH_ELEMENT_ATOMIC, PATH_LOCAL_THEN_SCATTER, PATH_ROW_OWNER,
+                  device_count, lib_path, load_library, mesh_structured, version)
+
+__all__ = ["Block", "MhaError", "PATH_AUTO", "PATH_ELEMENT_ATOMIC", "PATH_LOCAL_THEN_SCATTER", "PATH_ROW_OWNER",
+           "device_count", "lib_path", "load_library", "mesh_structured", "version"]

@@ -1,0 +1,268 @@
+"""ctypes binding of include/mrhyde_amd.h (one Python method per C entry point)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libmrhyde_amd.so")
+
+PATH_AUTO, PATH_ELEMENT_ATOMIC, PATH_ROW_OWNER, PATH_LOCAL_THEN_SCATTER = 0, 1, 2, 3
+FUNC_CONSTANT, FUNC_IP_ARRAY, FUNC_SINPROD = 0, 1, 2
+TOPO_QUAD4, TOPO_HEX8 = 4, 8
+PHYSICS_THERMAL = 1
+MAX_VARS = 8
+
+# every symbol include/mrhyde_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "mha_last_error", "mha_version", "mha_device_count", "mha_block_create", "mha_block_destroy", "mha_set_stream",
+    "mha_set_mesh", "mha_set_graph", "mha_get_graph_sizes", "mha_get_graph", "mha_physics_select",
+    "mha_set_function", "mha_set_time_integration", "mha_assemble_jacres", "mha_compute_local_jacres",
+    "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
+    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_get_info", "mha_set_timing",
+    "mha_get_last_kernel_ms",
+]
+
+
+class MhaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mrhyde_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("dimension", C.c_int), ("topology", C.c_int), ("num_vars", C.c_int),
+                ("basis_type", C.c_int * MAX_VARS), ("basis_order", C.c_int * MAX_VARS),
+                ("quadrature_degree", C.c_int), ("workset_size", C.c_int), ("device", C.c_int)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _LIB
+
+
+def load_library():
+    """Load the HIP shared library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError("%s is missing: run `make -C mrhyde_amd/csrc` (or __graft_entry__.build()); "
+                              "there is no fallback path" % _LIB)
+        _lib = C.CDLL(_LIB)
+        _lib.mha_last_error.restype = C.c_char_p
+        _lib.mha_version.restype = C.c_char_p
+        _lib.mha_block_destroy.restype = None
+        _lib.mha_set_function.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        _lib.mha_set_time_integration.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_assemble_jacres.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        _lib.mha_compute_local_jacres.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        _lib.mha_scatter_local.argtypes = [C.c_void_p] * 5
+        _lib.mha_apply_dbc_diag.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_set_mesh.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.mha_set_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_get_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_get_graph_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_physics_select.argtypes = [C.c_void_p, C.c_int]
+        _lib.mha_num_worksets.argtypes = [C.c_void_p]
+        _lib.mha_workset_update.argtypes = [C.c_void_p, C.c_int]
+        _lib.mha_workset_view.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_get_info.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        _lib.mha_set_timing.argtypes = [C.c_void_p, C.c_int]
+        _lib.mha_get_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_block_destroy.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MhaError(rc, load_library().mha_last_error().decode())
+
+
+def version():
+    return load_library().mha_version().decode()
+
+
+def device_count():
+    return load_library().mha_device_count()
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device arguments must be contiguous CUDA tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def mesh_structured(dim, order, ncell, lo=None, hi=None):
+    """Structured quad/hex mesh + HGRAD dof map (mha_mesh_structured).  Host numpy arrays."""
+    lib = load_library()
+    ncell = _np(ncell, np.int32)
+    lo = _np(np.zeros(3) if lo is None else lo, np.float64)
+    hi = _np(np.ones(3) if hi is None else hi, np.float64)
+    nv, ne, nd = C.c_int(), C.c_int(), C.c_int64()
+    _check(lib.mha_mesh_sizes(dim, order, ncell.ctypes.data_as(C.c_void_p), C.byref(nv), C.byref(ne), C.byref(nd)))
+    n, nn = (order + 1) ** dim, 2 ** dim
+    m = dict(verts=np.zeros((nv.value, dim)), cell2vert=np.zeros((ne.value, nn), np.int32),
+             lids=np.zeros((ne.value, n), np.int32), offsets=np.zeros(n, np.int32),
+             boundary=np.zeros(nd.value, np.uint8), ndof=nd.value, nelem=ne.value, dim=dim, order=order)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    _check(lib.mha_mesh_structured(dim, order, vp(ncell), vp(lo), vp(hi), vp(m["verts"]), vp(m["cell2vert"]),
+                                   vp(m["lids"]), vp(m["offsets"]), vp(m["boundary"])))
+    m["nodes"] = np.ascontiguousarray(m["verts"][m["cell2vert"]])
+    return m
+
+
+class Block:
+    """One element block on one GPU (mha_context)."""
+
+    def __init__(self, dim, order, quadrature=0, workset_size=100, device=0, physics="thermal"):
+        lib = load_library()
+        d = BlockDesc()
+        d.dimension, d.topology, d.num_vars = dim, (TOPO_QUAD4 if dim == 2 else TOPO_HEX8), 1
+        d.basis_type[0], d.basis_order[0] = 0, order
+        d.quadrature_degree, d.workset_size, d.device = quadrature, workset_size, device
+        self._h = C.c_void_p()
+        _check(lib.mha_block_create(C.byref(d), C.byref(self._h)))
+        self.dim, self.order = dim, order
+        self._keep = []
+        if physics == "thermal":
+            _check(lib.mha_physics_select(self._h, PHYSICS_THERMAL))
+        elif physics is not None:
+            raise ValueError(physics)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().mha_block_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup ------------------------------------------------------------
+    def set_stream(self, cuda_stream_handle):
+        _check(load_library().mha_set_stream(self._h, C.c_void_p(cuda_stream_handle)))
+
+    def set_mesh(self, nodes, lids, offsets, nrows, fixed=None):
+        nodes, lids, offsets = _np(nodes, np.float64), _np(lids, np.int32), _np(offsets, np.int32)
+        fixed = None if fixed is None else _np(fixed, np.uint8)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        _check(load_library().mha_set_mesh(self._h, lids.shape[0], vp(nodes), vp(lids), vp(offsets), int(nrows),
+                                           vp(fixed)))
+        self.nelem, self.n, self.nrows = lids.shape[0], lids.shape[1], int(nrows)
+
+    def set_graph(self, rowptr=None, colind=None):
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        if rowptr is not None:
+            rowptr, colind = _np(rowptr, np.int32), _np(colind, np.int32)
+        _check(load_library().mha_set_graph(self._h, vp(rowptr), vp(colind)))
+
+    def get_graph(self):
+        nr, nnz = C.c_int(), C.c_int64()
+        _check(load_library().mha_get_graph_sizes(self._h, C.byref(nr), C.byref(nnz)))
+        rowptr, colind = np.zeros(nr.value + 1, np.int32), np.zeros(nnz.value, np.int32)
+        _check(load_library().mha_get_graph(self._h, rowptr.ctypes.data_as(C.c_void_p),
+                                            colind.ctypes.data_as(C.c_void_p)))
+        return rowptr, colind
+
+    def set_function(self, name, value):
+        """value: float | ("sinprod", amp, freq[dim]) | CUDA tensor [E, numip]."""
+        lib = load_library()
+        if isinstance(value, (int, float)):
+            _check(lib.mha_set_function(self._h, name.encode(), FUNC_CONSTANT, float(value), None, None))
+        elif isinstance(value, tuple) and value[0] == "sinprod":
+            fr = np.zeros(3)
+            fr[:len(value[2])] = value[2]
+            _check(lib.mha_set_function(self._h, name.encode(), FUNC_SINPROD, float(value[1]),
+                                        fr.ctypes.data_as(C.c_void_p), None))
+        else:
+            self._keep.append(value)
+            _check(lib.mha_set_function(self._h, name.encode(), FUNC_IP_ARRAY, 0.0, None, _ptr(value)))
+
+    def set_time_integration(self, transient, nsteps=0, nstages=0, stage=0, dt=1.0, butcher_A=None, butcher_b=None,
+                             bdf=None):
+        vp = lambda a: None if a is None else _np(a, np.float64).ctypes.data_as(C.c_void_p)
+        A, b, w = (None if x is None else _np(x, np.float64) for x in (butcher_A, butcher_b, bdf))
+        _check(load_library().mha_set_time_integration(self._h, int(transient), nsteps, nstages, stage, float(dt),
+                                                       vp(A), vp(b), vp(w)))
+
+    # -- assembly -----------------------------------------------------------
+    def assemble_jacres(self, u, res, crs_vals=None, compute_jacobian=True, path=PATH_AUTO, u_prev=None,
+                        u_stage=None):
+        _check(load_library().mha_assemble_jacres(self._h, int(compute_jacobian), path, _ptr(u), _ptr(u_prev),
+                                                  _ptr(u_stage), _ptr(res), _ptr(crs_vals)))
+
+    def compute_local_jacres(self, u, local_J, local_res, compute_jacobian=True, u_prev=None, u_stage=None):
+        _check(load_library().mha_compute_local_jacres(self._h, int(compute_jacobian), _ptr(u), _ptr(u_prev),
+                                                       _ptr(u_stage), _ptr(local_J), _ptr(local_res)))
+
+    def scatter_local(self, local_J, local_res, res, crs_vals):
+        _check(load_library().mha_scatter_local(self._h, _ptr(local_J), _ptr(local_res), _ptr(res), _ptr(crs_vals)))
+
+    def apply_dbc_diag(self, crs_vals):
+        _check(load_library().mha_apply_dbc_diag(self._h, _ptr(crs_vals)))
+
+    def gather(self, vec, out):
+        _check(load_library().mha_gather(self._h, _ptr(vec), _ptr(out)))
+
+    # -- workset views ---------------------------------------------------------
+    def num_worksets(self):
+        return load_library().mha_num_worksets(self._h)
+
+    def workset_update(self, index):
+        _check(load_library().mha_workset_update(self._h, index))
+
+    def workset_view(self, name):
+        """-> (device pointer, shape tuple)."""
+        p, ext, rank = C.c_void_p(), (C.c_int64 * 4)(), C.c_int()
+        _check(load_library().mha_workset_view(self._h, name.encode(), C.byref(p), ext, C.byref(rank)))
+        return p.value, tuple(ext[k] for k in range(rank.value))
+
+    def workset_view_numpy(self, name):
+        """Copy a workset view to the host (tests)."""
+        import torch
+        ptr, shape = self.workset_view(name)
+        is_int = name in ("LIDs", "offsets")
+        count = int(np.prod(shape))
+        out = np.zeros(shape, np.int32 if is_int else np.float64)
+        torch.cuda.synchronize()
+        rc = _hip_memcpy_dtoh(out.ctypes.data, ptr, count * out.itemsize)
+        assert rc == 0, rc
+        return out
+
+    # -- introspection --------------------------------------------------------------
+    def info(self, key):
+        v = C.c_int64()
+        _check(load_library().mha_get_info(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def set_timing(self, on=True):
+        _check(load_library().mha_set_timing(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        v = C.c_double()
+        _check(load_library().mha_get_last_kernel_ms(self._h, C.byref(v)))
+        return v.value
+
+
+_hip = None
+
+
+def _hip_memcpy_dtoh(dst_host, src_dev, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _hip.hipMemcpy(C.c_void_p(dst_host), C.c_void_p(src_dev), nbytes, 2)

@@ -1,0 +1,325 @@
+#include "assembly_manager.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "mesh.hpp"
+
+namespace mha {
+
+AssemblyManager::AssemblyManager(const mha_block_desc &desc) {
+  MHA_REQUIRE(desc.dimension == 2 || desc.dimension == 3, MHA_ERR_INVALID, "dimension must be 2 or 3");
+  MHA_REQUIRE((desc.dimension == 2 && desc.topology == MHA_TOPO_QUAD4) ||
+                  (desc.dimension == 3 && desc.topology == MHA_TOPO_HEX8),
+              MHA_ERR_INVALID, "supported cell topologies: Quadrilateral_4 (2-D), Hexahedron_8 (3-D)");
+  MHA_REQUIRE(desc.num_vars == 1, MHA_ERR_INVALID,
+              "this build assembles single-variable blocks (thermal); got num_vars = " << desc.num_vars);
+  MHA_REQUIRE(desc.basis_type[0] == MHA_BASIS_HGRAD, MHA_ERR_INVALID, "only HGRAD bases are available");
+  dim_ = desc.dimension;
+  order_ = desc.basis_order[0];
+  // default quadrature = 2*max order (reference: discretizationInterface.cpp:166)
+  qdeg_ = desc.quadrature_degree > 0 ? desc.quadrature_degree : 2 * order_;
+  ref_ = make_ref_tables(dim_, order_, qdeg_);
+  n_ = ref_.nbasis;
+  nq_ = ref_.nq;
+  nnodes_ = ref_.nnodes;
+  workset_size_ = desc.workset_size;
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  MHA_REQUIRE(e == hipSuccess && ndev > 0, MHA_ERR_DEVICE,
+              "no HIP device available (" << hipGetErrorString(e) << "): the MI355X path has no CPU fallback");
+  MHA_REQUIRE(desc.device >= 0 && desc.device < ndev, MHA_ERR_INVALID, "device ordinal out of range");
+  MHA_HIP(hipSetDevice(desc.device));
+
+  d_ref_basis_.upload(ref_.basis);
+  d_ref_grad_.upload(ref_.grad);
+  d_ref_wts_.upload(ref_.wts);
+  d_nodeval_.upload(ref_.nodeval);
+  d_nodegrad_.upload(ref_.nodegrad);
+  MHA_HIP(hipEventCreate(&ev0_));
+  MHA_HIP(hipEventCreate(&ev1_));
+
+  wkset_.block = 0;
+  wkset_.dimension = dim_;
+  wkset_.numip = nq_;
+  wkset_.numVars = 1;
+  wkset_.order = order_;
+  wkset_.nq1 = ref_.nq1;
+}
+
+AssemblyManager::~AssemblyManager() {
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+}
+
+// createGroups' copies of LIDs / nodes (reference: assemblyManager.cpp:656-688) + createFixedDOFs (:185-265)
+void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lids, const int32_t *offsets,
+                              int nrows, const uint8_t *fixed) {
+  MHA_REQUIRE(nelem > 0 && nrows > 0 && nodes && lids && offsets, MHA_ERR_INVALID, "mha_set_mesh: null or empty input");
+  const size_t nl = static_cast<size_t>(nelem) * n_;
+  for (size_t k = 0; k < nl; ++k)
+    MHA_REQUIRE(lids[k] >= 0 && lids[k] < nrows, MHA_ERR_INVALID, "LID " << lids[k] << " outside [0," << nrows << ")");
+  std::vector<char> seen(n_, 0);
+  for (int t = 0; t < n_; ++t) {
+    MHA_REQUIRE(offsets[t] >= 0 && offsets[t] < n_ && !seen[offsets[t]], MHA_ERR_INVALID,
+                "offsets must be a permutation of 0.." << n_ - 1);
+    seen[offsets[t]] = 1;
+  }
+  nelem_ = nelem;
+  nrows_ = nrows;
+  h_lids_.assign(lids, lids + nl);
+  d_nodes_.upload(nodes, static_cast<size_t>(nelem) * nnodes_ * dim_);
+  d_lids_.upload(lids, nl);
+  d_offsets_.upload(offsets, n_);
+  has_fixed_ = fixed != nullptr;
+  if (fixed) d_fixed_.upload(fixed, nrows);
+  else d_fixed_.resize(0);
+  has_mesh_ = true;
+  has_graph_ = false;
+  // workset size <= 0 or larger than the block => one workset (reference: assemblyManager.cpp:326-332)
+  const int ws = (workset_size_ <= 0 || workset_size_ > nelem_) ? nelem_ : workset_size_;
+  wkset_.maxElem = ws;
+}
+
+void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "mha_set_graph before mha_set_mesh");
+  if (rowptr && colind) {
+    h_rowptr_.assign(rowptr, rowptr + nrows_ + 1);
+    MHA_REQUIRE(h_rowptr_[0] == 0, MHA_ERR_INVALID, "rowptr[0] must be 0");
+    for (int r = 0; r < nrows_; ++r)
+      MHA_REQUIRE(h_rowptr_[r + 1] >= h_rowptr_[r], MHA_ERR_INVALID, "rowptr must be non-decreasing");
+    h_colind_.assign(colind, colind + h_rowptr_[nrows_]);
+    for (int r = 0; r < nrows_; ++r)
+      for (int p = h_rowptr_[r] + 1; p < h_rowptr_[r + 1]; ++p)
+        MHA_REQUIRE(h_colind_[p] > h_colind_[p - 1], MHA_ERR_INVALID, "colind must be strictly ascending in row " << r);
+  } else {
+    MHA_REQUIRE(!rowptr && !colind, MHA_ERR_INVALID, "pass both rowptr and colind, or neither");
+    build_crs_graph(nrows_, nelem_, n_, h_lids_.data(), h_rowptr_, h_colind_);
+  }
+  d_rowptr_.upload(h_rowptr_);
+  d_colind_.upload(h_colind_);
+  has_graph_ = true;
+}
+
+void AssemblyManager::selectPhysics(int physics_id) {
+  physics_ = import_physics(physics_id);
+  physics_->defineFunctions(functions_);
+  physics_->setWorkset(&wkset_);
+}
+
+void AssemblyManager::setFunction(const std::string &name, int kind, double amp, const double *freq3,
+                                  const double *ip_dev) {
+  MHA_REQUIRE(kind == MHA_FUNC_CONSTANT || kind == MHA_FUNC_IP_ARRAY || kind == MHA_FUNC_SINPROD, MHA_ERR_INVALID,
+              "unknown function kind " << kind);
+  MHA_REQUIRE(kind != MHA_FUNC_IP_ARRAY || ip_dev, MHA_ERR_INVALID, "MHA_FUNC_IP_ARRAY needs a device array");
+  MHA_REQUIRE(kind != MHA_FUNC_SINPROD || freq3, MHA_ERR_INVALID, "MHA_FUNC_SINPROD needs freq[3]");
+  FuncDesc f;
+  f.kind = kind;
+  f.amp = amp;
+  if (freq3) for (int d = 0; d < 3; ++d) f.freq[d] = freq3[d];
+  f.ip = ip_dev;
+  functions_.addFunction(name, f);
+}
+
+// Butcher / BDF data consumed by the seeding (reference: src/tools/workset.cpp:571-598)
+void AssemblyManager::setTimeIntegration(int transient, int nsteps, int nstages, int stage, double dt,
+                                         const double *A, const double *b, const double *bdf) {
+  TimeDev t;
+  if (transient) {
+    MHA_REQUIRE(nsteps >= 1 && nsteps <= kMaxSteps && nstages >= 1 && nstages <= kMaxStages, MHA_ERR_INVALID,
+                "num_steps/num_stages out of range");
+    MHA_REQUIRE(stage >= 0 && stage < nstages && A && b && bdf && dt > 0.0, MHA_ERR_INVALID,
+                "bad time-integration tables");
+    t.transient = 1;
+    t.nsteps = nsteps;
+    t.nstages = nstages;
+    t.stage = stage;
+    t.alpha_u = A[stage * nstages + stage] / b[stage];
+    t.timewt = 1.0 / dt / b[stage];
+    t.alpha_t = bdf[0] * t.timewt;
+    for (int s = 0; s < stage; ++s) t.stage_ratio[s] = A[stage * nstages + s] / b[s];
+    for (int s = 0; s <= nsteps; ++s) t.bdf[s] = bdf[s];
+  }
+  time_ = t;
+  wkset_.isTransient = transient != 0;
+  wkset_.deltat = dt;
+  wkset_.current_stage = stage;
+}
+
+void AssemblyManager::requireReady(bool need_graph) const {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  MHA_REQUIRE(physics_ != nullptr, MHA_ERR_STATE, "no physics module: call mha_physics_select first");
+  MHA_REQUIRE(!need_graph || has_graph_, MHA_ERR_STATE, "no CRS graph: call mha_set_graph first");
+}
+
+BlockDev AssemblyManager::blockDev() const {
+  BlockDev b;
+  b.dim = dim_;
+  b.nelem = nelem_;
+  b.nrows = nrows_;
+  b.n = n_;
+  b.nq = nq_;
+  b.nnodes = nnodes_;
+  b.e_begin = 0;
+  b.e_count = nelem_;
+  b.nodes = d_nodes_.data();
+  b.lids = d_lids_.data();
+  b.offsets = d_offsets_.data();
+  b.fixed = has_fixed_ ? d_fixed_.data() : nullptr;
+  b.rowptr = d_rowptr_.data();
+  b.colind = d_colind_.data();
+  b.ref_basis = d_ref_basis_.data();
+  b.ref_grad = d_ref_grad_.data();
+  b.ref_wts = d_ref_wts_.data();
+  b.nodeval = d_nodeval_.data();
+  b.nodegrad = d_nodegrad_.data();
+  return b;
+}
+
+void AssemblyManager::bindState(const double *u, const double *u_prev, const double *u_stage) {
+  MHA_REQUIRE(u != nullptr, MHA_ERR_INVALID, "solution vector is null");
+  MHA_REQUIRE(!time_.transient || (u_prev && u_stage), MHA_ERR_INVALID,
+              "transient assembly needs u_prev and u_stage");
+  time_.u = u;
+  time_.u_prev = u_prev;
+  time_.u_stage = u_stage;
+  wkset_.dev = blockDev();
+  wkset_.time_dev = time_;
+  wkset_.stream = stream_;
+}
+
+void AssemblyManager::timedBegin() {
+  if (timing_) MHA_HIP(hipEventRecord(ev0_, stream_));
+}
+
+void AssemblyManager::timedEnd() {
+  if (!timing_) return;
+  MHA_HIP(hipEventRecord(ev1_, stream_));
+  MHA_HIP(hipEventSynchronize(ev1_));
+  float ms = 0.f;
+  MHA_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+  last_ms_ = ms;
+}
+
+// reference: AssemblyManager::assembleJacRes<EvalT> volume loop (assemblyManager.cpp:2357-2509) and
+// assembleRes (:2946-3151) when compute_jacobian == 0.
+void AssemblyManager::assembleJacRes(int compute_jacobian, int path, const double *u, const double *u_prev,
+                                     const double *u_stage, double *res, double *crs_vals) {
+  requireReady(true);
+  MHA_REQUIRE(res != nullptr, MHA_ERR_INVALID, "residual vector is null");
+  MHA_REQUIRE(!compute_jacobian || crs_vals, MHA_ERR_INVALID, "compute_jacobian set but crs_vals is null");
+  bindState(u, u_prev, u_stage);
+  if (path == MHA_PATH_AUTO) path = MHA_PATH_ELEMENT_ATOMIC;
+  timedBegin();
+  switch (path) {
+    case MHA_PATH_ELEMENT_ATOMIC: {
+      // one launch over the whole block: the worksets of the reference are an execution detail
+      // (sequential reuse of one Workset, assemblyManager.cpp:2355-2357) that does not change results
+      wkset_.first_elem = 0;
+      wkset_.numElem = nelem_;
+      wkset_.res = ElemOut();
+      wkset_.res.compute_jacobian = compute_jacobian ? 1 : 0;
+      wkset_.res.res = res;
+      wkset_.res.crs_vals = compute_jacobian ? crs_vals : nullptr;
+      physics_->volumeResidual();
+      break;
+    }
+    case MHA_PATH_LOCAL_THEN_SCATTER: {
+      // the reference's two-step path, workset by workset (assemblyManager.cpp:2442-2509)
+      const int ws = wkset_.maxElem;
+      d_local_J_.resize(static_cast<size_t>(ws) * n_ * n_);
+      d_local_res_.resize(static_cast<size_t>(ws) * n_);
+      for (int e0 = 0; e0 < nelem_; e0 += ws) {
+        const int ne = std::min(ws, nelem_ - e0);
+        MHA_HIP(hipMemsetAsync(d_local_J_.data(), 0, sizeof(double) * ne * n_ * n_, stream_));
+        MHA_HIP(hipMemsetAsync(d_local_res_.data(), 0, sizeof(double) * ne * n_, stream_));
+        wkset_.first_elem = e0;
+        wkset_.numElem = ne;
+        wkset_.res = ElemOut();
+        wkset_.res.compute_jacobian = compute_jacobian ? 1 : 0;
+        // dense arrays are indexed by the element's position inside the workset
+        wkset_.res.local_base = e0;
+        wkset_.res.local_J = d_local_J_.data();
+        wkset_.res.local_res = d_local_res_.data();
+        physics_->volumeResidual();
+        BlockDev b = blockDev();
+        b.e_begin = e0;
+        b.e_count = ne;
+        launch_scatter_local(b, compute_jacobian ? wkset_.res.local_J : nullptr, wkset_.res.local_res, res,
+                             compute_jacobian ? crs_vals : nullptr, e0, stream_);
+      }
+      break;
+    }
+    default:
+      MHA_REQUIRE(false, MHA_ERR_INVALID, "assembly path " << path << " is not available");
+  }
+  timedEnd();
+  last_path_ = path;
+}
+
+// reference: updateJac / updateRes on the whole block (assemblyManager.cpp:7412-7455, 7115-7152)
+void AssemblyManager::computeLocalJacRes(int compute_jacobian, const double *u, const double *u_prev,
+                                         const double *u_stage, double *local_J, double *local_res) {
+  requireReady(false);
+  MHA_REQUIRE(local_res != nullptr, MHA_ERR_INVALID, "local_res is null");
+  MHA_REQUIRE(!compute_jacobian || local_J, MHA_ERR_INVALID, "compute_jacobian set but local_J is null");
+  bindState(u, u_prev, u_stage);
+  wkset_.first_elem = 0;
+  wkset_.numElem = nelem_;
+  wkset_.res = ElemOut();
+  wkset_.res.compute_jacobian = compute_jacobian ? 1 : 0;
+  wkset_.res.local_J = compute_jacobian ? local_J : nullptr;
+  wkset_.res.local_res = local_res;
+  timedBegin();
+  physics_->volumeResidual();
+  timedEnd();
+}
+
+void AssemblyManager::scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals) {
+  requireReady(true);
+  timedBegin();
+  launch_scatter_local(blockDev(), local_J, local_res, res, crs_vals, 0, stream_);
+  timedEnd();
+}
+
+void AssemblyManager::applyDbcDiag(double *crs_vals) {
+  requireReady(true);
+  MHA_REQUIRE(crs_vals != nullptr, MHA_ERR_INVALID, "crs_vals is null");
+  launch_dbc_diag(blockDev(), crs_vals, stream_);
+}
+
+void AssemblyManager::gather(const double *vec, double *elem_vals) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  MHA_REQUIRE(vec && elem_vals, MHA_ERR_INVALID, "null pointer");
+  launch_gather(blockDev(), vec, elem_vals, stream_);
+}
+
+int AssemblyManager::numWorksets() const {
+  if (!has_mesh_) return 0;
+  return (nelem_ + wkset_.maxElem - 1) / wkset_.maxElem;
+}
+
+// reference: updateWorkset<EvalT> pointing the workset at group `index` (assemblyManager.cpp:6512-6596)
+void AssemblyManager::worksetUpdate(int index) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  MHA_REQUIRE(index >= 0 && index < numWorksets(), MHA_ERR_INVALID, "workset index out of range");
+  wkset_.dev = blockDev();
+  wkset_.stream = stream_;
+  wkset_.first_elem = index * wkset_.maxElem;
+  wkset_.numElem = std::min(wkset_.maxElem, nelem_ - wkset_.first_elem);
+  wkset_.update_views();
+}
+
+int64_t AssemblyManager::info(const std::string &key) const {
+  if (key == "num_elems") return nelem_;
+  if (key == "num_rows") return nrows_;
+  if (key == "nnz") return has_graph_ ? h_rowptr_[nrows_] : 0;
+  if (key == "dofs_per_elem") return n_;
+  if (key == "num_ip") return nq_;
+  if (key == "last_path") return last_path_;
+  if (key == "workset_size") return wkset_.maxElem;
+  throw Error(MHA_ERR_INVALID, "unknown info key '" + key + "'");
+}
+
+}  // namespace mha

@@ -1,0 +1,87 @@
+// assembly_manager.hpp -- host orchestration of one element block on one GPU.
+//
+// Plays the role of AssemblyManager for the volume terms of a block (reference:
+// src/managers/assemblyManager.hpp:173-239, src/managers/assemblyManager.cpp:2150-2665):
+// owns the block's mesh/map copies on the device, the reference tables, the physics module, the
+// function table and the workset; assembleJacRes drives gather -> residual/Jacobian -> scatter.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "physics.hpp"
+#include "ref_tables.hpp"
+#include "workset.hpp"
+
+namespace mha {
+
+class AssemblyManager {
+ public:
+  explicit AssemblyManager(const mha_block_desc &desc);
+  ~AssemblyManager();
+
+  void setStream(hipStream_t s) { stream_ = s; wkset_.stream = s; }
+  void setMesh(int nelem, const double *nodes, const int32_t *lids, const int32_t *offsets, int nrows,
+               const uint8_t *fixed);
+  void setGraph(const int32_t *rowptr, const int32_t *colind);
+  void selectPhysics(int physics_id);
+  void setFunction(const std::string &name, int kind, double amp, const double *freq3, const double *ip_dev);
+  void setTimeIntegration(int transient, int nsteps, int nstages, int stage, double dt, const double *A,
+                          const double *b, const double *bdf);
+
+  void assembleJacRes(int compute_jacobian, int path, const double *u, const double *u_prev,
+                      const double *u_stage, double *res, double *crs_vals);
+  void computeLocalJacRes(int compute_jacobian, const double *u, const double *u_prev, const double *u_stage,
+                          double *local_J, double *local_res);
+  void scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals);
+  void applyDbcDiag(double *crs_vals);
+  void gather(const double *vec, double *elem_vals);
+
+  int numWorksets() const;
+  void worksetUpdate(int index);
+  View worksetView(const std::string &name) const { return wkset_.get(name); }
+
+  int64_t info(const std::string &key) const;
+  void setTiming(bool on) { timing_ = on; }
+  double lastKernelMs() const { return last_ms_; }
+
+  const std::vector<int32_t> &rowptr() const { return h_rowptr_; }
+  const std::vector<int32_t> &colind() const { return h_colind_; }
+  int numRows() const { return nrows_; }
+
+ private:
+  void requireReady(bool need_graph) const;
+  BlockDev blockDev() const;
+  void bindState(const double *u, const double *u_prev, const double *u_stage);
+  void timedBegin();
+  void timedEnd();
+
+  int dim_ = 0, order_ = 0, qdeg_ = 0, n_ = 0, nq_ = 0, nnodes_ = 0;
+  int nelem_ = 0, nrows_ = 0, workset_size_ = 0;
+  bool has_mesh_ = false, has_graph_ = false;
+  int last_path_ = 0;
+  hipStream_t stream_ = nullptr;
+
+  RefTables ref_;
+  DeviceBuffer<double> d_ref_basis_, d_ref_grad_, d_ref_wts_, d_nodeval_, d_nodegrad_;
+  DeviceBuffer<double> d_nodes_;
+  DeviceBuffer<int32_t> d_lids_, d_offsets_, d_rowptr_, d_colind_;
+  DeviceBuffer<uint8_t> d_fixed_;
+  std::vector<int32_t> h_lids_, h_rowptr_, h_colind_;
+  bool has_fixed_ = false;
+
+  // scratch of the two-step (updateJac/scatterJac) path, one workset wide
+  DeviceBuffer<double> d_local_J_, d_local_res_;
+
+  std::unique_ptr<PhysicsBase> physics_;
+  FunctionManager functions_;
+  Workset wkset_;
+  TimeDev time_;
+
+  bool timing_ = false;
+  double last_ms_ = 0.0;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+};
+
+}  // namespace mha

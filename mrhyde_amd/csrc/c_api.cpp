@@ -1,0 +1,182 @@
+// c_api.cpp -- extern "C" boundary (include/mrhyde_amd.h) over the C++ host layer.
+#include <cstring>
+#include <string>
+
+#include "assembly_manager.hpp"
+#include "mesh.hpp"
+
+struct mha_context {
+  mha::AssemblyManager mgr;
+  explicit mha_context(const mha_block_desc &d) : mgr(d) {}
+};
+
+namespace {
+thread_local std::string g_last_error;
+
+template <class F>
+int guarded(F &&f) {
+  try {
+    f();
+    g_last_error.clear();
+    return MHA_OK;
+  } catch (const mha::Error &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return MHA_ERR_INVALID;
+  } catch (...) {
+    g_last_error = "unknown error";
+    return MHA_ERR_INVALID;
+  }
+}
+
+mha::AssemblyManager &mgr(mha_context *ctx) {
+  MHA_REQUIRE(ctx != nullptr, MHA_ERR_INVALID, "null context");
+  return ctx->mgr;
+}
+}  // namespace
+
+extern "C" {
+
+const char *mha_last_error(void) { return g_last_error.c_str(); }
+const char *mha_version(void) { return "mrhyde_amd 0.1 (gfx950)"; }
+
+int mha_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mha_block_create(const mha_block_desc *desc, mha_context **out) {
+  return guarded([&] {
+    MHA_REQUIRE(desc && out, MHA_ERR_INVALID, "null argument");
+    *out = nullptr;
+    *out = new mha_context(*desc);
+  });
+}
+
+void mha_block_destroy(mha_context *ctx) { delete ctx; }
+
+int mha_set_stream(mha_context *ctx, void *hip_stream) {
+  return guarded([&] { mgr(ctx).setStream(static_cast<hipStream_t>(hip_stream)); });
+}
+
+int mha_set_mesh(mha_context *ctx, int num_elems, const double *nodes, const int32_t *lids, const int32_t *offsets,
+                 int num_rows, const uint8_t *is_fixed) {
+  return guarded([&] { mgr(ctx).setMesh(num_elems, nodes, lids, offsets, num_rows, is_fixed); });
+}
+
+int mha_set_graph(mha_context *ctx, const int32_t *rowptr, const int32_t *colind) {
+  return guarded([&] { mgr(ctx).setGraph(rowptr, colind); });
+}
+
+int mha_get_graph_sizes(mha_context *ctx, int *num_rows, int64_t *nnz) {
+  return guarded([&] {
+    MHA_REQUIRE(num_rows && nnz, MHA_ERR_INVALID, "null argument");
+    *num_rows = mgr(ctx).numRows();
+    *nnz = mgr(ctx).info("nnz");
+  });
+}
+
+int mha_get_graph(mha_context *ctx, int32_t *rowptr, int32_t *colind) {
+  return guarded([&] {
+    auto &m = mgr(ctx);
+    MHA_REQUIRE(!m.rowptr().empty(), MHA_ERR_STATE, "no CRS graph: call mha_set_graph first");
+    MHA_REQUIRE(rowptr && colind, MHA_ERR_INVALID, "null argument");
+    std::memcpy(rowptr, m.rowptr().data(), m.rowptr().size() * sizeof(int32_t));
+    std::memcpy(colind, m.colind().data(), m.colind().size() * sizeof(int32_t));
+  });
+}
+
+int mha_physics_select(mha_context *ctx, int physics_id) {
+  return guarded([&] { mgr(ctx).selectPhysics(physics_id); });
+}
+
+int mha_set_function(mha_context *ctx, const char *name, int kind, double amp, const double *freq3,
+                     const double *ip_array_dev) {
+  return guarded([&] {
+    MHA_REQUIRE(name != nullptr, MHA_ERR_INVALID, "null function name");
+    mgr(ctx).setFunction(name, kind, amp, freq3, ip_array_dev);
+  });
+}
+
+int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int num_stages, int stage,
+                             double deltat, const double *A, const double *b, const double *bdf) {
+  return guarded([&] { mgr(ctx).setTimeIntegration(transient, num_steps, num_stages, stage, deltat, A, b, bdf); });
+}
+
+int mha_assemble_jacres(mha_context *ctx, int compute_jacobian, int path, const double *u, const double *u_prev,
+                        const double *u_stage, double *res, double *crs_vals) {
+  return guarded([&] { mgr(ctx).assembleJacRes(compute_jacobian, path, u, u_prev, u_stage, res, crs_vals); });
+}
+
+int mha_compute_local_jacres(mha_context *ctx, int compute_jacobian, const double *u, const double *u_prev,
+                             const double *u_stage, double *local_J, double *local_res) {
+  return guarded([&] { mgr(ctx).computeLocalJacRes(compute_jacobian, u, u_prev, u_stage, local_J, local_res); });
+}
+
+int mha_scatter_local(mha_context *ctx, const double *local_J, const double *local_res, double *res,
+                      double *crs_vals) {
+  return guarded([&] { mgr(ctx).scatterLocal(local_J, local_res, res, crs_vals); });
+}
+
+int mha_apply_dbc_diag(mha_context *ctx, double *crs_vals) {
+  return guarded([&] { mgr(ctx).applyDbcDiag(crs_vals); });
+}
+
+int mha_gather(mha_context *ctx, const double *vec, double *elem_vals) {
+  return guarded([&] { mgr(ctx).gather(vec, elem_vals); });
+}
+
+int mha_num_worksets(mha_context *ctx) { return ctx ? ctx->mgr.numWorksets() : 0; }
+
+int mha_workset_update(mha_context *ctx, int index) {
+  return guarded([&] { mgr(ctx).worksetUpdate(index); });
+}
+
+int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t extents[4], int *rank) {
+  return guarded([&] {
+    MHA_REQUIRE(name && dev_ptr && extents && rank, MHA_ERR_INVALID, "null argument");
+    const mha::View v = mgr(ctx).worksetView(name);
+    *dev_ptr = v.ptr;
+    *rank = v.rank;
+    for (int k = 0; k < 4; ++k) extents[k] = v.extent[k];
+  });
+}
+
+int mha_mesh_sizes(int dim, int order, const int *ncell, int *nverts, int *nelem, int64_t *ndof) {
+  return guarded([&] {
+    MHA_REQUIRE(ncell && nverts && nelem && ndof, MHA_ERR_INVALID, "null argument");
+    mha::mesh_sizes(dim, order, ncell, nverts, nelem, ndof);
+  });
+}
+
+int mha_mesh_structured(int dim, int order, const int *ncell, const double *lo, const double *hi, double *verts,
+                        int32_t *cell2vert, int32_t *lids, int32_t *offsets, uint8_t *boundary_dof) {
+  return guarded([&] {
+    MHA_REQUIRE(ncell && lo && hi && verts && cell2vert && lids && offsets, MHA_ERR_INVALID, "null argument");
+    MHA_REQUIRE(order >= 1 && order <= 8, MHA_ERR_INVALID, "HGRAD order must be in [1,8]");
+    mha::mesh_structured(dim, order, ncell, lo, hi, verts, cell2vert, lids, offsets, boundary_dof);
+  });
+}
+
+int mha_get_info(mha_context *ctx, const char *key, int64_t *value) {
+  return guarded([&] {
+    MHA_REQUIRE(key && value, MHA_ERR_INVALID, "null argument");
+    *value = mgr(ctx).info(key);
+  });
+}
+
+int mha_set_timing(mha_context *ctx, int enable) {
+  return guarded([&] { mgr(ctx).setTiming(enable != 0); });
+}
+
+int mha_get_last_kernel_ms(mha_context *ctx, double *ms) {
+  return guarded([&] {
+    MHA_REQUIRE(ms != nullptr, MHA_ERR_INVALID, "null argument");
+    *ms = mgr(ctx).lastKernelMs();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// device_types.hpp -- plain structs handed to the HIP kernels by value (host + device).
+#pragma once
+#include <cstdint>
+
+namespace mha {
+
+constexpr int kMaxStages = 8;
+constexpr int kMaxSteps = 8;
+
+// What FunctionManager::evaluate(name,"ip") yields for one named function
+// (reference: src/managers/functionManager.cpp:543-760): constant, per-ip data, or a closed form.
+struct FuncDesc {
+  int kind = 0;            // MHA_FUNC_*
+  double amp = 0.0;
+  double freq[3] = {0, 0, 0};
+  const double *ip = nullptr;  // [E][numip] device
+};
+
+// Device view of one element block.
+struct BlockDev {
+  int dim = 0, nelem = 0, nrows = 0, n = 0, nq = 0, nnodes = 0;
+  int e_begin = 0, e_count = 0;      // element range a launch works on (a workset, or all)
+  const double *nodes = nullptr;     // [E][nnodes][dim]
+  const int32_t *lids = nullptr;     // [E][n]
+  const int32_t *offsets = nullptr;  // [n]  (variable 0)
+  const uint8_t *fixed = nullptr;    // [nrows] or null
+  const int32_t *rowptr = nullptr;   // [nrows+1]
+  const int32_t *colind = nullptr;   // [nnz]
+  // reference tables (device copies)
+  const double *ref_basis = nullptr;   // [n][nq]
+  const double *ref_grad = nullptr;    // [n][nq][dim]
+  const double *ref_wts = nullptr;     // [nq]
+  const double *nodeval = nullptr;     // [nnodes][nq]
+  const double *nodegrad = nullptr;    // [nnodes][nq][dim]
+};
+
+// Time-integration coefficients of Workset::computeSolnTransientSeeded, seedwhat == 1
+// (reference: src/tools/workset.cpp:589-623).
+struct TimeDev {
+  int transient = 0, nsteps = 0, nstages = 0, stage = 0;
+  double alpha_u = 1.0, alpha_t = 0.0, timewt = 0.0;
+  double stage_ratio[kMaxStages] = {0};  // A(stage,s)/b(s), s < stage
+  double bdf[kMaxSteps + 1] = {0};
+  const double *u = nullptr;        // [nrows] current (stage) solution
+  const double *u_prev = nullptr;   // [nrows][nsteps]
+  const double *u_stage = nullptr;  // [nrows][nstages]
+};
+
+struct ThermalDev {
+  FuncDesc source, diff, cp, rho;
+  TimeDev time;
+};
+
+// Where an element kernel puts its results.
+struct ElemOut {
+  int compute_jacobian = 1;
+  int local_base = 0;           // element id stored at local_J[0] / local_res[0]
+  double *local_J = nullptr;    // [E][n][n]   (updateJac convention, +=)
+  double *local_res = nullptr;  // [E][n]      (updateRes convention, -=)
+  double *res = nullptr;        // [nrows]     atomic scatter of -res.val()
+  double *crs_vals = nullptr;   // [nnz]       atomic scatter of +res.dx()
+};
+
+}  // namespace mha

@@ -1,0 +1,30 @@
+// launch.hpp -- host-callable launchers of the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../common.hpp"
+#include "device_types.hpp"
+
+namespace mha {
+
+// thermal_element.hip
+bool thermal_element_supported(int dim, int order, int nq1);
+void launch_thermal_element(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph,
+                            const ElemOut &out, hipStream_t stream);
+
+// scatter.hip
+void launch_scatter_local(const BlockDev &b, const double *local_J, const double *local_res, double *res,
+                          double *crs_vals, int local_base, hipStream_t stream);
+void launch_dbc_diag(const BlockDev &b, double *crs_vals, hipStream_t stream);
+void launch_gather(const BlockDev &b, const double *vec, double *elem_vals, hipStream_t stream);
+
+// workset_views.hip: physical basis / integration data of elements [e0, e0+ne)
+struct WorksetViewsDev {
+  double *basis = nullptr;       // [ne][n][nq]
+  double *basis_grad = nullptr;  // [ne][n][nq][dim]
+  double *wts = nullptr;         // [ne][nq]
+  double *xyz[3] = {nullptr, nullptr, nullptr};  // [ne][nq] each
+};
+void launch_workset_views(const BlockDev &b, int e0, int ne, const WorksetViewsDev &v, hipStream_t stream);
+
+}  // namespace mha

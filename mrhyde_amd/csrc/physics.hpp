@@ -1,0 +1,72 @@
+// physics.hpp -- physics-module operator API of the MI355X path.
+//
+// Mirrors template<class EvalT> class PhysicsBase (reference: src/physics/physicsBase.hpp:30-205):
+// modules are created by name, get a FunctionManager-like table of named coefficient functions
+// through defineFunctions(), are pointed at a Workset with setWorkset(), and expose
+// volumeResidual() / boundaryResidual() / faceResidual() / computeFlux() with no arguments and
+// no return value -- all I/O goes through the workset.  There is one instance per block instead of
+// one per EvalT: the derivative array (EvalT = SFad<W>) is produced inside the kernel.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "workset.hpp"
+
+namespace mha {
+
+// The slice of FunctionManager<EvalT> the functors use: evaluate(name,"ip")
+// (reference: src/managers/functionManager.cpp:543-760).  A function is a constant, per-ip data,
+// or a member of a small closed family evaluated at the physical integration points.
+class FunctionManager {
+ public:
+  void addFunction(const std::string &name, const FuncDesc &f) { funcs_[name] = f; }
+  bool has(const std::string &name) const { return funcs_.count(name) != 0; }
+  const FuncDesc &evaluate(const std::string &name) const {
+    auto it = funcs_.find(name);
+    // reference: TEUCHOS_TEST_FOR_EXCEPTION "function manager could not evaluate" (functionManager.cpp:573)
+    MHA_REQUIRE(it != funcs_.end(), MHA_ERR_INVALID, "function manager could not evaluate: " << name);
+    return it->second;
+  }
+
+ private:
+  std::map<std::string, FuncDesc> funcs_;
+};
+
+class PhysicsBase {
+ public:
+  virtual ~PhysicsBase() = default;
+  virtual void defineFunctions(FunctionManager &fm) { functionManager = &fm; }
+  virtual void volumeResidual() { notImplemented("volumeResidual"); }
+  virtual void boundaryResidual() { notImplemented("boundaryResidual"); }
+  virtual void faceResidual() { notImplemented("faceResidual"); }
+  virtual void computeFlux() { notImplemented("computeFlux"); }
+  virtual void setWorkset(Workset *w) { wkset = w; }
+
+  std::string label;
+  Workset *wkset = nullptr;
+  FunctionManager *functionManager = nullptr;
+  std::vector<std::string> myvars, mybasistypes;
+
+ protected:
+  // the reference prints a message for un-overridden hooks (physicsBase.cpp); we raise
+  void notImplemented(const char *what) const {
+    throw Error(MHA_ERR_INVALID, "physics module '" + label + "' does not implement " + what);
+  }
+};
+
+// thermal: rho*cp*de/dt - div(kappa grad e) = source
+// (reference: src/physics/thermal.hpp, src/physics/thermal.cpp:24-165)
+class thermal : public PhysicsBase {
+ public:
+  thermal();
+  void defineFunctions(FunctionManager &fm) override;
+  void volumeResidual() override;
+  ThermalDev device_params() const;
+};
+
+// PhysicsImporter::import equivalent (reference: src/physics/physicsImporter.cpp:48-204)
+std::unique_ptr<PhysicsBase> import_physics(int physics_id);
+
+}  // namespace mha

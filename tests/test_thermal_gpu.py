@@ -1,0 +1,267 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): Jacobian entries within 1e-12 relative, integer maps bit-exact.
+"Relative" is measured against the largest magnitude in the same array (element matrix block /
+global CRS / residual vector), which is how an entry that is zero by cancellation is judged.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference")
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() / scale
+
+
+def perturbed(oracle, dim, order, ncell, seed, amp=0.15):
+    m = oracle.mesh_structured(dim, order, ncell)
+    rng = np.random.default_rng(seed)
+    v = m["verts"].copy()
+    interior = np.all((v > 1e-12) & (v < 1 - 1e-12), axis=1)
+    h = 1.0 / np.asarray(ncell, dtype=np.float64)
+    v[interior] += amp * h * rng.uniform(-1, 1, size=(interior.sum(), dim))
+    m["verts"] = v
+    m["nodes"] = np.ascontiguousarray(v[m["cell2vert"]])
+    return m
+
+
+def make_block(m, dim, order, qdeg, workset=100, fixed=None, graph=None):
+    import mrhyde_amd
+    blk = mrhyde_amd.Block(dim, order, quadrature=qdeg, workset_size=workset)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"], fixed)
+    if graph is None:
+        blk.set_graph()
+    else:
+        blk.set_graph(*graph)
+    return blk
+
+
+CASES = [  # dim, order, qdeg, ncell
+    (2, 1, 2, (7, 5)),
+    (2, 2, 4, (4, 3)),
+    (2, 4, 8, (3, 2)),
+    (3, 1, 2, (4, 3, 2)),
+    (3, 2, 4, (3, 3, 2)),
+]
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell", CASES)
+@pytest.mark.parametrize("path", ["element_atomic", "local_then_scatter"])
+def test_jacres_matches_oracle(oracle, dim, order, qdeg, ncell, path):
+    torch = _torch()
+    import mrhyde_amd
+    m = perturbed(oracle, dim, order, ncell, seed=3)
+    rng = np.random.default_rng(11)
+    u = rng.uniform(-1, 1, m["ndof"])
+    fixed = m["boundary"]
+    freq = [2 * np.pi] * dim
+    amp = 4.0 * dim * np.pi ** 2
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed,
+                                  workset_size=7, source=("sinprod", amp, freq), diff=1.7, want_local=True)
+    blk = make_block(m, dim, order, qdeg, workset=7, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+    blk.set_function("thermal source", ("sinprod", amp, freq))
+    blk.set_function("thermal diffusion", 1.7)
+    ud = torch.tensor(u, device="cuda")
+    res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+    p = {"element_atomic": mrhyde_amd.PATH_ELEMENT_ATOMIC, "local_then_scatter": mrhyde_amd.PATH_LOCAL_THEN_SCATTER}[path]
+    blk.assemble_jacres(ud, res, vals, path=p)
+    torch.cuda.synchronize()
+    assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+    # fixed rows untouched by the scatter, then unit diagonal
+    fr = np.flatnonzero(fixed)
+    v = vals.cpu().numpy()
+    for r in fr[:50]:
+        assert np.all(v[ref["rowptr"][r]:ref["rowptr"][r + 1]] == 0.0)
+    blk.apply_dbc_diag(vals)
+    torch.cuda.synchronize()
+    oracle.apply_dbc_diag(fixed, ref["rowptr"], ref["colind"], ref["crs_vals"])
+    assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell", CASES)
+def test_local_jacres_matches_oracle(oracle, dim, order, qdeg, ncell):
+    """updateJac / updateRes convention: element by element, entry by entry."""
+    torch = _torch()
+    m = perturbed(oracle, dim, order, ncell, seed=5)
+    rng = np.random.default_rng(12)
+    u = rng.uniform(-1, 1, m["ndof"])
+    E, n = m["lids"].shape
+    nq = oracle.ref_sizes(dim, order, qdeg)[1]
+    src = rng.uniform(-2, 2, (E, nq))
+    kap = rng.uniform(0.5, 2.0, (E, nq))
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, source=("array", src),
+                                  diff_ip=kap, want_local=True, want_crs=False, want_res=False)
+    blk = make_block(m, dim, order, qdeg)
+    blk.set_function("thermal source", torch.tensor(src, device="cuda"))
+    blk.set_function("thermal diffusion", torch.tensor(kap, device="cuda"))
+    ud = torch.tensor(u, device="cuda")
+    lJ = torch.zeros(E, n, n, dtype=torch.float64, device="cuda")
+    lr = torch.zeros(E, n, dtype=torch.float64, device="cuda")
+    blk.compute_local_jacres(ud, lJ, lr)
+    torch.cuda.synchronize()
+    J, r = lJ.cpu().numpy(), lr.cpu().numpy()
+    for e in range(E):
+        assert rel_err(J[e], ref["local_J"][e]) < RTOL, e
+    assert rel_err(r, ref["local_res"]) < RTOL
+    # residual-only (ScalarT) path leaves the Jacobian alone: assembleRes, assemblyManager.cpp:2946-3151
+    lJ.zero_(); lr.zero_()
+    blk.compute_local_jacres(ud, None, lr, compute_jacobian=False)
+    torch.cuda.synchronize()
+    assert rel_err(lr.cpu().numpy(), ref["local_res"]) < RTOL
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell,stage", [(2, 1, 2, (6, 5), 0), (3, 2, 4, (2, 3, 2), 1), (3, 1, 2, (3, 3, 3), 2)])
+def test_transient_seeding_matches_oracle(oracle, dim, order, qdeg, ncell, stage):
+    """computeSolnTransientSeeded (workset.cpp:589-623): 3-stage DIRK tableau, BDF-2 weights."""
+    torch = _torch()
+    m = perturbed(oracle, dim, order, ncell, seed=7)
+    rng = np.random.default_rng(13)
+    nd = m["ndof"]
+    u = rng.uniform(-1, 1, nd)
+    nsteps, nstages = 2, 3
+    A = np.array([[0.4358665215, 0, 0], [0.2820667392, 0.4358665215, 0], [1.208496649, -0.644363171, 0.4358665215]])
+    b = np.array([1.208496649, -0.644363171, 0.4358665215])
+    bdf = np.array([1.5, -2.0, 0.5])
+    tr = dict(u_prev=rng.uniform(-1, 1, (nd, nsteps)), u_stage=rng.uniform(-1, 1, (nd, nstages)), stage=stage,
+              butcher_A=A, butcher_b=b, bdf=bdf, dt=0.013)
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, transient=tr, rho=1.3,
+                                  cp=0.7, diff=0.9, source=("const", 0.4))
+    blk = make_block(m, dim, order, qdeg, graph=(ref["rowptr"], ref["colind"]))
+    blk.set_function("thermal source", 0.4)
+    blk.set_function("thermal diffusion", 0.9)
+    blk.set_function("density", 1.3)
+    blk.set_function("specific heat", 0.7)
+    blk.set_time_integration(True, nsteps, nstages, stage, 0.013, A, b, bdf)
+    t = lambda a: torch.tensor(a, device="cuda")
+    res = torch.zeros(nd, dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(t(u), res, vals, u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]))
+    torch.cuda.synchronize()
+    assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell", [(2, 1, 2, (5, 4)), (3, 2, 4, (2, 2, 3)), (3, 1, 2, (3, 2, 2))])
+def test_workset_views_match_oracle(oracle, dim, order, qdeg, ncell):
+    """basis / basis_grad / wts / x,y,z views of every workset (ragged last workset included)."""
+    _torch()
+    m = perturbed(oracle, dim, order, ncell, seed=9)
+    pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+    ws = 7
+    blk = make_block(m, dim, order, qdeg, workset=ws)
+    E = m["nelem"]
+    assert blk.num_worksets() == (E + ws - 1) // ws
+    for w in range(blk.num_worksets()):
+        blk.workset_update(w)
+        e0, e1 = w * ws, min(E, (w + 1) * ws)
+        b = blk.workset_view_numpy("basis")
+        assert b.shape == (e1 - e0, m["lids"].shape[1], pb["basis"].shape[2], 1)
+        assert rel_err(b[..., 0], pb["basis"][e0:e1]) < RTOL
+        assert rel_err(blk.workset_view_numpy("basis_grad"), pb["basis_grad"][e0:e1]) < RTOL
+        assert rel_err(blk.workset_view_numpy("wts"), pb["wts"][e0:e1]) < RTOL
+        for k, name in enumerate("xyz"[:dim]):
+            assert rel_err(blk.workset_view_numpy(name), pb["ip"][e0:e1, :, k]) < RTOL
+        assert np.array_equal(blk.workset_view_numpy("LIDs"), m["lids"][e0:e1])  # integer map bit-exact
+    assert np.array_equal(blk.workset_view_numpy("offsets")[0], m["offsets"])
+    import mrhyde_amd
+    with pytest.raises(mrhyde_amd.MhaError) as ei:
+        blk.workset_view("grad(q)[x]")
+    assert ei.value.code == 4
+
+
+def test_hgrad_gold_through_device_views():
+    """The reference's own basis gold (regression/discretization/HGRAD) read back from the device views."""
+    _torch()
+    import mrhyde_amd
+    txt = open(os.path.join(GOLD, "discretization_HGRAD.gold")).read()
+    vals = re.findall(r"^dof (\d+), point (\d+): ([-0-9.e]+)$", txt, flags=re.M)
+    grads = re.findall(r"^dof (\d+), point (\d+) grad: \(([-0-9.e,]+)\)$", txt, flags=re.M)
+    for dim, nv in ((2, vals[:16]), (3, vals[16:])):
+        m = mrhyde_amd.mesh_structured(dim, 1, (1,) * dim)
+        blk = make_block(m, dim, 1, 2)
+        blk.workset_update(0)
+        b = blk.workset_view_numpy("basis")
+        g = blk.workset_view_numpy("basis_grad")
+        for dof, pt, v in nv:
+            assert float("%.6g" % b[0, int(dof), int(pt), 0]) == float(v)
+        for dof, pt, tup in grads:
+            comp = [float(x) for x in tup.split(",")]
+            if len(comp) != dim:
+                continue
+            for d in range(dim):
+                assert float("%.6g" % g[0, int(dof), int(pt), d]) == comp[d]
+
+
+def test_gather_bit_exact(oracle):
+    torch = _torch()
+    m = oracle.mesh_structured(3, 2, (3, 2, 2))
+    blk = make_block(m, 3, 2, 4)
+    u = np.random.default_rng(1).uniform(-1, 1, m["ndof"])
+    out = torch.zeros(m["lids"].shape, dtype=torch.float64, device="cuda")
+    blk.gather(torch.tensor(u, device="cuda"), out)
+    torch.cuda.synchronize()
+    # data(e,dof) = u[LIDs(e, offsets(dof))]  (assemblyManager.cpp:3633-3641)
+    assert np.array_equal(out.cpu().numpy(), u[m["lids"][:, m["offsets"]]])
+
+
+def test_thermal_gold_end_to_end(oracle):
+    """regression/thermal/2D_verification: assemble on the GPU, solve on the host, L2 error = 0.00102776."""
+    torch = _torch()
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import mrhyde_amd
+    dim, order, qdeg = 2, 1, 2
+    m = mrhyde_amd.mesh_structured(dim, order, (40, 40))
+    blk = make_block(m, dim, order, qdeg, workset=100, fixed=m["boundary"])
+    freq = [2 * np.pi] * 2
+    blk.set_function("thermal source", ("sinprod", 8 * np.pi ** 2, freq))
+    rowptr, colind = blk.get_graph()
+    u = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    res = torch.zeros_like(u)
+    vals = torch.zeros(len(colind), dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(u, res, vals)
+    blk.apply_dbc_diag(vals)
+    torch.cuda.synchronize()
+    J = sp.csr_matrix((vals.cpu().numpy(), colind, rowptr), shape=(m["ndof"],) * 2)
+    du = spla.spsolve(J.tocsc(), res.cpu().numpy())
+    pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+    err = oracle.l2_error_sinprod(dim, order, qdeg, m["lids"], m["offsets"], pb, du, freq)
+    gold = float(re.search(r"for e = ([-0-9.e]+)", open(os.path.join(GOLD, "thermal_2D_verification.gold")).read()).group(1))
+    assert "%.6g" % err == "%.6g" % gold
+
+
+def test_error_behaviour_on_device():
+    torch = _torch()
+    import mrhyde_amd
+    m = mrhyde_amd.mesh_structured(2, 1, (3, 3))
+    blk = mrhyde_amd.Block(2, 1)
+    u = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    with pytest.raises(mrhyde_amd.MhaError) as ei:
+        blk.assemble_jacres(u, u.clone(), u.clone())
+    assert ei.value.code == 2  # no mesh yet
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+    with pytest.raises(mrhyde_amd.MhaError) as ei:
+        blk.assemble_jacres(u, u.clone(), u.clone())
+    assert ei.value.code == 2  # no graph yet
+    bad = m["lids"].copy()
+    bad[0, 0] = m["ndof"]
+    with pytest.raises(mrhyde_amd.MhaError) as ei:
+        blk.set_mesh(m["nodes"], bad, m["offsets"], m["ndof"])
+    assert ei.value.code == 1
