@@ -48,8 +48,28 @@ def synthetic_state(dim, order, ncell, lo, hi, seed):
     return np.prod(np.sin(2 * np.pi * xyz), axis=1) + 0.01 * rng.uniform(-1, 1, xyz.shape[0])
 
 
-def cpu_baseline(dim, order, qdeg, ncell_sample, threads, reps=2):
+def host_threads():
+    """Threads for the CPU baseline: the box's CPU share (affinity mask, cgroup quota, at most 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MHA_CPU_THREADS", "16"))))
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline(dim, order, qdeg, ncell_sample, threads, target_s=12.0, max_reps=8):
     """Oracle ("port" of the reference data flow) timed on the host cores on a bounded sample."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     m = oracle_lib.mesh_structured(dim, order, ncell_sample)
@@ -58,12 +78,15 @@ def cpu_baseline(dim, order, qdeg, ncell_sample, threads, reps=2):
     rowptr, colind = oracle_lib.build_graph(m["ndof"], m["lids"])
     freq = [2 * np.pi] * dim
     ts = []
-    for _ in range(reps):
+    reps = 1
+    while len(ts) < reps:
         t0 = time.perf_counter()
         oracle_lib.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=m["boundary"],
                                     pb=pb, workset_size=100, source=("sinprod", 4.0 * dim * np.pi ** 2, freq),
                                     num_threads=threads, rowptr=rowptr, colind=colind)
         ts.append(time.perf_counter() - t0)
+        if len(ts) == 1:  # size the repetition count so that about target_s of CPU work is timed
+            reps = int(min(max_reps, max(2, np.ceil(target_s / max(ts[0], 1e-3)))))
     t = float(np.median(ts))
     return {"value": m["nelem"] / t, "unit": "elements/s", "cores": threads, "kind": "port",
             "sample": "%s Q%d hex elements (%d), workset 100, stored basis, AD width %d, median of %d" % (
@@ -81,7 +104,7 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "element_atomic", "row_owner", "local_then_scatter"])
     ap.add_argument("--mesh", default="affine", choices=["affine", "perturbed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-layers", type=int, default=16)
+    ap.add_argument("--cpu-sample-layers", type=int, default=0, help="z-layers of the CPU sample (0 = all)")
     args = ap.parse_args()
 
     import torch
@@ -125,8 +148,10 @@ def main():
         if rank < world - 1:
             f = fixed[-P:].reshape(order * args.ncell + 1, -1)
             f[1:-1, 1:-1] = 0
+    log("mesh generated: %d elements, %d dofs" % (E, nrows))
     blk.set_mesh(m["nodes"], m["lids"], m["offsets"], nrows, fixed)
     blk.set_graph()
+    log("mesh + graph on device")
     rowptr, colind = blk.get_graph()
     nnz = len(colind)
     freq = [2 * np.pi] * 3
@@ -140,9 +165,8 @@ def main():
             "row_owner": mrhyde_amd.PATH_ROW_OWNER, "local_then_scatter": mrhyde_amd.PATH_LOCAL_THEN_SCATTER}[args.path]
 
     def step():
-        res.zero_()
-        vals.zero_()
-        blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path)
+        # MHA_ASSEMBLE_OVERWRITE: the zeroing of res/J the Newton loop does before assembling is part of the step
+        blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path, overwrite=True)
         if exch is not None:
             exch.export_add(res, vals)
 
@@ -152,14 +176,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("state ready, nnz = %d" % nnz)
     for _ in range(args.warmup):
         step()
     fence()
+    log("warmup done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    log("timed %d steps: %.3f s" % (args.steps, elapsed))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -169,9 +196,7 @@ def main():
     blk.set_timing(True)
     kms = []
     for _ in range(max(3, min(args.steps, 10))):
-        res.zero_()
-        vals.zero_()
-        blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path)
+        blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path, overwrite=True)
         kms.append(blk.last_kernel_ms())
     blk.set_timing(False)
     kernel_ms = float(np.mean(kms))
@@ -191,6 +216,8 @@ def main():
                                    "volume Jacobian+residual assembled into CRS" % (order, args.ncell, args.mesh, qdeg),
                        "elements_per_gpu": E, "dofs_per_gpu": nrows, "nnz_per_gpu": nnz,
                        "path": {1: "element_atomic", 2: "row_owner", 3: "local_then_scatter"}.get(blk.info("last_path")),
+                       "affine_elements": blk.info("num_affine_elems"), "row_blocks": blk.info("row_blocks"),
+                       "row_owner_lds_bytes": blk.info("row_owner_lds_bytes"),
                        "partition": "z-slabs, 1 per GPU" if world > 1 else "single block",
                        "shared_row_bytes_per_step": exch.bytes_on_wire() if exch else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -198,8 +225,9 @@ def main():
                          "kernel_ms": kernel_ms, "bytes_per_elem": b_elem},
         }
         if not args.no_cpu_baseline:
-            threads = len(os.sched_getaffinity(0))
-            out["cpu_baseline"] = cpu_baseline(dim, order, qdeg, (args.ncell, args.ncell, args.cpu_sample_layers), threads)
+            threads = host_threads()
+            log("cpu baseline on %d threads" % threads)
+            out["cpu_baseline"] = cpu_baseline(dim, order, qdeg, (args.ncell, args.ncell, args.cpu_sample_layers or args.ncell), threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -115,16 +115,23 @@ int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int
  * replaces: AssemblyManager::assembleJacRes<EvalT>  assemblyManager.cpp:2150-2665
  *   (volume loop: performGather :3598, updateWorkset :6512, volumeResidual,
  *    scatter :4031) and assembleRes :2946-3151 (compute_jacobian = 0).
- * u_dev[nrows]; u_prev_dev[nrows][num_steps], u_stage_dev[nrows][num_stages] (transient only);
- * res_dev[nrows] and crs_vals_dev[nnz] are ACCUMULATED into (the caller zeroes them,
- * solverManager.cpp:1528-1533).  crs_vals_dev may be NULL iff !compute_jacobian.
+ * u_dev[nrows]; u_prev_dev[nrows][num_steps], u_stage_dev[nrows][num_stages] (transient only).
+ * flags: MHA_ASSEMBLE_JACOBIAN (seedwhat = 1: residual and Jacobian; without it the ScalarT
+ *   residual-only pass), MHA_ASSEMBLE_OVERWRITE (see below).
+ * res_dev[nrows] and crs_vals_dev[nnz] are ACCUMULATED into: the caller zeroes them first, as
+ * SolverManager does (solverManager.cpp:1528-1533).  With MHA_ASSEMBLE_OVERWRITE the call stores
+ * instead, i.e. it fuses that zeroing (res_over->putScalar(0), J_over->setAllToScalar(0)) into the
+ * assembly; use it when this call is the first contribution of the Newton step.
+ * crs_vals_dev may be NULL iff the Jacobian is not requested.
  * path: MHA_PATH_AUTO picks the fastest valid kernel; the others force one.          */
+#define MHA_ASSEMBLE_JACOBIAN 1
+#define MHA_ASSEMBLE_OVERWRITE 2
 #define MHA_PATH_AUTO 0
 #define MHA_PATH_ELEMENT_ATOMIC 1 /* per-element kernel, atomic scatter (reference's
                                      fused "assembly insert Jac" with useAtomics)     */
 #define MHA_PATH_ROW_OWNER 2      /* fused row-owner kernel, no global atomics           */
 #define MHA_PATH_LOCAL_THEN_SCATTER 3 /* updateJac/updateRes then scatterJac/scatterRes   */
-int mha_assemble_jacres(mha_context *ctx, int compute_jacobian, int path, const double *u_dev,
+int mha_assemble_jacres(mha_context *ctx, int flags, int path, const double *u_dev,
                         const double *u_prev_dev, const double *u_stage_dev, double *res_dev,
                         double *crs_vals_dev);
 /* replaces: updateJac / updateRes  assemblyManager.cpp:7412-7455, 7115-7152
@@ -164,9 +171,26 @@ int mha_mesh_structured(int dim, int order, const int *ncell, const double *lo, 
                         double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
                         uint8_t *boundary_dof);
 
+/* ---- row partition (host only; no GPU needed) -------------------------------------
+ * The fused kernel is row-owner: each CRS row is produced by exactly one workgroup that
+ * visits all elements incident to its rows -- the scatter of the reference
+ * (assemblyManager.cpp:4063-4144) without atomics.  These entry points expose the partition
+ * for inspection: blocks of rows (ascending) and the elements each block touches.
+ * caps[4] = {elements per Morton chunk, max CRS entries, max rows, max elements} or NULL.   */
+typedef struct mha_row_partition mha_row_partition;
+int mha_row_partition_build(int dim, int num_elems, int dofs_per_elem, int num_rows, const double *nodes_host,
+                            const int32_t *lids_host, const int32_t *rowptr_host, const int *caps,
+                            mha_row_partition **out);
+int mha_row_partition_sizes(const mha_row_partition *p, int *num_blocks, int64_t *num_rows, int64_t *num_elems,
+                            int *max_rows, int *max_elems, int *max_entries);
+int mha_row_partition_get(const mha_row_partition *p, int32_t *row_ptr, int32_t *rows, int32_t *elem_ptr,
+                          int32_t *elems);
+void mha_row_partition_destroy(mha_row_partition *p);
+
 /* ---- introspection for bench / tests ---------------------------------------------
- * keys: "num_elems","num_rows","nnz","dofs_per_elem","num_ip","num_affine_elems",
- *       "row_blocks","last_path"                                                       */
+ * keys: "num_elems","num_rows","nnz","dofs_per_elem","num_ip","workset_size","last_path",
+ *       "row_blocks","num_affine_elems","row_block_max_rows","row_block_max_elems",
+ *       "row_block_max_acc","row_owner_lds_bytes"                                      */
 int mha_get_info(mha_context *ctx, const char *key, int64_t *value);
 /* average device time (ms) of the last assembly's kernels, measured with HIP events on the
  * context's stream; valid after mha_set_timing(ctx,1).                                  */

@@ -20,7 +20,8 @@ EXPORTS = [
     "mha_set_function", "mha_set_time_integration", "mha_assemble_jacres", "mha_compute_local_jacres",
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
     "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_get_info", "mha_set_timing",
-    "mha_get_last_kernel_ms",
+    "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
+    "mha_row_partition_destroy",
 ]
 
 
@@ -50,6 +51,9 @@ def load_library():
         if not os.path.exists(_LIB):
             raise ImportError("%s is missing: run `make -C mrhyde_amd/csrc` (or __graft_entry__.build()); "
                               "there is no fallback path" % _LIB)
+        # PyTorch bundles its own libamdhip64 (same soname as /opt/rocm's): load torch first so the process
+        # holds exactly one HIP runtime, the one that owns torch's device memory and streams.
+        import torch  # noqa: F401
         _lib = C.CDLL(_LIB)
         _lib.mha_last_error.restype = C.c_char_p
         _lib.mha_version.restype = C.c_char_p
@@ -120,6 +124,34 @@ def mesh_structured(dim, order, ncell, lo=None, hi=None):
                                    vp(m["lids"]), vp(m["offsets"]), vp(m["boundary"])))
     m["nodes"] = np.ascontiguousarray(m["verts"][m["cell2vert"]])
     return m
+
+
+def row_partition(dim, nodes, lids, nrows, rowptr, caps=None):
+    """Host-only: the row-owner partition (mha_row_partition_*).  -> dict(row_ptr, rows, elem_ptr, elems, max_*)."""
+    lib = load_library()
+    nodes, lids, rowptr = _np(nodes, np.float64), _np(lids, np.int32), _np(rowptr, np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    h = C.c_void_p()
+    cp = None if caps is None else _np(caps, np.int32)
+    lib.mha_row_partition_build.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
+    _check(lib.mha_row_partition_build(dim, lids.shape[0], lids.shape[1], int(nrows), vp(nodes), vp(lids), vp(rowptr),
+                                       None if cp is None else vp(cp), C.byref(h)))
+    try:
+        nb, nr, ne = C.c_int(), C.c_int64(), C.c_int64()
+        mr, me, ma = C.c_int(), C.c_int(), C.c_int()
+        lib.mha_row_partition_sizes.argtypes = [C.c_void_p] * 7
+        _check(lib.mha_row_partition_sizes(h, C.byref(nb), C.byref(nr), C.byref(ne), C.byref(mr), C.byref(me),
+                                           C.byref(ma)))
+        out = dict(row_ptr=np.zeros(nb.value + 1, np.int32), rows=np.zeros(nr.value, np.int32),
+                   elem_ptr=np.zeros(nb.value + 1, np.int32), elems=np.zeros(ne.value, np.int32),
+                   max_rows=mr.value, max_elems=me.value, max_entries=ma.value, num_blocks=nb.value)
+        lib.mha_row_partition_get.argtypes = [C.c_void_p] * 5
+        _check(lib.mha_row_partition_get(h, vp(out["row_ptr"]), vp(out["rows"]), vp(out["elem_ptr"]), vp(out["elems"])))
+    finally:
+        lib.mha_row_partition_destroy.argtypes = [C.c_void_p]
+        lib.mha_row_partition_destroy.restype = None
+        lib.mha_row_partition_destroy(h)
+    return out
 
 
 class Block:
@@ -200,8 +232,9 @@ class Block:
 
     # -- assembly -----------------------------------------------------------
     def assemble_jacres(self, u, res, crs_vals=None, compute_jacobian=True, path=PATH_AUTO, u_prev=None,
-                        u_stage=None):
-        _check(load_library().mha_assemble_jacres(self._h, int(compute_jacobian), path, _ptr(u), _ptr(u_prev),
+                        u_stage=None, overwrite=False):
+        flags = (1 if compute_jacobian else 0) | (2 if overwrite else 0)
+        _check(load_library().mha_assemble_jacres(self._h, flags, path, _ptr(u), _ptr(u_prev),
                                                   _ptr(u_stage), _ptr(res), _ptr(crs_vals)))
 
     def compute_local_jacres(self, u, local_J, local_res, compute_jacobian=True, u_prev=None, u_stage=None):

@@ -100,6 +100,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   d_rowptr_.upload(h_rowptr_);
   d_colind_.upload(h_colind_);
   has_graph_ = true;
+  ro_ = RowOwnerData();
 }
 
 void AssemblyManager::selectPhysics(int physics_id) {
@@ -204,15 +205,33 @@ void AssemblyManager::timedEnd() {
 
 // reference: AssemblyManager::assembleJacRes<EvalT> volume loop (assemblyManager.cpp:2357-2509) and
 // assembleRes (:2946-3151) when compute_jacobian == 0.
-void AssemblyManager::assembleJacRes(int compute_jacobian, int path, const double *u, const double *u_prev,
+void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const double *u_prev,
                                      const double *u_stage, double *res, double *crs_vals) {
+  const int compute_jacobian = (flags & MHA_ASSEMBLE_JACOBIAN) ? 1 : 0;
+  const bool overwrite = (flags & MHA_ASSEMBLE_OVERWRITE) != 0;
   requireReady(true);
   MHA_REQUIRE(res != nullptr, MHA_ERR_INVALID, "residual vector is null");
   MHA_REQUIRE(!compute_jacobian || crs_vals, MHA_ERR_INVALID, "compute_jacobian set but crs_vals is null");
   bindState(u, u_prev, u_stage);
-  if (path == MHA_PATH_AUTO) path = MHA_PATH_ELEMENT_ATOMIC;
+  if (path == MHA_PATH_AUTO) {
+    if (!ro_.ready && thermal_row_owner_supported(dim_, order_, ref_.nq1)) prepareRowOwner();
+    path = rowOwnerUsable(nullptr) ? MHA_PATH_ROW_OWNER : MHA_PATH_ELEMENT_ATOMIC;
+  }
+  if (path == MHA_PATH_ROW_OWNER) {
+    if (!ro_.ready) prepareRowOwner();
+    std::string why;
+    MHA_REQUIRE(rowOwnerUsable(&why), MHA_ERR_INVALID, "row-owner path not available: " << why);
+  }
   timedBegin();
+  if (overwrite && !(path == MHA_PATH_ROW_OWNER && ro_.all_rows_covered)) {
+    // the accumulate-only kernels get the fused zeroing as an explicit memset on the same stream
+    MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
+    if (compute_jacobian) MHA_HIP(hipMemsetAsync(crs_vals, 0, sizeof(double) * h_rowptr_[nrows_], stream_));
+  }
   switch (path) {
+    case MHA_PATH_ROW_OWNER:
+      launchRowOwner(compute_jacobian != 0, overwrite && ro_.all_rows_covered, res, crs_vals);
+      break;
     case MHA_PATH_ELEMENT_ATOMIC: {
       // one launch over the whole block: the worksets of the reference are an execution detail
       // (sequential reuse of one Workset, assemblyManager.cpp:2355-2357) that does not change results
@@ -311,6 +330,141 @@ void AssemblyManager::worksetUpdate(int index) {
   wkset_.update_views();
 }
 
+// ---------------------------------------------------------------------------------------------
+// row-owner path
+// ---------------------------------------------------------------------------------------------
+
+void AssemblyManager::prepareRowOwner() {
+  requireReady(true);
+  MHA_REQUIRE(thermal_row_owner_supported(dim_, order_, ref_.nq1), MHA_ERR_INVALID,
+              "row-owner kernel: unsupported (dim,order,points/dir)");
+  RowOwnerData &ro = ro_;
+  const BlockDev b = blockDev();
+  // 1. element classification on the device
+  ro.flags.resize(nelem_);
+  launch_classify_affine(b, ro.flags.data(), 1e-14, stream_);
+  std::vector<uint8_t> flags(nelem_);
+  MHA_HIP(hipStreamSynchronize(stream_));
+  ro.flags.download(flags.data());
+  ro.num_affine_elems = 0;
+  for (int e = 0; e < nelem_; ++e) ro.num_affine_elems += flags[e];
+  // 2. row blocks
+  std::vector<double> nodes(static_cast<size_t>(nelem_) * nnodes_ * dim_);
+  d_nodes_.download(nodes.data());
+  RowBlockCaps caps = default_caps(dim_, n_);
+  // budget: two workgroups per CU (80 KiB each)
+  {
+    RowBlocksDev probe;
+    probe.lds_rows = caps.max_rows;
+    probe.lds_elems = 1;
+    probe.lds_acc = 0;
+    const size_t fixed_bytes = thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, probe);
+    probe.lds_elems = 2;
+    const size_t per_elem = thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, probe) - fixed_bytes;
+    const int neigh = (dim_ == 3) ? 27 : 25;  // touched elements of an aligned interior chunk
+    caps.max_elems = std::max(neigh, 8) + (dim_ == 3 ? 5 : 0);
+    const long budget = 80 * 1024 - 256 - static_cast<long>(fixed_bytes) - static_cast<long>(per_elem) * (caps.max_elems - 1);
+    MHA_REQUIRE(budget >= 8 * 512, MHA_ERR_INVALID, "row-owner kernel does not fit the LDS budget for this element");
+    caps.max_acc = static_cast<int>(budget / 8);
+  }
+  ro.rb = build_row_blocks(dim_, nnodes_, nelem_, n_, nrows_, nodes.data(), h_lids_.data(), h_rowptr_.data(), caps);
+  const RowBlocks &rb = ro.rb;
+  ro.row_ptr.upload(rb.row_ptr);
+  ro.rows.upload(rb.rows);
+  ro.row_off.upload(rb.row_off);
+  ro.acc_size.upload(rb.acc_size);
+  ro.elem_ptr.upload(rb.elem_ptr);
+  ro.elems.upload(rb.elems);
+  ro.all_rows_covered = static_cast<int>(rb.rows.size()) == nrows_;
+  // 3. block classification: affine blocks touch affine elements only
+  std::vector<int32_t> aff, gen;
+  for (int k = 0; k < rb.num_blocks; ++k) {
+    bool a = true;
+    for (int p = rb.elem_ptr[k]; p < rb.elem_ptr[k + 1] && a; ++p) a = flags[rb.elems[p]] != 0;
+    (a ? aff : gen).push_back(k);
+  }
+  ro.num_affine_blocks = static_cast<int>(aff.size());
+  ro.num_general_blocks = static_cast<int>(gen.size());
+  ro.affine_list.upload(aff);
+  ro.general_list.upload(gen);
+  // 4. element -> CRS slot map
+  int max_row = 0;
+  for (int r = 0; r < nrows_; ++r) max_row = std::max(max_row, h_rowptr_[r + 1] - h_rowptr_[r]);
+  MHA_REQUIRE(max_row <= 65536, MHA_ERR_INVALID, "CRS rows longer than 65536 entries are not supported");
+  ro.slot_bytes = max_row <= 256 ? 1 : 2;
+  ro.slot.resize(static_cast<size_t>(nelem_) * n_ * n_ * ro.slot_bytes);
+  launch_build_slot_map(b, ro.slot.data(), ro.slot_bytes, stream_);
+  // 5. reference tables of the affine path, in LID-slot space
+  const int nsym = dim_ * (dim_ + 1) / 2;
+  std::vector<double> khat(static_cast<size_t>(nsym + 1) * n_ * n_, 0.0);
+  std::vector<int32_t> offs(n_);
+  d_offsets_.download(offs.data());
+  for (int ib = 0; ib < n_; ++ib)
+    for (int jb = 0; jb < n_; ++jb) {
+      const size_t idx = static_cast<size_t>(offs[ib]) * n_ + offs[jb];
+      int k = 0;
+      for (int a = 0; a < dim_; ++a)
+        for (int c = a; c < dim_; ++c, ++k) {
+          double s = 0.0;
+          for (int q = 0; q < nq_; ++q) {
+            const double *gi = &ref_.grad[(static_cast<size_t>(ib) * nq_ + q) * dim_];
+            const double *gj = &ref_.grad[(static_cast<size_t>(jb) * nq_ + q) * dim_];
+            s += ref_.wts[q] * (a == c ? gi[a] * gj[a] : gi[a] * gj[c] + gi[c] * gj[a]);
+          }
+          khat[static_cast<size_t>(k) * n_ * n_ + idx] = s;
+        }
+      double m = 0.0;
+      for (int q = 0; q < nq_; ++q) m += ref_.wts[q] * ref_.basis[ib * nq_ + q] * ref_.basis[jb * nq_ + q];
+      khat[static_cast<size_t>(nsym) * n_ * n_ + idx] = m;
+    }
+  ro.khat.upload(khat);
+  ro.phi.upload(ref_.phi1d);
+  ro.dphi.upload(ref_.dphi1d);
+  ro.gw.upload(ref_.gauss_wts);
+  ro.gp.upload(ref_.gauss_pts);
+  MHA_HIP(hipStreamSynchronize(stream_));
+  ro.ready = true;
+}
+
+bool AssemblyManager::rowOwnerUsable(std::string *why) const {
+  auto fail = [&](const char *m) { if (why) *why = m; return false; };
+  if (!ro_.ready) return fail("partition not built (unsupported element?)");
+  if (ro_.num_general_blocks > 0) return fail("block has non-affine elements (general row-owner kernel not built yet)");
+  for (const char *name : {"thermal diffusion", "specific heat", "density"})
+    if (functions_.evaluate(name).kind != MHA_FUNC_CONSTANT) return fail("coefficient is not element-wise constant");
+  return true;
+}
+
+void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals) {
+  RowBlocksDev rb;
+  rb.num_blocks = ro_.rb.num_blocks;
+  rb.row_ptr = ro_.row_ptr.data();
+  rb.rows = ro_.rows.data();
+  rb.row_off = ro_.row_off.data();
+  rb.acc_size = ro_.acc_size.data();
+  rb.elem_ptr = ro_.elem_ptr.data();
+  rb.elems = ro_.elems.data();
+  rb.lds_rows = ro_.rb.max_rows;
+  rb.lds_elems = ro_.rb.max_elems;
+  rb.lds_acc = ro_.rb.max_acc;
+  AffineDev af;
+  af.khat = ro_.khat.data();
+  af.phi1d = ro_.phi.data();
+  af.dphi1d = ro_.dphi.data();
+  af.gw1d = ro_.gw.data();
+  af.gp1d = ro_.gp.data();
+  af.slot = ro_.slot.data();
+  af.slot_bytes = ro_.slot_bytes;
+  RowOut out;
+  out.res = res;
+  out.vals = crs_vals;
+  out.overwrite = overwrite ? 1 : 0;
+  out.compute_jacobian = compute_jacobian ? 1 : 0;
+  thermal *th = dynamic_cast<thermal *>(physics_.get());
+  MHA_REQUIRE(th != nullptr, MHA_ERR_INVALID, "row-owner path: physics module is not thermal");
+  launch_thermal_row_owner_affine(dim_, order_, ref_.nq1, blockDev(), th->device_params(), rb, af, out, stream_);
+}
+
 int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "num_elems") return nelem_;
   if (key == "num_rows") return nrows_;
@@ -319,6 +473,19 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "num_ip") return nq_;
   if (key == "last_path") return last_path_;
   if (key == "workset_size") return wkset_.maxElem;
+  if (key == "row_blocks") return ro_.ready ? ro_.rb.num_blocks : 0;
+  if (key == "num_affine_elems") return ro_.ready ? ro_.num_affine_elems : -1;
+  if (key == "row_block_max_rows") return ro_.rb.max_rows;
+  if (key == "row_block_max_elems") return ro_.rb.max_elems;
+  if (key == "row_block_max_acc") return ro_.rb.max_acc;
+  if (key == "row_owner_lds_bytes") {
+    if (!ro_.ready) return 0;
+    RowBlocksDev rb;
+    rb.lds_rows = ro_.rb.max_rows;
+    rb.lds_elems = ro_.rb.max_elems;
+    rb.lds_acc = ro_.rb.max_acc;
+    return static_cast<int64_t>(thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, rb));
+  }
   throw Error(MHA_ERR_INVALID, "unknown info key '" + key + "'");
 }
 

@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "physics.hpp"
 #include "ref_tables.hpp"
+#include "row_blocks.hpp"
 #include "workset.hpp"
 
 namespace mha {
@@ -30,7 +31,7 @@ class AssemblyManager {
   void setTimeIntegration(int transient, int nsteps, int nstages, int stage, double dt, const double *A,
                           const double *b, const double *bdf);
 
-  void assembleJacRes(int compute_jacobian, int path, const double *u, const double *u_prev,
+  void assembleJacRes(int flags, int path, const double *u, const double *u_prev,
                       const double *u_stage, double *res, double *crs_vals);
   void computeLocalJacRes(int compute_jacobian, const double *u, const double *u_prev, const double *u_stage,
                           double *local_J, double *local_res);
@@ -52,6 +53,9 @@ class AssemblyManager {
 
  private:
   void requireReady(bool need_graph) const;
+  void prepareRowOwner();
+  bool rowOwnerUsable(std::string *why) const;
+  void launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals);
   BlockDev blockDev() const;
   void bindState(const double *u, const double *u_prev, const double *u_stage);
   void timedBegin();
@@ -70,6 +74,18 @@ class AssemblyManager {
   DeviceBuffer<uint8_t> d_fixed_;
   std::vector<int32_t> h_lids_, h_rowptr_, h_colind_;
   bool has_fixed_ = false;
+
+  // row-owner path (row_blocks.hpp, kernels/thermal_row_owner.hip), built lazily
+  struct RowOwnerData {
+    bool ready = false;
+    RowBlocks rb;
+    DeviceBuffer<int32_t> row_ptr, rows, row_off, acc_size, elem_ptr, elems, affine_list, general_list;
+    DeviceBuffer<uint8_t> slot, flags;
+    DeviceBuffer<double> khat, phi, dphi, gw, gp;
+    int slot_bytes = 1;
+    int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
+    bool all_rows_covered = false;
+  } ro_;
 
   // scratch of the two-step (updateJac/scatterJac) path, one workset wide
   DeviceBuffer<double> d_local_J_, d_local_res_;

@@ -4,6 +4,11 @@
 
 #include "assembly_manager.hpp"
 #include "mesh.hpp"
+#include "row_blocks.hpp"
+
+struct mha_row_partition {
+  mha::RowBlocks rb;
+};
 
 struct mha_context {
   mha::AssemblyManager mgr;
@@ -106,9 +111,9 @@ int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int
   return guarded([&] { mgr(ctx).setTimeIntegration(transient, num_steps, num_stages, stage, deltat, A, b, bdf); });
 }
 
-int mha_assemble_jacres(mha_context *ctx, int compute_jacobian, int path, const double *u, const double *u_prev,
+int mha_assemble_jacres(mha_context *ctx, int flags, int path, const double *u, const double *u_prev,
                         const double *u_stage, double *res, double *crs_vals) {
-  return guarded([&] { mgr(ctx).assembleJacRes(compute_jacobian, path, u, u_prev, u_stage, res, crs_vals); });
+  return guarded([&] { mgr(ctx).assembleJacRes(flags, path, u, u_prev, u_stage, res, crs_vals); });
 }
 
 int mha_compute_local_jacres(mha_context *ctx, int compute_jacobian, const double *u, const double *u_prev,
@@ -160,6 +165,57 @@ int mha_mesh_structured(int dim, int order, const int *ncell, const double *lo, 
     mha::mesh_structured(dim, order, ncell, lo, hi, verts, cell2vert, lids, offsets, boundary_dof);
   });
 }
+
+int mha_row_partition_build(int dim, int num_elems, int n, int num_rows, const double *nodes, const int32_t *lids,
+                            const int32_t *rowptr, const int *caps, mha_row_partition **out) {
+  return guarded([&] {
+    MHA_REQUIRE(nodes && lids && rowptr && out, MHA_ERR_INVALID, "null argument");
+    MHA_REQUIRE((dim == 2 || dim == 3) && num_elems > 0 && n > 0 && num_rows > 0, MHA_ERR_INVALID, "bad sizes");
+    mha::RowBlockCaps c = mha::default_caps(dim, n);
+    if (caps) {
+      c.chunk_elems = caps[0];
+      c.max_acc = caps[1];
+      c.max_rows = caps[2];
+      c.max_elems = caps[3];
+    }
+    *out = nullptr;
+    auto *p = new mha_row_partition();
+    try {
+      p->rb = mha::build_row_blocks(dim, 1 << dim, num_elems, n, num_rows, nodes, lids, rowptr, c);
+    } catch (...) {
+      delete p;
+      throw;
+    }
+    *out = p;
+  });
+}
+
+int mha_row_partition_sizes(const mha_row_partition *p, int *num_blocks, int64_t *num_rows, int64_t *num_elems,
+                            int *max_rows, int *max_elems, int *max_entries) {
+  return guarded([&] {
+    MHA_REQUIRE(p && num_blocks && num_rows && num_elems && max_rows && max_elems && max_entries, MHA_ERR_INVALID,
+                "null argument");
+    *num_blocks = p->rb.num_blocks;
+    *num_rows = static_cast<int64_t>(p->rb.rows.size());
+    *num_elems = static_cast<int64_t>(p->rb.elems.size());
+    *max_rows = p->rb.max_rows;
+    *max_elems = p->rb.max_elems;
+    *max_entries = p->rb.max_acc;
+  });
+}
+
+int mha_row_partition_get(const mha_row_partition *p, int32_t *row_ptr, int32_t *rows, int32_t *elem_ptr,
+                          int32_t *elems) {
+  return guarded([&] {
+    MHA_REQUIRE(p && row_ptr && rows && elem_ptr && elems, MHA_ERR_INVALID, "null argument");
+    std::memcpy(row_ptr, p->rb.row_ptr.data(), p->rb.row_ptr.size() * sizeof(int32_t));
+    std::memcpy(rows, p->rb.rows.data(), p->rb.rows.size() * sizeof(int32_t));
+    std::memcpy(elem_ptr, p->rb.elem_ptr.data(), p->rb.elem_ptr.size() * sizeof(int32_t));
+    std::memcpy(elems, p->rb.elems.data(), p->rb.elems.size() * sizeof(int32_t));
+  });
+}
+
+void mha_row_partition_destroy(mha_row_partition *p) { delete p; }
 
 int mha_get_info(mha_context *ctx, const char *key, int64_t *value) {
   return guarded([&] {

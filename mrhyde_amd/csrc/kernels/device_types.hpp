@@ -61,4 +61,34 @@ struct ElemOut {
   double *crs_vals = nullptr;   // [nnz]       atomic scatter of +res.dx()
 };
 
+// Row-block partition on the device (row_blocks.hpp).
+struct RowBlocksDev {
+  int num_blocks = 0;
+  const int32_t *row_ptr = nullptr, *rows = nullptr, *row_off = nullptr, *acc_size = nullptr;
+  const int32_t *elem_ptr = nullptr, *elems = nullptr;
+  const int32_t *block_list = nullptr;  // blocks this launch handles (null = all)
+  int list_len = 0;
+  int lds_rows = 0, lds_elems = 0, lds_acc = 0;  // LDS carve sizes (maxima over the partition)
+};
+
+// Data of the affine fast path: reference stiffness / mass tables in LID-slot space and the
+// element -> CRS slot map.
+struct AffineDev {
+  const double *khat = nullptr;    // [NSYM+1][n*n]: sum_q w (d_a N_i d_b N_j + sym), last = sum_q w N_i N_j
+  const double *phi1d = nullptr;   // [order+1][nq1]
+  const double *dphi1d = nullptr;  // [order+1][nq1]
+  const double *gw1d = nullptr;    // [nq1]
+  const double *gp1d = nullptr;    // [nq1]
+  const void *slot = nullptr;      // [E][n][n] position of (row LIDs[e][i], col LIDs[e][j]) inside the CRS row
+  int slot_bytes = 1;              // 1 (uint8) or 2 (uint16)
+};
+
+// Destination of the row-owner kernels.
+struct RowOut {
+  double *res = nullptr;
+  double *vals = nullptr;
+  int overwrite = 0;         // 1: store (fuses the caller's zeroing), 0: accumulate
+  int compute_jacobian = 1;
+};
+
 }  // namespace mha

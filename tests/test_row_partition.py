@@ -1,0 +1,69 @@
+"""Host logic of the row-owner partition (no GPU): every row owned exactly once, every incident
+element of an owned row is in the block's element list, caps respected, aligned chunks on tensor meshes."""
+import numpy as np
+import pytest
+
+import mrhyde_amd
+
+
+def _check_partition(m, rowptr, part, caps=None):
+    nrows = m["ndof"]
+    rows = part["rows"]
+    assert len(rows) == nrows and np.array_equal(np.sort(rows), np.arange(nrows)), "each row owned exactly once"
+    inc = [[] for _ in range(nrows)]
+    for e, l in enumerate(m["lids"]):
+        for r in l:
+            inc[r].append(e)
+    for b in range(part["num_blocks"]):
+        br = rows[part["row_ptr"][b]:part["row_ptr"][b + 1]]
+        be = part["elems"][part["elem_ptr"][b]:part["elem_ptr"][b + 1]]
+        assert np.all(np.diff(br) > 0) and np.all(np.diff(be) > 0)
+        need = sorted(set(e for r in br for e in inc[r]))
+        assert need == be.tolist(), "block %d element list" % b
+        acc = int(sum(rowptr[r + 1] - rowptr[r] for r in br))
+        assert acc <= part["max_entries"] and len(br) <= part["max_rows"] and len(be) <= part["max_elems"]
+        if caps is not None:
+            assert acc <= caps[1] and len(br) <= caps[2] and len(be) <= caps[3]
+
+
+@pytest.mark.parametrize("dim,order,ncell", [(3, 2, (4, 4, 4)), (3, 2, (5, 3, 2)), (3, 1, (4, 4, 4)), (2, 1, (9, 7)),
+                                              (2, 4, (4, 4)), (2, 2, (8, 8))])
+def test_partition_covers_rows_and_elements(oracle, dim, order, ncell):
+    m = mrhyde_amd.mesh_structured(dim, order, ncell)
+    rowptr, _ = oracle.build_graph(m["ndof"], m["lids"])
+    part = mrhyde_amd.row_partition(dim, m["nodes"], m["lids"], m["ndof"], rowptr)
+    _check_partition(m, rowptr, part)
+
+
+def test_partition_aligned_chunks_on_tensor_mesh(oracle):
+    """64^3-style case in small: interior 2x2x2 element chunks own 64 rows / 4096 entries / touch 27 elements."""
+    m = mrhyde_amd.mesh_structured(3, 2, (8, 8, 8))
+    rowptr, _ = oracle.build_graph(m["ndof"], m["lids"])
+    part = mrhyde_amd.row_partition(3, m["nodes"], m["lids"], m["ndof"], rowptr, caps=[8, 4224, 128, 32])
+    _check_partition(m, rowptr, part, caps=[8, 4224, 128, 32])
+    nr = np.diff(part["row_ptr"])
+    ne = np.diff(part["elem_ptr"])
+    assert part["max_elems"] == 27
+    interior = (nr == 64) & (ne == 27)
+    assert interior.sum() == 8  # chunks touching neither the low nor the high faces: 2 of 4 per direction
+
+
+def test_partition_perturbed_and_shuffled_elements(oracle):
+    """Element numbering and vertex perturbation must not matter for validity."""
+    rng = np.random.default_rng(4)
+    m = mrhyde_amd.mesh_structured(3, 1, (5, 4, 3))
+    v = m["verts"] + 0.02 * rng.uniform(-1, 1, m["verts"].shape)
+    perm = rng.permutation(m["nelem"])
+    m["lids"] = np.ascontiguousarray(m["lids"][perm])
+    m["nodes"] = np.ascontiguousarray(v[m["cell2vert"][perm]])
+    rowptr, _ = oracle.build_graph(m["ndof"], m["lids"])
+    part = mrhyde_amd.row_partition(3, m["nodes"], m["lids"], m["ndof"], rowptr, caps=[8, 300, 16, 20])
+    _check_partition(m, rowptr, part, caps=[8, 300, 16, 20])
+
+
+def test_partition_rejects_impossible_caps(oracle):
+    m = mrhyde_amd.mesh_structured(2, 1, (3, 3))
+    rowptr, _ = oracle.build_graph(m["ndof"], m["lids"])
+    with pytest.raises(mrhyde_amd.MhaError) as ei:
+        mrhyde_amd.row_partition(2, m["nodes"], m["lids"], m["ndof"], rowptr, caps=[4, 4, 8, 8])
+    assert ei.value.code == 1 and "exceeds" in str(ei.value)

@@ -247,6 +247,129 @@ def test_thermal_gold_end_to_end(oracle):
     assert "%.6g" % err == "%.6g" % gold
 
 
+def affine_mesh(oracle, dim, order, ncell, shear=True):
+    """Structured mesh pushed through an affine map: every element is a (non-rectangular) parallelepiped."""
+    m = oracle.mesh_structured(dim, order, ncell)
+    if shear:
+        A = np.eye(dim) + 0.25 * np.array([[0.3, 0.8, -0.4], [-0.5, 0.2, 0.6], [0.7, -0.3, 0.1]])[:dim, :dim]
+        m["verts"] = m["verts"] @ A.T + 0.3
+        m["nodes"] = np.ascontiguousarray(m["verts"][m["cell2vert"]])
+    return m
+
+
+RO_CASES = [  # dim, order, qdeg, ncell
+    (2, 1, 2, (9, 7)),
+    (2, 2, 4, (6, 5)),
+    (2, 4, 8, (5, 4)),
+    (3, 1, 2, (5, 4, 3)),
+    (3, 2, 4, (5, 4, 6)),
+]
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell", RO_CASES)
+@pytest.mark.parametrize("mode", ["accumulate", "overwrite"])
+def test_row_owner_matches_oracle(oracle, dim, order, qdeg, ncell, mode):
+    """Fused row-owner kernel on affine (sheared) meshes vs the oracle: CRS values, residual, fixed rows."""
+    torch = _torch()
+    import mrhyde_amd
+    m = affine_mesh(oracle, dim, order, ncell)
+    rng = np.random.default_rng(21)
+    u = rng.uniform(-1, 1, m["ndof"])
+    fixed = m["boundary"]
+    freq = [1.3, 0.7, 2.1][:dim]
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed,
+                                  source=("sinprod", 3.0, freq), diff=1.7)
+    blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+    blk.set_function("thermal source", ("sinprod", 3.0, freq))
+    blk.set_function("thermal diffusion", 1.7)
+    ud = torch.tensor(u, device="cuda")
+    if mode == "overwrite":  # garbage in, every entry must be overwritten (fixed rows: zeros)
+        res = torch.full((m["ndof"],), 7.0, dtype=torch.float64, device="cuda")
+        vals = torch.full((len(ref["colind"]),), -3.0, dtype=torch.float64, device="cuda")
+    else:
+        res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+        vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(ud, res, vals, path=mrhyde_amd.PATH_ROW_OWNER, overwrite=(mode == "overwrite"))
+    torch.cuda.synchronize()
+    assert blk.info("num_affine_elems") == m["nelem"] and blk.info("last_path") == mrhyde_amd.PATH_ROW_OWNER
+    assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+    v = vals.cpu().numpy()
+    for r in np.flatnonzero(fixed)[:40]:
+        assert np.all(v[ref["rowptr"][r]:ref["rowptr"][r + 1]] == 0.0)
+    # accumulate semantics: a second call doubles everything
+    if mode == "accumulate":
+        blk.assemble_jacres(ud, res, vals, path=mrhyde_amd.PATH_ROW_OWNER)
+        torch.cuda.synchronize()
+        assert rel_err(vals.cpu().numpy(), 2 * ref["crs_vals"]) < RTOL
+        assert rel_err(res.cpu().numpy(), 2 * ref["res"]) < RTOL
+    # residual-only pass (assembleRes): Jacobian untouched
+    keep = vals.clone()
+    res.zero_()
+    blk.assemble_jacres(ud, res, vals, compute_jacobian=False, path=mrhyde_amd.PATH_ROW_OWNER)
+    torch.cuda.synchronize()
+    assert torch.equal(keep, vals)
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+
+
+def test_row_owner_transient_and_source_array(oracle):
+    torch = _torch()
+    import mrhyde_amd
+    dim, order, qdeg, ncell = 3, 2, 4, (3, 4, 3)
+    m = affine_mesh(oracle, dim, order, ncell)
+    rng = np.random.default_rng(23)
+    nd = m["ndof"]
+    u = rng.uniform(-1, 1, nd)
+    E = m["nelem"]
+    nq = oracle.ref_sizes(dim, order, qdeg)[1]
+    src = rng.uniform(-2, 2, (E, nq))
+    nsteps, nstages, stage = 2, 2, 1
+    A = np.array([[0.2928932188, 0.0], [0.7071067812, 0.2928932188]])
+    b = np.array([0.7071067812, 0.2928932188])
+    bdf = np.array([1.5, -2.0, 0.5])
+    tr = dict(u_prev=rng.uniform(-1, 1, (nd, nsteps)), u_stage=rng.uniform(-1, 1, (nd, nstages)), stage=stage,
+              butcher_A=A, butcher_b=b, bdf=bdf, dt=0.02)
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, transient=tr, rho=1.3,
+                                  cp=0.7, diff=0.9, source=("array", src), fixed=m["boundary"])
+    blk = make_block(m, dim, order, qdeg, fixed=m["boundary"], graph=(ref["rowptr"], ref["colind"]))
+    blk.set_function("thermal source", torch.tensor(src, device="cuda"))
+    blk.set_function("thermal diffusion", 0.9)
+    blk.set_function("density", 1.3)
+    blk.set_function("specific heat", 0.7)
+    blk.set_time_integration(True, nsteps, nstages, stage, 0.02, A, b, bdf)
+    t = lambda a: torch.tensor(a, device="cuda")
+    res = torch.zeros(nd, dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(t(u), res, vals, u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]), path=mrhyde_amd.PATH_ROW_OWNER)
+    torch.cuda.synchronize()
+    assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+
+
+def test_auto_path_selection(oracle):
+    """AUTO = row-owner on affine meshes with constant coefficients, element kernel otherwise; both correct."""
+    torch = _torch()
+    import mrhyde_amd
+    dim, order, qdeg, ncell = 3, 2, 4, (3, 3, 3)
+    for mesh_fn, expect in ((lambda: affine_mesh(oracle, dim, order, ncell), mrhyde_amd.PATH_ROW_OWNER),
+                            (lambda: perturbed(oracle, dim, order, ncell, seed=2), mrhyde_amd.PATH_ELEMENT_ATOMIC)):
+        m = mesh_fn()
+        u = np.random.default_rng(5).uniform(-1, 1, m["ndof"])
+        ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, source=("const", 1.0))
+        blk = make_block(m, dim, order, qdeg, graph=(ref["rowptr"], ref["colind"]))
+        blk.set_function("thermal source", 1.0)
+        res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+        vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True)
+        torch.cuda.synchronize()
+        assert blk.info("last_path") == expect
+        assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+        assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+        if expect == mrhyde_amd.PATH_ELEMENT_ATOMIC:
+            with pytest.raises(mrhyde_amd.MhaError):
+                blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, path=mrhyde_amd.PATH_ROW_OWNER)
+
+
 def test_error_behaviour_on_device():
     torch = _torch()
     import mrhyde_amd
