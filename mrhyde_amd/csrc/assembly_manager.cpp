@@ -1,6 +1,7 @@
 #include "assembly_manager.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "mesh.hpp"
@@ -73,6 +74,7 @@ void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lid
   d_lids_.upload(lids, nl);
   d_offsets_.upload(offsets, n_);
   has_fixed_ = fixed != nullptr;
+  if (fixed) h_fixed_.assign(fixed, fixed + nrows);
   if (fixed) d_fixed_.upload(fixed, nrows);
   else d_fixed_.resize(0);
   has_mesh_ = true;
@@ -351,23 +353,31 @@ void AssemblyManager::prepareRowOwner() {
   // 2. row blocks
   std::vector<double> nodes(static_cast<size_t>(nelem_) * nnodes_ * dim_);
   d_nodes_.download(nodes.data());
+  int max_row = 0;
+  for (int r = 0; r < nrows_; ++r) max_row = std::max(max_row, h_rowptr_[r + 1] - h_rowptr_[r]);
+  MHA_REQUIRE(max_row <= 65536, MHA_ERR_INVALID, "CRS rows longer than 65536 entries are not supported");
+  ro.slot_bytes = max_row <= 256 ? 1 : 2;
   RowBlockCaps caps = default_caps(dim_, n_);
-  // budget: two workgroups per CU (80 KiB each)
+  // LDS budget: two workgroups per CU (80 KiB each).  An aligned interior chunk touches 3^dim elements
+  // and owns (2*order)^dim rows; the accumulator gets whatever the fixed parts leave.
   {
+    const int neigh = (dim_ == 3) ? 27 : 25;
+    caps.max_elems = neigh;
+    caps.max_rows = 96;
+    caps.max_pairs = 256;
     RowBlocksDev probe;
     probe.lds_rows = caps.max_rows;
-    probe.lds_elems = 1;
+    probe.lds_elems = caps.max_elems;
+    probe.lds_pairs = caps.max_pairs;
     probe.lds_acc = 0;
-    const size_t fixed_bytes = thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, probe);
-    probe.lds_elems = 2;
-    const size_t per_elem = thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, probe) - fixed_bytes;
-    const int neigh = (dim_ == 3) ? 27 : 25;  // touched elements of an aligned interior chunk
-    caps.max_elems = std::max(neigh, 8) + (dim_ == 3 ? 5 : 0);
-    const long budget = 80 * 1024 - 256 - static_cast<long>(fixed_bytes) - static_cast<long>(per_elem) * (caps.max_elems - 1);
-    MHA_REQUIRE(budget >= 8 * 512, MHA_ERR_INVALID, "row-owner kernel does not fit the LDS budget for this element");
+    const long fixed_bytes =
+        static_cast<long>(thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, probe, ro.slot_bytes, false));
+    const long budget = 80 * 1024 - 256 - fixed_bytes;
+    MHA_REQUIRE(budget >= 8 * 2 * max_row, MHA_ERR_INVALID, "row-owner kernel does not fit the LDS budget for this element");
     caps.max_acc = static_cast<int>(budget / 8);
   }
-  ro.rb = build_row_blocks(dim_, nnodes_, nelem_, n_, nrows_, nodes.data(), h_lids_.data(), h_rowptr_.data(), caps);
+  ro.rb = build_row_blocks(dim_, nnodes_, nelem_, n_, nrows_, nodes.data(), h_lids_.data(), h_rowptr_.data(), caps,
+                           has_fixed_ ? h_fixed_.data() : nullptr);
   const RowBlocks &rb = ro.rb;
   ro.row_ptr.upload(rb.row_ptr);
   ro.rows.upload(rb.rows);
@@ -375,6 +385,8 @@ void AssemblyManager::prepareRowOwner() {
   ro.acc_size.upload(rb.acc_size);
   ro.elem_ptr.upload(rb.elem_ptr);
   ro.elems.upload(rb.elems);
+  ro.pair_ptr.upload(rb.pair_ptr);
+  ro.pairs.upload(rb.pairs);
   ro.all_rows_covered = static_cast<int>(rb.rows.size()) == nrows_;
   // 3. block classification: affine blocks touch affine elements only
   std::vector<int32_t> aff, gen;
@@ -387,13 +399,9 @@ void AssemblyManager::prepareRowOwner() {
   ro.num_general_blocks = static_cast<int>(gen.size());
   ro.affine_list.upload(aff);
   ro.general_list.upload(gen);
-  // 4. element -> CRS slot map
-  int max_row = 0;
-  for (int r = 0; r < nrows_; ++r) max_row = std::max(max_row, h_rowptr_[r + 1] - h_rowptr_[r]);
-  MHA_REQUIRE(max_row <= 65536, MHA_ERR_INVALID, "CRS rows longer than 65536 entries are not supported");
-  ro.slot_bytes = max_row <= 256 ? 1 : 2;
-  ro.slot.resize(static_cast<size_t>(nelem_) * n_ * n_ * ro.slot_bytes);
-  launch_build_slot_map(b, ro.slot.data(), ro.slot_bytes, stream_);
+  // 4. block-major slot table (position of every contribution inside its CRS row)
+  ro.slot.resize(std::max<size_t>(1, rb.pairs.size() * n_ * ro.slot_bytes));
+  launch_build_block_slots(b, rowBlocksDev(), ro.slot.data(), ro.slot_bytes, stream_);
   // 5. reference tables of the affine path, in LID-slot space
   const int nsym = dim_ * (dim_ + 1) / 2;
   std::vector<double> khat(static_cast<size_t>(nsym + 1) * n_ * n_, 0.0);
@@ -435,7 +443,7 @@ bool AssemblyManager::rowOwnerUsable(std::string *why) const {
   return true;
 }
 
-void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals) {
+RowBlocksDev AssemblyManager::rowBlocksDev() const {
   RowBlocksDev rb;
   rb.num_blocks = ro_.rb.num_blocks;
   rb.row_ptr = ro_.row_ptr.data();
@@ -444,9 +452,17 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   rb.acc_size = ro_.acc_size.data();
   rb.elem_ptr = ro_.elem_ptr.data();
   rb.elems = ro_.elems.data();
+  rb.pair_ptr = ro_.pair_ptr.data();
+  rb.pairs = ro_.pairs.data();
   rb.lds_rows = ro_.rb.max_rows;
   rb.lds_elems = ro_.rb.max_elems;
   rb.lds_acc = ro_.rb.max_acc;
+  rb.lds_pairs = ro_.rb.max_pairs;
+  return rb;
+}
+
+void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals) {
+  const RowBlocksDev rb = rowBlocksDev();
   AffineDev af;
   af.khat = ro_.khat.data();
   af.phi1d = ro_.phi.data();
@@ -460,6 +476,7 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   out.vals = crs_vals;
   out.overwrite = overwrite ? 1 : 0;
   out.compute_jacobian = compute_jacobian ? 1 : 0;
+  if (const char *dbg = std::getenv("MHA_DEBUG_SKIP")) out.debug_skip = std::atoi(dbg);  // profiling ablations only
   thermal *th = dynamic_cast<thermal *>(physics_.get());
   MHA_REQUIRE(th != nullptr, MHA_ERR_INVALID, "row-owner path: physics module is not thermal");
   launch_thermal_row_owner_affine(dim_, order_, ref_.nq1, blockDev(), th->device_params(), rb, af, out, stream_);
@@ -478,14 +495,9 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "row_block_max_rows") return ro_.rb.max_rows;
   if (key == "row_block_max_elems") return ro_.rb.max_elems;
   if (key == "row_block_max_acc") return ro_.rb.max_acc;
-  if (key == "row_owner_lds_bytes") {
-    if (!ro_.ready) return 0;
-    RowBlocksDev rb;
-    rb.lds_rows = ro_.rb.max_rows;
-    rb.lds_elems = ro_.rb.max_elems;
-    rb.lds_acc = ro_.rb.max_acc;
-    return static_cast<int64_t>(thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, rb));
-  }
+  if (key == "row_block_max_pairs") return ro_.rb.max_pairs;
+  if (key == "row_owner_lds_bytes")
+    return ro_.ready ? static_cast<int64_t>(thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, rowBlocksDev(), ro_.slot_bytes, time_.transient != 0)) : 0;
   throw Error(MHA_ERR_INVALID, "unknown info key '" + key + "'");
 }
 

@@ -56,6 +56,7 @@ class AssemblyManager {
   void prepareRowOwner();
   bool rowOwnerUsable(std::string *why) const;
   void launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals);
+  RowBlocksDev rowBlocksDev() const;
   BlockDev blockDev() const;
   void bindState(const double *u, const double *u_prev, const double *u_stage);
   void timedBegin();
@@ -73,13 +74,15 @@ class AssemblyManager {
   DeviceBuffer<int32_t> d_lids_, d_offsets_, d_rowptr_, d_colind_;
   DeviceBuffer<uint8_t> d_fixed_;
   std::vector<int32_t> h_lids_, h_rowptr_, h_colind_;
+  std::vector<uint8_t> h_fixed_;
   bool has_fixed_ = false;
 
   // row-owner path (row_blocks.hpp, kernels/thermal_row_owner.hip), built lazily
   struct RowOwnerData {
     bool ready = false;
     RowBlocks rb;
-    DeviceBuffer<int32_t> row_ptr, rows, row_off, acc_size, elem_ptr, elems, affine_list, general_list;
+    DeviceBuffer<int32_t> row_ptr, rows, row_off, acc_size, elem_ptr, elems, pair_ptr, affine_list, general_list;
+    DeviceBuffer<uint32_t> pairs;
     DeviceBuffer<uint8_t> slot, flags;
     DeviceBuffer<double> khat, phi, dphi, gw, gp;
     int slot_bytes = 1;

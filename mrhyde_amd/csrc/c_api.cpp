@@ -177,6 +177,7 @@ int mha_row_partition_build(int dim, int num_elems, int n, int num_rows, const d
       c.max_acc = caps[1];
       c.max_rows = caps[2];
       c.max_elems = caps[3];
+      c.max_pairs = c.max_rows * 8;
     }
     *out = nullptr;
     auto *p = new mha_row_partition();

@@ -66,9 +66,11 @@ struct RowBlocksDev {
   int num_blocks = 0;
   const int32_t *row_ptr = nullptr, *rows = nullptr, *row_off = nullptr, *acc_size = nullptr;
   const int32_t *elem_ptr = nullptr, *elems = nullptr;
+  const int32_t *pair_ptr = nullptr;
+  const uint32_t *pairs = nullptr;       // local_row << 16 | local_elem << 8 | LID slot
   const int32_t *block_list = nullptr;  // blocks this launch handles (null = all)
   int list_len = 0;
-  int lds_rows = 0, lds_elems = 0, lds_acc = 0;  // LDS carve sizes (maxima over the partition)
+  int lds_rows = 0, lds_elems = 0, lds_acc = 0, lds_pairs = 0;  // LDS carve sizes (maxima over the partition)
 };
 
 // Data of the affine fast path: reference stiffness / mass tables in LID-slot space and the
@@ -79,7 +81,7 @@ struct AffineDev {
   const double *dphi1d = nullptr;  // [order+1][nq1]
   const double *gw1d = nullptr;    // [nq1]
   const double *gp1d = nullptr;    // [nq1]
-  const void *slot = nullptr;      // [E][n][n] position of (row LIDs[e][i], col LIDs[e][j]) inside the CRS row
+  const void *slot = nullptr;      // block-major [pair][n]: position of column LIDs[e][j] inside the pair's CRS row
   int slot_bytes = 1;              // 1 (uint8) or 2 (uint16)
 };
 
@@ -89,6 +91,7 @@ struct RowOut {
   double *vals = nullptr;
   int overwrite = 0;         // 1: store (fuses the caller's zeroing), 0: accumulate
   int compute_jacobian = 1;
+  int debug_skip = 0;        // profiling only (MHA_DEBUG_SKIP): bit0 fields, bit1 Jacobian, bit2 residual, bit3 stores, bit4 gather
 };
 
 }  // namespace mha

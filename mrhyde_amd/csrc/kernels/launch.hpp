@@ -29,9 +29,11 @@ void launch_workset_views(const BlockDev &b, int e0, int ne, const WorksetViewsD
 
 // thermal_row_owner.hip
 void launch_classify_affine(const BlockDev &b, uint8_t *flags, double tol, hipStream_t stream);
-void launch_build_slot_map(const BlockDev &b, void *slot, int slot_bytes, hipStream_t stream);
+void launch_build_block_slots(const BlockDev &b, const RowBlocksDev &rb, void *bslot, int slot_bytes,
+                              hipStream_t stream);
 bool thermal_row_owner_supported(int dim, int order, int nq1);
-size_t thermal_row_owner_affine_lds(int dim, int order, int nq1, const RowBlocksDev &rb);
+size_t thermal_row_owner_affine_lds(int dim, int order, int nq1, const RowBlocksDev &rb, int slot_bytes,
+                                    bool transient);
 void launch_thermal_row_owner_affine(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph,
                                      const RowBlocksDev &rb, const AffineDev &af, const RowOut &out,
                                      hipStream_t stream);

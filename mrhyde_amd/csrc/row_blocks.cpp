@@ -42,7 +42,10 @@ uint64_t spread2(uint64_t v) {
 }  // namespace
 
 RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, const double *nodes,
-                           const int32_t *lids, const int32_t *rowptr, const RowBlockCaps &caps) {
+                           const int32_t *lids, const int32_t *rowptr, const RowBlockCaps &caps,
+                           const uint8_t *fixed) {
+  MHA_REQUIRE(caps.max_rows <= 65535 && caps.max_elems <= 255 && n <= 255, MHA_ERR_INVALID,
+              "row-block caps exceed the pair encoding (rows <= 65535, elements <= 255, dofs <= 255)");
   MHA_REQUIRE(caps.chunk_elems >= 1 && caps.max_acc >= 1 && caps.max_rows >= 1 && caps.max_elems >= 1,
               MHA_ERR_INVALID, "bad row-block caps");
   // --- Morton rank of every element (centroid of its vertices) ---
@@ -125,7 +128,7 @@ RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, con
   rb.elem_ptr.push_back(0);
   std::vector<int32_t> mark(nelem, -1);
   std::vector<int32_t> cur_elems;
-  int cur_rows = 0, cur_acc = 0;
+  int cur_rows = 0, cur_acc = 0, cur_pairs = 0;
   auto close_block = [&]() {
     if (cur_rows == 0) return;
     std::sort(cur_elems.begin(), cur_elems.end());
@@ -140,6 +143,7 @@ RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, con
     cur_elems.clear();
     cur_rows = 0;
     cur_acc = 0;
+    cur_pairs = 0;
   };
   for (int c = 0; c < nchunks; ++c) {
     for (int k = chunk_cnt[c]; k < chunk_cnt[c + 1]; ++k) {
@@ -151,7 +155,10 @@ RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, con
       MHA_REQUIRE(nnz <= caps.max_acc && inc_ptr[r + 1] - inc_ptr[r] <= caps.max_elems, MHA_ERR_INVALID,
                   "row " << r << " alone exceeds the row-block caps (nnz " << nnz << ", incident elements "
                          << inc_ptr[r + 1] - inc_ptr[r] << ")");
+      const int npair = inc_ptr[r + 1] - inc_ptr[r];
+      MHA_REQUIRE(npair <= caps.max_pairs, MHA_ERR_INVALID, "row " << r << " alone exceeds the pair cap");
       if (cur_rows > 0 && (cur_rows + 1 > caps.max_rows || cur_acc + nnz > caps.max_acc ||
+                           cur_pairs + npair > caps.max_pairs ||
                            static_cast<int>(cur_elems.size()) + fresh > caps.max_elems))
         close_block();
       for (int p = inc_ptr[r]; p < inc_ptr[r + 1]; ++p)
@@ -162,9 +169,31 @@ RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, con
       rb.rows.push_back(r);
       rb.row_off.push_back(cur_acc);
       cur_acc += nnz;
+      cur_pairs += npair;
       cur_rows++;
     }
     close_block();
+  }
+
+  // --- contribution pairs of every block ---
+  rb.pair_ptr.assign(1, 0);
+  std::vector<uint32_t> tmp;
+  for (int k = 0; k < rb.num_blocks; ++k) {
+    tmp.clear();
+    const int32_t *be = rb.elems.data() + rb.elem_ptr[k];
+    const int ne = rb.elem_ptr[k + 1] - rb.elem_ptr[k];
+    for (int o = 0; o < rb.row_ptr[k + 1] - rb.row_ptr[k]; ++o) {
+      const int r = rb.rows[rb.row_ptr[k] + o];
+      if (fixed && fixed[r]) continue;
+      for (int p = inc_ptr[r]; p < inc_ptr[r + 1]; ++p) {
+        const int t = static_cast<int>(std::lower_bound(be, be + ne, inc_elem[p]) - be);
+        tmp.push_back(static_cast<uint32_t>(o) << 16 | static_cast<uint32_t>(t) << 8 | static_cast<uint32_t>(inc_lpos[p]));
+      }
+    }
+    std::sort(tmp.begin(), tmp.end(), [](uint32_t a, uint32_t b) { return (a & 0xffffu) < (b & 0xffffu); });
+    rb.pairs.insert(rb.pairs.end(), tmp.begin(), tmp.end());
+    rb.pair_ptr.push_back(static_cast<int32_t>(rb.pairs.size()));
+    rb.max_pairs = std::max(rb.max_pairs, static_cast<int>(tmp.size()));
   }
   return rb;
 }

@@ -21,6 +21,7 @@ struct RowBlockCaps {
   int max_acc = 4608;    // CRS entries accumulated in LDS per block
   int max_rows = 128;    // owned rows per block
   int max_elems = 40;    // touched elements per block
+  int max_pairs = 1024;  // (element, slot) contribution pairs per block
 };
 
 struct RowBlocks {
@@ -31,12 +32,17 @@ struct RowBlocks {
   std::vector<int32_t> acc_size;  // [nb] accumulator entries of the block
   std::vector<int32_t> elem_ptr;  // [nb+1] -> elems
   std::vector<int32_t> elems;     // touched elements of each block, ascending
-  int max_rows = 0, max_elems = 0, max_acc = 0;
+  // (element, LID slot) pairs whose row the block owns and that receive contributions (fixed rows
+  // excluded), sorted by (element, slot): pair = local_row << 16 | local_elem << 8 | slot
+  std::vector<int32_t> pair_ptr;  // [nb+1] -> pairs
+  std::vector<uint32_t> pairs;
+  int max_rows = 0, max_elems = 0, max_acc = 0, max_pairs = 0;
 };
 
 RowBlockCaps default_caps(int dim, int n);
 
 RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, const double *nodes,
-                           const int32_t *lids, const int32_t *rowptr, const RowBlockCaps &caps);
+                           const int32_t *lids, const int32_t *rowptr, const RowBlockCaps &caps,
+                           const uint8_t *fixed = nullptr);
 
 }  // namespace mha
