@@ -361,23 +361,25 @@ void AssemblyManager::prepareRowOwner() {
   // LDS budget: two workgroups per CU (80 KiB each).  An aligned interior chunk touches 3^dim elements
   // and owns (2*order)^dim rows; the accumulator gets whatever the fixed parts leave.
   {
+    // LDS budget of K2: four workgroups per CU (40 KiB each).  An aligned interior chunk touches
+    // 3^dim elements; the accumulator gets whatever the pair tables leave.
     const int neigh = (dim_ == 3) ? 27 : 25;
     caps.max_elems = neigh;
     caps.max_rows = 96;
-    caps.max_pairs = 256;
+    caps.max_pairs = (dim_ == 3) ? 216 : 256;
+    caps.max_acc = 65534;
     RowBlocksDev probe;
     probe.lds_rows = caps.max_rows;
     probe.lds_elems = caps.max_elems;
     probe.lds_pairs = caps.max_pairs;
     probe.lds_acc = 0;
-    const long fixed_bytes =
-        static_cast<long>(thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, probe, ro.slot_bytes, false));
-    const long budget = 80 * 1024 - 256 - fixed_bytes;
+    const long fixed_bytes = static_cast<long>(row_owner_jacobian_lds(probe, n_, ro.slot_bytes));
+    const long budget = 40 * 1024 - fixed_bytes;
     MHA_REQUIRE(budget >= 8 * 2 * max_row, MHA_ERR_INVALID, "row-owner kernel does not fit the LDS budget for this element");
-    caps.max_acc = static_cast<int>(budget / 8);
+    caps.max_acc = std::min(65534, static_cast<int>(budget / 8) / 2 * 2);
   }
   ro.rb = build_row_blocks(dim_, nnodes_, nelem_, n_, nrows_, nodes.data(), h_lids_.data(), h_rowptr_.data(), caps,
-                           has_fixed_ ? h_fixed_.data() : nullptr);
+                           has_fixed_ ? h_fixed_.data() : nullptr, ro.slot_bytes);
   const RowBlocks &rb = ro.rb;
   ro.row_ptr.upload(rb.row_ptr);
   ro.rows.upload(rb.rows);
@@ -387,6 +389,23 @@ void AssemblyManager::prepareRowOwner() {
   ro.elems.upload(rb.elems);
   ro.pair_ptr.upload(rb.pair_ptr);
   ro.pairs.upload(rb.pairs);
+  ro.pair_off.upload(rb.pair_off);
+  ro.row_base.upload(rb.row_base);
+  ro.row_len.upload(rb.row_len);
+  ro.emask.upload(rb.emask);
+  ro.epbase.upload(rb.epbase);
+  ro.slot_ptr.upload(rb.slot_ptr);
+  ro.seg_ptr.upload(rb.seg_ptr);
+  ro.seg_acc.upload(rb.seg_acc);
+  ro.seg_base.upload(rb.seg_base);
+  ro.seg_len.upload(rb.seg_len);
+  ro.geo.resize(static_cast<size_t>(nelem_) * kGeoRec);
+  launch_affine_geometry(b, ro.geo.data(), stream_);
+  {
+    std::vector<uint16_t> po(rb.pair_off.size());
+    for (size_t i = 0; i < po.size(); ++i) po[i] = static_cast<uint16_t>(rb.pair_off[i]);
+    ro.pair_off16.upload(po);
+  }
   ro.all_rows_covered = static_cast<int>(rb.rows.size()) == nrows_;
   // 3. block classification: affine blocks touch affine elements only
   std::vector<int32_t> aff, gen;
@@ -400,8 +419,10 @@ void AssemblyManager::prepareRowOwner() {
   ro.affine_list.upload(aff);
   ro.general_list.upload(gen);
   // 4. block-major slot table (position of every contribution inside its CRS row)
-  ro.slot.resize(std::max<size_t>(1, rb.pairs.size() * n_ * ro.slot_bytes));
+  ro.slot.resize(std::max<size_t>(16, static_cast<size_t>(rb.slot_ptr.back())));
   launch_build_block_slots(b, rowBlocksDev(), ro.slot.data(), ro.slot_bytes, stream_);
+  ro.erec.resize(std::max<size_t>(8, rb.elems.size() * 8));
+  launch_build_erec(dim_, rowBlocksDev(), ro.geo.data(), ro.erec.data(), static_cast<int>(rb.elems.size()), stream_);
   // 5. reference tables of the affine path, in LID-slot space
   const int nsym = dim_ * (dim_ + 1) / 2;
   std::vector<double> khat(static_cast<size_t>(nsym + 1) * n_ * n_, 0.0);
@@ -454,6 +475,16 @@ RowBlocksDev AssemblyManager::rowBlocksDev() const {
   rb.elems = ro_.elems.data();
   rb.pair_ptr = ro_.pair_ptr.data();
   rb.pairs = ro_.pairs.data();
+  rb.pair_off = ro_.pair_off.data();
+  rb.row_base = ro_.row_base.data();
+  rb.row_len = ro_.row_len.data();
+  rb.emask = ro_.emask.data();
+  rb.epbase = ro_.epbase.data();
+  rb.slot_ptr = ro_.slot_ptr.data();
+  rb.seg_ptr = ro_.seg_ptr.data();
+  rb.seg_acc = ro_.seg_acc.data();
+  rb.seg_base = ro_.seg_base.data();
+  rb.seg_len = ro_.seg_len.data();
   rb.lds_rows = ro_.rb.max_rows;
   rb.lds_elems = ro_.rb.max_elems;
   rb.lds_acc = ro_.rb.max_acc;
@@ -471,15 +502,23 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   af.gp1d = ro_.gp.data();
   af.slot = ro_.slot.data();
   af.slot_bytes = ro_.slot_bytes;
+  af.geo = ro_.geo.data();
+  af.erec = ro_.erec.data();
+  af.pair_off16 = ro_.pair_off16.data();
   RowOut out;
   out.res = res;
   out.vals = crs_vals;
   out.overwrite = overwrite ? 1 : 0;
   out.compute_jacobian = compute_jacobian ? 1 : 0;
-  if (const char *dbg = std::getenv("MHA_DEBUG_SKIP")) out.debug_skip = std::atoi(dbg);  // profiling ablations only
   thermal *th = dynamic_cast<thermal *>(physics_.get());
   MHA_REQUIRE(th != nullptr, MHA_ERR_INVALID, "row-owner path: physics module is not thermal");
-  launch_thermal_row_owner_affine(dim_, order_, ref_.nq1, blockDev(), th->device_params(), rb, af, out, stream_);
+  const ThermalDev ph = th->device_params();
+  // K1 accumulates the residual with atomics: the fused zeroing becomes a (small) memset
+  if (overwrite) MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
+  launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, stream_);
+  if (compute_jacobian)
+    launch_row_owner_jacobian(dim_, n_, rb, af, out, ph.time.alpha_u * ph.diff.amp,
+                              ph.time.alpha_t * ph.rho.amp * ph.cp.amp, stream_);
 }
 
 int64_t AssemblyManager::info(const std::string &key) const {
@@ -497,7 +536,7 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "row_block_max_acc") return ro_.rb.max_acc;
   if (key == "row_block_max_pairs") return ro_.rb.max_pairs;
   if (key == "row_owner_lds_bytes")
-    return ro_.ready ? static_cast<int64_t>(thermal_row_owner_affine_lds(dim_, order_, ref_.nq1, rowBlocksDev(), ro_.slot_bytes, time_.transient != 0)) : 0;
+    return ro_.ready ? static_cast<int64_t>(row_owner_jacobian_lds(rowBlocksDev(), n_, ro_.slot_bytes)) : 0;
   throw Error(MHA_ERR_INVALID, "unknown info key '" + key + "'");
 }
 

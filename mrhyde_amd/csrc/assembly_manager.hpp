@@ -82,6 +82,11 @@ class AssemblyManager {
     bool ready = false;
     RowBlocks rb;
     DeviceBuffer<int32_t> row_ptr, rows, row_off, acc_size, elem_ptr, elems, pair_ptr, affine_list, general_list;
+    DeviceBuffer<int32_t> pair_off, row_base, row_len, emask, epbase, seg_ptr, seg_acc, seg_base, seg_len;
+    DeviceBuffer<int64_t> slot_ptr;
+    DeviceBuffer<double> geo;  // [E][kGeoRec] cached element geometry
+    DeviceBuffer<double> erec;  // block-major element records of K2
+    DeviceBuffer<uint16_t> pair_off16;
     DeviceBuffer<uint32_t> pairs;
     DeviceBuffer<uint8_t> slot, flags;
     DeviceBuffer<double> khat, phi, dphi, gw, gp;

@@ -29,6 +29,29 @@ __device__ __forceinline__ void invert<3>(const double *J, double *Ji, double &d
   Ji[6] = c2 * r; Ji[7] = (J[1] * J[6] - J[0] * J[7]) * r; Ji[8] = (J[0] * J[4] - J[1] * J[3]) * r;
 }
 
+// sin(x) for moderate |x|: Cody-Waite reduction by pi/2 and the fdlibm kernel polynomials (< 1 ulp);
+// falls back to the library routine for huge arguments.  About a quarter of the instructions of the
+// full-range sin(), which matters because the source term is evaluated at every integration point.
+__device__ __forceinline__ double sin_moderate(double x) {
+  if (!(fabs(x) < 1.0e5)) return sin(x);
+  const double kd = rint(x * 6.36619772367581382433e-01);
+  const int k = (int)kd;
+  double r = fma(-kd, 1.57079632673412561417e+00, x);
+  r = fma(-kd, 6.07710050650619224932e-11, r);
+  r = fma(-kd, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  const double sp = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                             2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double sr = fma(r * z, sp, r);
+  const double cp = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                             -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double cr = fma(z * z, cp, fma(-0.5, z, 1.0));
+  const double v = (k & 1) ? cr : sr;
+  return (k & 2) ? -v : v;
+}
+
 // Value of a named function at integration point (e,q) with physical coordinates x.
 template <int DIM>
 __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int nq, const double *x) {
@@ -36,7 +59,7 @@ __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int
   if (f.kind == MHA_FUNC_IP_ARRAY) return f.ip[(size_t)e * nq + q];
   double s = f.amp;
 #pragma unroll
-  for (int d = 0; d < DIM; ++d) s *= sin(f.freq[d] * x[d]);
+  for (int d = 0; d < DIM; ++d) s *= sin_moderate(f.freq[d] * x[d]);
   return s;
 }
 

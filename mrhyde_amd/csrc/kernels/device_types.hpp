@@ -6,6 +6,8 @@ namespace mha {
 
 constexpr int kMaxStages = 8;
 constexpr int kMaxSteps = 8;
+// cached geometry record of an affine element: detJ*J^{-1}J^{-T} (NSYM, padded to 6), detJ, J (9), centroid (3)
+constexpr int kGeoRec = 20, kGeoDet = 6, kGeoJ = 7, kGeoXc = 16;
 
 // What FunctionManager::evaluate(name,"ip") yields for one named function
 // (reference: src/managers/functionManager.cpp:543-760): constant, per-ip data, or a closed form.
@@ -68,6 +70,9 @@ struct RowBlocksDev {
   const int32_t *elem_ptr = nullptr, *elems = nullptr;
   const int32_t *pair_ptr = nullptr;
   const uint32_t *pairs = nullptr;       // local_row << 16 | local_elem << 8 | LID slot
+  const int32_t *pair_off = nullptr, *row_base = nullptr, *row_len = nullptr, *emask = nullptr, *epbase = nullptr;
+  const int64_t *slot_ptr = nullptr;     // [nb+1] byte offset of the block's slot table (16-byte aligned)
+  const int32_t *seg_ptr = nullptr, *seg_acc = nullptr, *seg_base = nullptr, *seg_len = nullptr;
   const int32_t *block_list = nullptr;  // blocks this launch handles (null = all)
   int list_len = 0;
   int lds_rows = 0, lds_elems = 0, lds_acc = 0, lds_pairs = 0;  // LDS carve sizes (maxima over the partition)
@@ -81,7 +86,10 @@ struct AffineDev {
   const double *dphi1d = nullptr;  // [order+1][nq1]
   const double *gw1d = nullptr;    // [nq1]
   const double *gp1d = nullptr;    // [nq1]
-  const void *slot = nullptr;      // block-major [pair][n]: position of column LIDs[e][j] inside the pair's CRS row
+  const void *slot = nullptr;      // block-major [pair][n] (blocks padded to 16 B): position of column LIDs[e][j] inside the pair's CRS row
+  const double *geo = nullptr;     // [E][kGeoRec] cached element geometry (affine elements)
+  const double *erec = nullptr;    // block-major [touched element][8]: geometric factors + ownership data
+  const uint16_t *pair_off16 = nullptr;  // block-major [pair]: accumulator offset of the pair's row
   int slot_bytes = 1;              // 1 (uint8) or 2 (uint16)
 };
 
@@ -91,7 +99,6 @@ struct RowOut {
   double *vals = nullptr;
   int overwrite = 0;         // 1: store (fuses the caller's zeroing), 0: accumulate
   int compute_jacobian = 1;
-  int debug_skip = 0;        // profiling only (MHA_DEBUG_SKIP): bit0 fields, bit1 Jacobian, bit2 residual, bit3 stores, bit4 gather
 };
 
 }  // namespace mha

@@ -32,10 +32,15 @@ void launch_classify_affine(const BlockDev &b, uint8_t *flags, double tol, hipSt
 void launch_build_block_slots(const BlockDev &b, const RowBlocksDev &rb, void *bslot, int slot_bytes,
                               hipStream_t stream);
 bool thermal_row_owner_supported(int dim, int order, int nq1);
-size_t thermal_row_owner_affine_lds(int dim, int order, int nq1, const RowBlocksDev &rb, int slot_bytes,
-                                    bool transient);
-void launch_thermal_row_owner_affine(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph,
-                                     const RowBlocksDev &rb, const AffineDev &af, const RowOut &out,
-                                     hipStream_t stream);
+size_t row_owner_jacobian_lds(const RowBlocksDev &rb, int n, int slot_bytes);
+void launch_affine_geometry(const BlockDev &b, double *geo, hipStream_t stream);
+void launch_build_erec(int dim, const RowBlocksDev &rb, const double *geo, double *erec, int total,
+                       hipStream_t stream);
+// K1: element-wise residual (-> res with atomics)
+void launch_thermal_affine_element(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph,
+                                   const AffineDev &af, double *res, hipStream_t stream);
+// K2: row-owner Jacobian; scale_u = alpha_u*kappa, scale_t = alpha_t*rho*cp
+void launch_row_owner_jacobian(int dim, int n, const RowBlocksDev &rb, const AffineDev &af, const RowOut &out,
+                               double scale_u, double scale_t, hipStream_t stream);
 
 }  // namespace mha

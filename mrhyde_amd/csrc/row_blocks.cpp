@@ -43,7 +43,7 @@ uint64_t spread2(uint64_t v) {
 
 RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, const double *nodes,
                            const int32_t *lids, const int32_t *rowptr, const RowBlockCaps &caps,
-                           const uint8_t *fixed) {
+                           const uint8_t *fixed, int slot_bytes) {
   MHA_REQUIRE(caps.max_rows <= 65535 && caps.max_elems <= 255 && n <= 255, MHA_ERR_INVALID,
               "row-block caps exceed the pair encoding (rows <= 65535, elements <= 255, dofs <= 255)");
   MHA_REQUIRE(caps.chunk_elems >= 1 && caps.max_acc >= 1 && caps.max_rows >= 1 && caps.max_elems >= 1,
@@ -175,7 +175,18 @@ RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, con
     close_block();
   }
 
+  // --- CRS placement of the owned rows ---
+  rb.row_base.resize(rb.rows.size());
+  rb.row_len.resize(rb.rows.size());
+  for (size_t k = 0; k < rb.rows.size(); ++k) {
+    const int r = rb.rows[k];
+    const int len = rowptr[r + 1] - rowptr[r];
+    rb.row_base[k] = rowptr[r];
+    rb.row_len[k] = (fixed && fixed[r]) ? -len - 1 : len;
+  }
   // --- contribution pairs of every block ---
+  rb.emask.assign(rb.elems.size(), 0);
+  rb.epbase.assign(rb.elems.size(), 0);
   rb.pair_ptr.assign(1, 0);
   std::vector<uint32_t> tmp;
   for (int k = 0; k < rb.num_blocks; ++k) {
@@ -191,9 +202,47 @@ RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, con
       }
     }
     std::sort(tmp.begin(), tmp.end(), [](uint32_t a, uint32_t b) { return (a & 0xffffu) < (b & 0xffffu); });
+    for (size_t i = 0; i < tmp.size(); ++i) {
+      const int o = tmp[i] >> 16, t = (tmp[i] >> 8) & 0xff, si = tmp[i] & 0xff;
+      rb.pair_off.push_back(rb.row_off[rb.row_ptr[k] + o]);
+      int32_t &m = rb.emask[rb.elem_ptr[k] + t];
+      if (m == 0) rb.epbase[rb.elem_ptr[k] + t] = static_cast<int32_t>(i);
+      if (si < 32) m |= (1 << si);
+    }
     rb.pairs.insert(rb.pairs.end(), tmp.begin(), tmp.end());
     rb.pair_ptr.push_back(static_cast<int32_t>(rb.pairs.size()));
     rb.max_pairs = std::max(rb.max_pairs, static_cast<int>(tmp.size()));
+  }
+  // --- aligned slot-table offsets ---
+  rb.slot_ptr.assign(1, 0);
+  for (int k = 0; k < rb.num_blocks; ++k) {
+    const int64_t bytes = static_cast<int64_t>(rb.pair_ptr[k + 1] - rb.pair_ptr[k]) * n * slot_bytes;
+    rb.slot_ptr.push_back(rb.slot_ptr.back() + (bytes + 15) / 16 * 16);
+  }
+  // --- store segments ---
+  rb.seg_ptr.assign(1, 0);
+  for (int k = 0; k < rb.num_blocks; ++k) {
+    int nseg = 0;
+    for (int i = rb.row_ptr[k]; i < rb.row_ptr[k + 1]; ++i) {
+      const bool fx = rb.row_len[i] < 0;
+      const int len = fx ? -rb.row_len[i] - 1 : rb.row_len[i];
+      bool extend = false;
+      if (nseg > 0) {
+        const size_t s = rb.seg_acc.size() - 1;
+        const bool sfx = rb.seg_len[s] < 0;
+        const int slen = sfx ? -rb.seg_len[s] : rb.seg_len[s];
+        extend = sfx == fx && rb.seg_acc[s] + slen == rb.row_off[i] && rb.seg_base[s] + slen == rb.row_base[i];
+        if (extend) rb.seg_len[s] = fx ? -(slen + len) : slen + len;
+      }
+      if (!extend) {
+        rb.seg_acc.push_back(rb.row_off[i]);
+        rb.seg_base.push_back(rb.row_base[i]);
+        rb.seg_len.push_back(fx ? -len : len);
+        ++nseg;
+      }
+    }
+    rb.seg_ptr.push_back(static_cast<int32_t>(rb.seg_acc.size()));
+    rb.max_segs = std::max(rb.max_segs, nseg);
   }
   return rb;
 }

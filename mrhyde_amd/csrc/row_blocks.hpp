@@ -34,8 +34,21 @@ struct RowBlocks {
   std::vector<int32_t> elems;     // touched elements of each block, ascending
   // (element, LID slot) pairs whose row the block owns and that receive contributions (fixed rows
   // excluded), sorted by (element, slot): pair = local_row << 16 | local_elem << 8 | slot
-  std::vector<int32_t> pair_ptr;  // [nb+1] -> pairs
+  std::vector<int32_t> pair_ptr;  // [nb+1] -> pairs / pair_off
   std::vector<uint32_t> pairs;
+  std::vector<int32_t> pair_off;  // accumulator offset of the pair's row (= row_off of its row)
+  // per owned row (parallel to rows): CRS offset and length; length stored as -(len)-1 for fixed rows
+  std::vector<int32_t> row_base, row_len;
+  // per touched element (parallel to elems): bit si set when (elem, si) is a pair; index of its first pair
+  std::vector<int32_t> emask, epbase;
+  // byte offset of the block's slot table inside the block-major slot array (16-byte aligned), [nb+1]
+  std::vector<int64_t> slot_ptr;
+  // store segments: maximal runs of owned rows that are contiguous both in the accumulator and in the
+  // CRS value array.  seg_len < 0 marks a run of fixed rows (-len entries; written as zeros in
+  // overwrite mode, untouched otherwise).
+  std::vector<int32_t> seg_ptr;   // [nb+1]
+  std::vector<int32_t> seg_acc, seg_base, seg_len;
+  int max_segs = 0;
   int max_rows = 0, max_elems = 0, max_acc = 0, max_pairs = 0;
 };
 
@@ -43,6 +56,6 @@ RowBlockCaps default_caps(int dim, int n);
 
 RowBlocks build_row_blocks(int dim, int nnodes, int nelem, int n, int nrows, const double *nodes,
                            const int32_t *lids, const int32_t *rowptr, const RowBlockCaps &caps,
-                           const uint8_t *fixed = nullptr);
+                           const uint8_t *fixed = nullptr, int slot_bytes = 1);
 
 }  // namespace mha
