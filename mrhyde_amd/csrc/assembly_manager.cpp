@@ -366,7 +366,7 @@ void AssemblyManager::prepareRowOwner() {
     const int neigh = (dim_ == 3) ? 27 : 25;
     caps.max_elems = neigh;
     caps.max_rows = 96;
-    caps.max_pairs = (dim_ == 3) ? 216 : 256;
+    caps.max_pairs = (dim_ == 3) ? 224 : 256;
     caps.max_acc = 65534;
     RowBlocksDev probe;
     probe.lds_rows = caps.max_rows;

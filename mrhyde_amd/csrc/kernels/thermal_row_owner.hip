@@ -367,8 +367,7 @@ __global__ __launch_bounds__(NT, (NT >= 384 ? 6 : 1)) void row_owner_jacobian_ke
 
   extern __shared__ double smem[];
   double *acc = smem;                                                    // [lds_acc], lds_acc even
-  double *s_erec = acc + rb.lds_acc;                                     // [lds_elems][kERec], pre-scaled
-  SlotT *s_slot = reinterpret_cast<SlotT *>(s_erec + (size_t)rb.lds_elems * kERec);  // [lds_pairs*N -> 16 B]
+  SlotT *s_slot = reinterpret_cast<SlotT *>(acc + rb.lds_acc);           // [lds_pairs*N -> 16 B]
   uint16_t *s_pairoff = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(s_slot) +
                                                      ((size_t)rb.lds_pairs * N * sizeof(SlotT) + 15) / 16 * 16);
 
@@ -386,7 +385,8 @@ __global__ __launch_bounds__(NT, (NT >= 384 ? 6 : 1)) void row_owner_jacobian_ke
     my_low[it] = (1u << si) - 1u;
     my_sj[it] = idx - si * N;
 #pragma unroll
-    for (int k = 0; k <= NSYM; ++k) kh[it][k] = (idx < NN2) ? khat[k * NN2 + idx] : 0.0;
+    for (int k = 0; k <= NSYM; ++k)  // the run-time scale factors are folded into the table entries once
+      kh[it][k] = (idx < NN2) ? (k < NSYM ? su : st) * khat[k * NN2 + idx] : 0.0;
     const int lo = wave * 64 + it * NT, hi = min(lo + 63, NN2 - 1);
     if (lo < NN2) {
       const int a = lo / N, c = hi / N;
@@ -394,12 +394,7 @@ __global__ __launch_bounds__(NT, (NT >= 384 ? 6 : 1)) void row_owner_jacobian_ke
     }
   }
 
-  // ---- block tables into LDS (element records pre-scaled), zero the accumulators ----
-  for (int i = tid; i < T * kERec; i += NT) {
-    const int k = i & (kERec - 1);
-    const double v = erec[(size_t)t0 * kERec + i];
-    s_erec[i] = (k < NSYM) ? su * v : (k == NSYM ? st * v : v);
-  }
+  // ---- block tables into LDS, zero the accumulators ----
   for (int p = tid; p < NP; p += NT) s_pairoff[p] = pair_off16[p0 + p];
   {
     const uint4 *src = slot16 + rb.slot_ptr[blk] / 16;
@@ -413,10 +408,11 @@ __global__ __launch_bounds__(NT, (NT >= 384 ? 6 : 1)) void row_owner_jacobian_ke
   }
   __syncthreads();
 
-  // ---- contributions: lane (si,sj) walks the block's elements; the element record is read from LDS
-  //      at a wave-uniform address; a wave skips elements none of whose owned rows fall into its si range ----
+  // ---- contributions: lane (si,sj) walks the block's elements; the 64-byte element record is one
+  //      wave-uniform (scalar) load from the block-major table; a wave skips elements none of whose
+  //      owned rows fall into its si range ----
   for (int t = 0; t < T; ++t) {
-    const double *E = s_erec + t * kERec;
+    const double *E = erec + (size_t)(t0 + t) * kERec;
     const double mp = E[7];
     const unsigned mask = (unsigned)__double2loint(mp);
     if ((mask & wave_si) == 0u) continue;
@@ -457,7 +453,7 @@ __global__ __launch_bounds__(NT, (NT >= 384 ? 6 : 1)) void row_owner_jacobian_ke
 size_t k2_lds_bytes(const RowBlocksDev &rb, int n, int slot_bytes) {
   const size_t acc = ((size_t)rb.lds_acc + 1) / 2 * 2 * sizeof(double);
   const size_t slots = ((size_t)rb.lds_pairs * n * slot_bytes + 15) / 16 * 16;
-  return acc + (size_t)rb.lds_elems * kERec * sizeof(double) + slots + ((size_t)rb.lds_pairs * 2 + 15) / 16 * 16;
+  return acc + slots + ((size_t)rb.lds_pairs * 2 + 15) / 16 * 16;
 }
 
 template <int DIM, int N, int NT, typename SlotT>
