@@ -377,6 +377,9 @@ void AssemblyManager::prepareRowOwner() {
     const long budget = 40 * 1024 - fixed_bytes;
     MHA_REQUIRE(budget >= 8 * 2 * max_row, MHA_ERR_INVALID, "row-owner kernel does not fit the LDS budget for this element");
     caps.max_acc = std::min(65534, static_cast<int>(budget / 8) / 2 * 2);
+    // tuning knobs (experiments): elements per Morton chunk and the accumulator cap
+    if (const char *e = std::getenv("MHA_RB_CHUNK")) caps.chunk_elems = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("MHA_RB_MAXACC")) caps.max_acc = std::max(2 * max_row, std::atoi(e));
   }
   ro.rb = build_row_blocks(dim_, nnodes_, nelem_, n_, nrows_, nodes.data(), h_lids_.data(), h_rowptr_.data(), caps,
                            has_fixed_ ? h_fixed_.data() : nullptr, ro.slot_bytes);
@@ -489,6 +492,7 @@ RowBlocksDev AssemblyManager::rowBlocksDev() const {
   rb.lds_elems = ro_.rb.max_elems;
   rb.lds_acc = ro_.rb.max_acc;
   rb.lds_pairs = ro_.rb.max_pairs;
+  rb.lds_segs = ro_.rb.max_segs;
   return rb;
 }
 

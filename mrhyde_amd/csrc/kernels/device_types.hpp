@@ -75,7 +75,7 @@ struct RowBlocksDev {
   const int32_t *seg_ptr = nullptr, *seg_acc = nullptr, *seg_base = nullptr, *seg_len = nullptr;
   const int32_t *block_list = nullptr;  // blocks this launch handles (null = all)
   int list_len = 0;
-  int lds_rows = 0, lds_elems = 0, lds_acc = 0, lds_pairs = 0;  // LDS carve sizes (maxima over the partition)
+  int lds_rows = 0, lds_elems = 0, lds_acc = 0, lds_pairs = 0, lds_segs = 0;  // LDS carve sizes (maxima over the partition)
 };
 
 // Data of the affine fast path: reference stiffness / mass tables in LID-slot space and the

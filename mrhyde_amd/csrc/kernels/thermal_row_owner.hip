@@ -25,6 +25,9 @@
 // 937-1062; src/interfaces/discretizationInterface.cpp:732-776, 898-981; src/physics/thermal.cpp:71-165).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "launch.hpp"
 
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void build_erec_kernel(RowBlocksDev rb, const 
 }
 
 template <int DIM, int N, int NT, typename SlotT>
-__global__ __launch_bounds__(NT, (NT >= 384 ? 6 : 1)) void row_owner_jacobian_kernel(
+__global__ __launch_bounds__(NT, (NT == 384 ? 6 : 1)) void row_owner_jacobian_kernel(
     RowBlocksDev rb, const double *__restrict__ erec, const double *__restrict__ khat,
     const uint4 *__restrict__ slot16, const uint16_t *__restrict__ pair_off16, RowOut out, double su, double st) {
   constexpr int NSYM = DIM * (DIM + 1) / 2, NN2 = N * N, NITER = (NN2 + NT - 1) / NT;
@@ -450,6 +453,176 @@ __global__ __launch_bounds__(NT, (NT >= 384 ? 6 : 1)) void row_owner_jacobian_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K2, persistent + software-pipelined form
+//   - workgroups walk the row blocks blockIdx.x, blockIdx.x + gridDim.x, ...; the reference-table
+//     registers are set up once per workgroup;
+//   - the tables of block i+1 are prefetched into registers while block i is accumulated;
+//   - the stores of block i are only ISSUED before the workgroup moves on, so they drain behind block
+//     i+1's work (a workgroup that ends sits on its LDS until its stores are acknowledged: s_endpgm
+//     waits for outstanding memory operations);
+//   - barriers wait for LDS traffic only: gfx950 counts loads and stores in one in-order vmcnt, so a
+//     __syncthreads() (which implies vmcnt(0)) would stall on the stores in flight;
+//   - element records live in LDS (a scalar load per element inside the loop costs a memory round
+//     trip each: measured 1.6x slower).
+// DBG != 0 only in profiling launches (env MHA_K2_ABLATE): 1 no contributions, 2 no stores, 3 neither.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxBlockElems = 27, kMaxBlockPairs = 256;  // caps of a row block (host: prepareRowOwner)
+
+template <int DIM, int N, int NT, typename SlotT, int DBG>
+__global__ __launch_bounds__(NT, (NT == 384 ? 5 : (NT == 256 ? 4 : 1))) void row_owner_jacobian_persistent_kernel(
+    RowBlocksDev rb, const double *__restrict__ erec, const double *__restrict__ khat,
+    const uint4 *__restrict__ slot16, const uint16_t *__restrict__ pair_off16, RowOut out, double su, double st) {
+  constexpr int NSYM = DIM * (DIM + 1) / 2, NN2 = N * N, NITER = (NN2 + NT - 1) / NT;
+  static_assert(N <= 32, "ownership masks are 32 bits wide");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nwork = rb.block_list ? rb.list_len : rb.num_blocks;
+  constexpr int NW = NT / 64;
+
+  extern __shared__ double smem[];
+  double *acc = smem;                                                    // [lds_acc], lds_acc even
+  double *s_erec = acc + rb.lds_acc;                                     // [lds_elems][kERec]
+  SlotT *s_slot = reinterpret_cast<SlotT *>(s_erec + (size_t)rb.lds_elems * kERec);  // [lds_pairs*N -> 16 B]
+  uint16_t *s_pairoff = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(s_slot) +
+                                                     ((size_t)rb.lds_pairs * N * sizeof(SlotT) + 15) / 16 * 16);
+
+  // this lane's reference table entries (pre-scaled by the run-time factors), kept in registers for the
+  // life of the workgroup; the LID slots (si) this WAVE covers, as a bit mask, for the wave-level skip
+  double kh[NITER][NSYM + 1];
+  unsigned my_bit[NITER], my_low[NITER];
+  int my_sj[NITER];
+  unsigned wave_si = 0u;
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const int idx = tid + it * NT;
+    const int si = (idx < NN2) ? idx / N : 0;
+    my_bit[it] = (idx < NN2) ? (1u << si) : 0u;
+    my_low[it] = (1u << si) - 1u;
+    my_sj[it] = idx - si * N;
+#pragma unroll
+    for (int k = 0; k <= NSYM; ++k) kh[it][k] = (k < NSYM ? su : st) * khat[k * NN2 + min(idx, NN2 - 1)];
+    const int lo = wave * 64 + it * NT, hi = min(lo + 63, NN2 - 1);
+    if (lo < NN2) {
+      const int a = lo / N, c = hi / N;
+      wave_si |= (c >= 31 ? 0xffffffffu : ((1u << (c + 1)) - 1u)) & ~((1u << a) - 1u);
+    }
+  }
+
+  // per-thread pieces of one block's tables (sized for the caps the host enforces)
+  constexpr int EREC_PT = (kMaxBlockElems * kERec + NT - 1) / NT;
+  constexpr int PAIR_PT = (kMaxBlockPairs + NT - 1) / NT;
+  constexpr int SLOT16_PT = ((kMaxBlockPairs * N * (int)sizeof(SlotT) + 15) / 16 + NT - 1) / NT;
+  struct Prefetch {
+    double erec[EREC_PT];
+    uint4 slot[SLOT16_PT];
+    uint16_t pairoff[PAIR_PT];
+    int sg_acc, sg_base, sg_len;
+  };
+  auto prefetch = [&](int work, Prefetch &pf) {  // unconditional loads, clamped indices: all in flight together
+    const int blk = rb.block_list ? rb.block_list[work] : work;
+    const int t0 = rb.elem_ptr[blk], T = rb.elem_ptr[blk + 1] - t0;
+    const int p0 = rb.pair_ptr[blk], NP = rb.pair_ptr[blk + 1] - p0;
+    const int g0 = rb.seg_ptr[blk], NS = rb.seg_ptr[blk + 1] - g0;
+#pragma unroll
+    for (int j = 0; j < EREC_PT; ++j) pf.erec[j] = erec[(size_t)t0 * kERec + min(tid + j * NT, T * kERec - 1)];
+#pragma unroll
+    for (int j = 0; j < PAIR_PT; ++j) pf.pairoff[j] = pair_off16[p0 + min(tid + j * NT, max(NP - 1, 0))];
+    const uint4 *src = slot16 + rb.slot_ptr[blk] / 16;
+    const int n16 = (int)((rb.slot_ptr[blk + 1] - rb.slot_ptr[blk]) / 16);
+#pragma unroll
+    for (int j = 0; j < SLOT16_PT; ++j) pf.slot[j] = src[min(tid + j * NT, max(n16 - 1, 0))];
+    const int sidx = min(wave + NW * lane, NS - 1);  // store runs of this wave, one per lane
+    pf.sg_acc = rb.seg_acc[g0 + sidx];
+    pf.sg_base = rb.seg_base[g0 + sidx];
+    pf.sg_len = rb.seg_len[g0 + sidx];
+  };
+  auto tables_to_lds = [&](const Prefetch &pf) {
+#pragma unroll
+    for (int j = 0; j < EREC_PT; ++j)
+      if (tid + j * NT < rb.lds_elems * kERec) s_erec[tid + j * NT] = pf.erec[j];
+#pragma unroll
+    for (int j = 0; j < PAIR_PT; ++j)
+      if (tid + j * NT < rb.lds_pairs) s_pairoff[tid + j * NT] = pf.pairoff[j];
+    uint4 *dst = reinterpret_cast<uint4 *>(s_slot);
+    const int cap16 = (int)(((size_t)rb.lds_pairs * N * sizeof(SlotT) + 15) / 16);
+#pragma unroll
+    for (int j = 0; j < SLOT16_PT; ++j)
+      if (tid + j * NT < cap16) dst[tid + j * NT] = pf.slot[j];
+  };
+  auto lds_barrier = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  auto zero_acc = [&]() {
+    double2 *a2 = reinterpret_cast<double2 *>(acc);
+    for (int i = tid; i < rb.lds_acc / 2; i += NT) a2[i] = make_double2(0.0, 0.0);
+  };
+
+  if ((int)blockIdx.x >= nwork) return;
+  Prefetch cur;
+  prefetch(blockIdx.x, cur);
+  tables_to_lds(cur);
+  zero_acc();
+  lds_barrier();
+
+  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    const int blk = rb.block_list ? rb.block_list[work] : work;
+    const int T = rb.elem_ptr[blk + 1] - rb.elem_ptr[blk];
+    const int NS = rb.seg_ptr[blk + 1] - rb.seg_ptr[blk];
+    const int sg_acc = cur.sg_acc, sg_base = cur.sg_base, sg_len = cur.sg_len;
+    const int next = work + gridDim.x;
+    Prefetch nxt = cur;
+    if (next < nwork) prefetch(next, nxt);  // lands while this block is accumulated
+
+    // contributions: lane (si,sj) walks the block's elements; the 64-byte element record is read from LDS at a
+    // wave-uniform address; a wave skips elements none of whose owned rows fall into its si range
+    for (int t = 0; t < ((DBG & 1) ? 0 : T); ++t) {
+      const double *E = s_erec + t * kERec;
+      const double mp = E[7];
+      const unsigned mask = (unsigned)__double2loint(mp);
+      if ((mask & wave_si) == 0u) continue;
+      const int pb = __double2hiint(mp);
+      double g[NSYM + 1];
+#pragma unroll
+      for (int k = 0; k <= NSYM; ++k) g[k] = E[k];
+#pragma unroll
+      for (int it = 0; it < NITER; ++it) {
+        if (mask & my_bit[it]) {
+          const int p = pb + __popc(mask & my_low[it]);
+          double v = g[NSYM] * kh[it][NSYM];
+#pragma unroll
+          for (int k = 0; k < NSYM; ++k) v += g[k] * kh[it][k];
+          atomicAdd(&acc[(int)s_pairoff[p] + (int)s_slot[p * N + my_sj[it]]], v);
+        }
+      }
+    }
+    lds_barrier();  // accumulators complete; tables no longer needed
+
+    if (next < nwork) tables_to_lds(nxt);  // the prefetch has had the whole accumulation phase to land
+
+    // stream the finished rows: each wave takes whole contiguous runs; stores are issued and left in flight
+    for (int j = 0; wave + NW * j < ((DBG & 2) ? 0 : NS); ++j) {
+      int len = __builtin_amdgcn_readlane(sg_len, j);
+      if (len < 0) {  // run of fixed rows: zeros when storing, untouched when accumulating
+        if (!out.overwrite) continue;
+        len = -len;
+      }
+      double *dst = out.vals + __builtin_amdgcn_readlane(sg_base, j);
+      const double *src = acc + __builtin_amdgcn_readlane(sg_acc, j);
+      if (out.overwrite) {
+        for (int k = lane; k < len; k += 64) dst[k] = src[k];
+      } else {
+        for (int k = lane; k < len; k += 64) dst[k] += src[k];
+      }
+    }
+    lds_barrier();  // every wave has read its runs out of the accumulator
+    zero_acc();
+    lds_barrier();
+    cur = nxt;
+  }
+}
+
 size_t k2_lds_bytes(const RowBlocksDev &rb, int n, int slot_bytes) {
   const size_t acc = ((size_t)rb.lds_acc + 1) / 2 * 2 * sizeof(double);
   const size_t slots = ((size_t)rb.lds_pairs * n * slot_bytes + 15) / 16 * 16;
@@ -464,10 +637,31 @@ void launch_k2_t(RowBlocksDev rb, const AffineDev &af, const RowOut &out, double
   const size_t lds = k2_lds_bytes(rb, N, sizeof(SlotT));
   MHA_REQUIRE(lds <= 160 * 1024, MHA_ERR_INVALID, "row-owner kernel needs " << lds << " B of LDS (> 160 KiB)");
   MHA_REQUIRE(rb.lds_acc < 65536, MHA_ERR_INVALID, "row-owner kernel: accumulator offsets must fit 16 bits");
-  auto kern = row_owner_jacobian_kernel<DIM, N, NT, SlotT>;
-  MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, rb, af.erec, af.khat, static_cast<const uint4 *>(af.slot),
-                     af.pair_off16, out, su, st);
+  int mode = 1, per_cu = 3, dbg = 0;
+  if (const char *e = std::getenv("MHA_K2_MODE")) mode = std::atoi(e);            // tuning / profiling knobs
+  if (const char *e = std::getenv("MHA_K2_WGS_PER_CU")) per_cu = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("MHA_K2_ABLATE")) dbg = std::atoi(e);
+  if (mode == 1) {
+    MHA_REQUIRE(rb.lds_elems <= kMaxBlockElems && rb.lds_pairs <= kMaxBlockPairs && rb.lds_segs <= 64 * (NT / 64),
+                MHA_ERR_INVALID, "persistent row-owner kernel: row block exceeds its caps");
+    const size_t lds_p = lds + (size_t)rb.lds_elems * kERec * sizeof(double);
+    auto go = [&](auto kern) {
+      MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      hipLaunchKernelGGL(kern, dim3(std::min(grid, 256 * per_cu)), dim3(NT), lds_p, stream, rb, af.erec, af.khat,
+                         static_cast<const uint4 *>(af.slot), af.pair_off16, out, su, st);
+    };
+    switch (dbg) {
+      case 1: go(row_owner_jacobian_persistent_kernel<DIM, N, NT, SlotT, 1>); break;
+      case 2: go(row_owner_jacobian_persistent_kernel<DIM, N, NT, SlotT, 2>); break;
+      case 3: go(row_owner_jacobian_persistent_kernel<DIM, N, NT, SlotT, 3>); break;
+      default: go(row_owner_jacobian_persistent_kernel<DIM, N, NT, SlotT, 0>); break;
+    }
+  } else {
+    auto kern = row_owner_jacobian_kernel<DIM, N, NT, SlotT>;
+    MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, rb, af.erec, af.khat,
+                       static_cast<const uint4 *>(af.slot), af.pair_off16, out, su, st);
+  }
   MHA_HIP(hipGetLastError());
 }
 
@@ -553,7 +747,12 @@ void launch_row_owner_jacobian(int dim, int n, const RowBlocksDev &rb, const Aff
   if (dim == 2 && n == 9) return launch_k2<2, 9, 128>(rb, af, out, scale_u, scale_t, stream);
   if (dim == 2 && n == 25) return launch_k2<2, 25, 320>(rb, af, out, scale_u, scale_t, stream);
   if (dim == 3 && n == 8) return launch_k2<3, 8, 64>(rb, af, out, scale_u, scale_t, stream);
-  if (dim == 3 && n == 27) return launch_k2<3, 27, 384>(rb, af, out, scale_u, scale_t, stream);
+  if (dim == 3 && n == 27) {
+    const char *e = std::getenv("MHA_K2_NT");  // tuning knob
+    if (e && std::atoi(e) == 384) return launch_k2<3, 27, 384>(rb, af, out, scale_u, scale_t, stream);
+    if (e && std::atoi(e) == 256) return launch_k2<3, 27, 256>(rb, af, out, scale_u, scale_t, stream);
+    return launch_k2<3, 27, 192>(rb, af, out, scale_u, scale_t, stream);
+  }
   MHA_REQUIRE(false, MHA_ERR_INVALID, "row-owner Jacobian kernel: unsupported (dim, dofs/elem)");
 }
 
