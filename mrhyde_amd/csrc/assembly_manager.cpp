@@ -426,6 +426,41 @@ void AssemblyManager::prepareRowOwner() {
   launch_build_block_slots(b, rowBlocksDev(), ro.slot.data(), ro.slot_bytes, stream_);
   ro.erec.resize(std::max<size_t>(8, rb.elems.size() * 8));
   launch_build_erec(dim_, rowBlocksDev(), ro.geo.data(), ro.erec.data(), static_cast<int>(rb.elems.size()), stream_);
+  // 4b. lane layout of K2: pair up LID slots that are usually owned together by the same (block, element),
+  //     so that a wave-instruction working on two slots side by side is either skipped or mostly busy.
+  {
+    std::vector<double> both(static_cast<size_t>(n_) * n_, 0.0), cnt(n_, 0.0);
+    const size_t stride = std::max<size_t>(1, rb.emask.size() / 200000);  // a sample is plenty
+    for (size_t i = 0; i < rb.emask.size(); i += stride) {
+      const uint32_t m = static_cast<uint32_t>(rb.emask[i]);
+      for (int a = 0; a < n_ && a < 32; ++a) {
+        if (!((m >> a) & 1u)) continue;
+        cnt[a] += 1.0;
+        for (int c = a + 1; c < n_ && c < 32; ++c)
+          if ((m >> c) & 1u) both[static_cast<size_t>(a) * n_ + c] += 1.0;
+      }
+    }
+    std::vector<int> pairs(2 * ((n_ + 1) / 2), -1);
+    std::vector<char> used(n_, 0);
+    for (int r = 0; r < n_ / 2; ++r) {  // greedy matching by Jaccard similarity of ownership
+      int ba = -1, bc = -1;
+      double best = -1.0;
+      for (int a = 0; a < n_; ++a)
+        for (int c = a + 1; c < n_; ++c) {
+          if (used[a] || used[c]) continue;
+          const double uni = cnt[a] + cnt[c] - both[static_cast<size_t>(a) * n_ + c];
+          const double jac = uni > 0.0 ? both[static_cast<size_t>(a) * n_ + c] / uni : 0.0;
+          if (jac > best) { best = jac; ba = a; bc = c; }
+        }
+      pairs[2 * r] = ba;
+      pairs[2 * r + 1] = bc;
+      used[ba] = used[bc] = 1;
+    }
+    if (n_ % 2)
+      for (int a = 0; a < n_; ++a)
+        if (!used[a]) pairs[2 * (n_ / 2)] = a;
+    ro.slot_pair.upload(pairs);
+  }
   // 5. reference tables of the affine path, in LID-slot space
   const int nsym = dim_ * (dim_ + 1) / 2;
   std::vector<double> khat(static_cast<size_t>(nsym + 1) * n_ * n_, 0.0);
@@ -509,6 +544,7 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   af.geo = ro_.geo.data();
   af.erec = ro_.erec.data();
   af.pair_off16 = ro_.pair_off16.data();
+  af.slot_pair = ro_.slot_pair.data();
   RowOut out;
   out.res = res;
   out.vals = crs_vals;

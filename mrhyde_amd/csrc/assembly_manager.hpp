@@ -87,6 +87,7 @@ class AssemblyManager {
     DeviceBuffer<double> geo;  // [E][kGeoRec] cached element geometry
     DeviceBuffer<double> erec;  // block-major element records of K2
     DeviceBuffer<uint16_t> pair_off16;
+    DeviceBuffer<int> slot_pair;  // LID slots paired by co-ownership (K2 lane layout)
     DeviceBuffer<uint32_t> pairs;
     DeviceBuffer<uint8_t> slot, flags;
     DeviceBuffer<double> khat, phi, dphi, gw, gp;

@@ -90,6 +90,7 @@ struct AffineDev {
   const double *geo = nullptr;     // [E][kGeoRec] cached element geometry (affine elements)
   const double *erec = nullptr;    // block-major [touched element][8]: geometric factors + ownership data
   const uint16_t *pair_off16 = nullptr;  // block-major [pair]: accumulator offset of the pair's row
+  const int *slot_pair = nullptr;        // [2*ceil(n/2)]: LID slots paired by co-ownership (-1 = none), K2's lane layout
   int slot_bytes = 1;              // 1 (uint8) or 2 (uint16)
 };
 

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kK1Threads) void thermal_affine_element_kernel(Bloc
             r += E[S::O_RQ + q] * a0 * a1 + E[S::O_F + q * DIM] * d0 * a1 + E[S::O_F + q * DIM + 1] * a0 * d1;
           }
         (void)i2;
-      } else {
+      } else {  // (a sum-factorised form of this loop nest was measured 15 % slower: longer dependent chains)
 #pragma unroll
         for (int q2 = 0; q2 < NQ1; ++q2)
 #pragma unroll
@@ -469,15 +469,19 @@ __global__ __launch_bounds__(NT, (NT == 384 ? 6 : 1)) void row_owner_jacobian_ke
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxBlockElems = 27, kMaxBlockPairs = 256;  // caps of a row block (host: prepareRowOwner)
 
+
 template <int DIM, int N, int NT, typename SlotT, int DBG>
 __global__ __launch_bounds__(NT, (NT == 384 ? 5 : (NT == 256 ? 4 : 1))) void row_owner_jacobian_persistent_kernel(
     RowBlocksDev rb, const double *__restrict__ erec, const double *__restrict__ khat,
-    const uint4 *__restrict__ slot16, const uint16_t *__restrict__ pair_off16, RowOut out, double su, double st) {
-  constexpr int NSYM = DIM * (DIM + 1) / 2, NN2 = N * N, NITER = (NN2 + NT - 1) / NT;
-  static_assert(N <= 32, "ownership masks are 32 bits wide");
+    const uint4 *__restrict__ slot16, const uint16_t *__restrict__ pair_off16, const int *__restrict__ slot_pair,
+    RowOut out, double su, double st) {
+  constexpr int NSYM = DIM * (DIM + 1) / 2, NN2 = N * N;
+  constexpr int NW = NT / 64;
+  constexpr int NR = (N + 1) / 2;             // slot ranges: two LID slots (si) per wave-instruction
+  constexpr int NITER = (NR + NW - 1) / NW;   // ranges (register sets) per wave
+  static_assert(N <= 32, "one LID slot per 32-lane half; ownership masks are 32 bits wide");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nwork = rb.block_list ? rb.list_len : rb.num_blocks;
-  constexpr int NW = NT / 64;
 
   extern __shared__ double smem[];
   double *acc = smem;                                                    // [lds_acc], lds_acc even
@@ -486,25 +490,27 @@ __global__ __launch_bounds__(NT, (NT == 384 ? 5 : (NT == 256 ? 4 : 1))) void row
   uint16_t *s_pairoff = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(s_slot) +
                                                      ((size_t)rb.lds_pairs * N * sizeof(SlotT) + 15) / 16 * 16);
 
-  // this lane's reference table entries (pre-scaled by the run-time factors), kept in registers for the
-  // life of the workgroup; the LID slots (si) this WAVE covers, as a bit mask, for the wave-level skip
+  // Lane layout: each 32-lane half of a wave works on ONE LID slot si at a time, its lanes are the
+  // columns sj.  Range r = (si_a, si_b) puts two slots side by side in one wave-instruction; the host
+  // pairs slots that are usually owned together (slot_pair), so a visit is either skipped by the whole
+  // wave or keeps most lanes busy.  Wave w owns ranges w, w+NW, ...; the reference-table entries of
+  // "its" (si,sj) -- pre-scaled by the run-time factors -- stay in registers for the life of the workgroup.
   double kh[NITER][NSYM + 1];
   unsigned my_bit[NITER], my_low[NITER];
-  int my_sj[NITER];
+  const int my_sj = min(lane & 31, N - 1);
   unsigned wave_si = 0u;
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
-    const int idx = tid + it * NT;
-    const int si = (idx < NN2) ? idx / N : 0;
-    my_bit[it] = (idx < NN2) ? (1u << si) : 0u;
-    my_low[it] = (1u << si) - 1u;
-    my_sj[it] = idx - si * N;
+    const int r = wave + it * NW;
+    const int si = (r < NR) ? slot_pair[2 * r + (lane >> 5)] : -1;  // -1: no slot (odd N, or past the last range)
+    const bool ok = si >= 0 && (lane & 31) < N;
+    my_bit[it] = ok ? (1u << si) : 0u;
+    my_low[it] = ok ? (1u << si) - 1u : 0u;
 #pragma unroll
-    for (int k = 0; k <= NSYM; ++k) kh[it][k] = (k < NSYM ? su : st) * khat[k * NN2 + min(idx, NN2 - 1)];
-    const int lo = wave * 64 + it * NT, hi = min(lo + 63, NN2 - 1);
-    if (lo < NN2) {
-      const int a = lo / N, c = hi / N;
-      wave_si |= (c >= 31 ? 0xffffffffu : ((1u << (c + 1)) - 1u)) & ~((1u << a) - 1u);
+    for (int k = 0; k <= NSYM; ++k) kh[it][k] = (k < NSYM ? su : st) * khat[k * NN2 + max(si, 0) * N + my_sj];
+    if (r < NR) {
+      const int sa = slot_pair[2 * r], sb = slot_pair[2 * r + 1];
+      wave_si |= (sa >= 0 ? 1u << sa : 0u) | (sb >= 0 ? 1u << sb : 0u);
     }
   }
 
@@ -577,15 +583,19 @@ __global__ __launch_bounds__(NT, (NT == 384 ? 5 : (NT == 256 ? 4 : 1))) void row
 
     // contributions: lane (si,sj) walks the block's elements; the 64-byte element record is read from LDS at a
     // wave-uniform address; a wave skips elements none of whose owned rows fall into its si range
+    // The LDS array is the busiest unit of this kernel, and wave-uniform reads cost as much as any other:
+    // ownership data of all elements are fetched once per wave (lane t <- element t) and consulted through
+    // v_readlane; the geometric factors are read with 16-byte accesses, only for elements the wave works on.
+    const double mp_l = s_erec[min(lane, T - 1) * kERec + 7];
+    const int mk_l = __double2loint(mp_l), pb_l = __double2hiint(mp_l);
     for (int t = 0; t < ((DBG & 1) ? 0 : T); ++t) {
-      const double *E = s_erec + t * kERec;
-      const double mp = E[7];
-      const unsigned mask = (unsigned)__double2loint(mp);
+      const unsigned mask = (unsigned)__builtin_amdgcn_readlane(mk_l, t);
       if ((mask & wave_si) == 0u) continue;
-      const int pb = __double2hiint(mp);
-      double g[NSYM + 1];
-#pragma unroll
-      for (int k = 0; k <= NSYM; ++k) g[k] = E[k];
+      const int pb = __builtin_amdgcn_readlane(pb_l, t);
+      // (fetching the factors through v_readlane instead was measured 20 % slower: VALU is as loaded as LDS)
+      const double2 *E2 = reinterpret_cast<const double2 *>(s_erec + t * kERec);
+      const double2 e0 = E2[0], e1 = E2[1], e2 = E2[2];
+      const double g[7] = {e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, s_erec[t * kERec + 6]};
 #pragma unroll
       for (int it = 0; it < NITER; ++it) {
         if (mask & my_bit[it]) {
@@ -593,7 +603,7 @@ __global__ __launch_bounds__(NT, (NT == 384 ? 5 : (NT == 256 ? 4 : 1))) void row
           double v = g[NSYM] * kh[it][NSYM];
 #pragma unroll
           for (int k = 0; k < NSYM; ++k) v += g[k] * kh[it][k];
-          atomicAdd(&acc[(int)s_pairoff[p] + (int)s_slot[p * N + my_sj[it]]], v);
+          atomicAdd(&acc[(int)s_pairoff[p] + (int)s_slot[p * N + my_sj]], v);
         }
       }
     }
@@ -648,7 +658,7 @@ void launch_k2_t(RowBlocksDev rb, const AffineDev &af, const RowOut &out, double
     auto go = [&](auto kern) {
       MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
       hipLaunchKernelGGL(kern, dim3(std::min(grid, 256 * per_cu)), dim3(NT), lds_p, stream, rb, af.erec, af.khat,
-                         static_cast<const uint4 *>(af.slot), af.pair_off16, out, su, st);
+                         static_cast<const uint4 *>(af.slot), af.pair_off16, af.slot_pair, out, su, st);
     };
     switch (dbg) {
       case 1: go(row_owner_jacobian_persistent_kernel<DIM, N, NT, SlotT, 1>); break;
