@@ -67,6 +67,18 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
+def measured_traffic(args, blk):
+    """HBM bytes per assembly from the committed PMC run of this exact workload (profiles/r1_traffic.json:
+    FETCH_SIZE x2 + WRITE_SIZE, the gfx950 corrections of MI355X_MICROARCH.md), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        if (t["ncell"], t["order"], t["mesh"]) == (args.ncell, args.order, args.mesh) and blk.info("last_path") == t["path"]:
+            return t["hbm_bytes_per_assembly"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(dim, order, qdeg, ncell_sample, threads, target_s=12.0, max_reps=8):
     """Oracle ("port" of the reference data flow) timed on the host cores on a bounded sample."""
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
@@ -117,10 +129,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the MI355X path has no CPU fallback"
+    # MHA_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- lets the N>1 code path run on a
+    # one-GPU box; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("MHA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     dim, order, qdeg = 3, args.order, 2 * args.order
     ncell = (args.ncell,) * 3
@@ -221,8 +241,10 @@ def main():
                        "partition": "z-slabs, 1 per GPU" if world > 1 else "single block",
                        "shared_row_bytes_per_step": exch.bytes_on_wire() if exch else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": kernel_ms, "bytes_per_elem": b_elem},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, blk),
+                         "kernel_ms": kernel_ms, "bytes_per_elem": b_elem,
+                         "kernels": "thermal_affine_element_kernel + row_owner_jacobian_persistent_kernel (HIP events "
+                                    "around both on the context's stream)"},
         }
         if not args.no_cpu_baseline:
             threads = host_threads()

@@ -47,6 +47,26 @@ class SlabExchange:
             self.recv_res = torch.zeros(self.P, dtype=torch.float64, device=device)
             self.remote_vals = torch.zeros(int((~inplane).sum()), dtype=torch.float64, device=device)
 
+    def _export_add_staged(self, res, vals):
+        """Same exchange with host staging (gloo cannot move device buffers); used only to rehearse N>1 on one GPU."""
+        import torch.distributed as dist
+        ops, keep = [], []
+        if self.has_lower:
+            a, b = vals[:self.nsend].cpu(), res[:self.P].cpu()
+            keep += [a, b]
+            ops += [dist.P2POp(dist.isend, a, self.rank - 1), dist.P2POp(dist.isend, b, self.rank - 1)]
+        if self.has_upper:
+            rv, rr = self.recv_vals.cpu(), self.recv_res.cpu()
+            ops += [dist.P2POp(dist.irecv, rv, self.rank + 1), dist.P2POp(dist.irecv, rr, self.rank + 1)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if self.has_upper:
+            self.recv_vals.copy_(rv)
+            self.recv_res.copy_(rr)
+            vals.index_add_(0, self.dst_pos, self.recv_vals[self.src_idx])
+            res[self.top0:] += self.recv_res
+            self.remote_vals.copy_(self.recv_vals[self.remote_idx])
+
     def bytes_on_wire(self):
         return (self.nsend + self.P) * 8
 
@@ -55,6 +75,8 @@ class SlabExchange:
         import torch.distributed as dist
         if self.world == 1:
             return
+        if dist.get_backend() == "gloo" and vals.is_cuda:
+            return self._export_add_staged(res, vals)  # rehearsal on one GPU: gloo moves host buffers
         ops = []
         if self.has_lower:
             ops.append(dist.P2POp(dist.isend, vals[:self.nsend], self.rank - 1))
