@@ -38,6 +38,10 @@ AssemblyManager::AssemblyManager(const mha_block_desc &desc) {
   d_ref_wts_.upload(ref_.wts);
   d_nodeval_.upload(ref_.nodeval);
   d_nodegrad_.upload(ref_.nodegrad);
+  d_phi1d_.upload(ref_.phi1d);
+  d_dphi1d_.upload(ref_.dphi1d);
+  d_gw1d_.upload(ref_.gauss_wts);
+  d_gp1d_.upload(ref_.gauss_pts);
   MHA_HIP(hipEventCreate(&ev0_));
   MHA_HIP(hipEventCreate(&ev1_));
 
@@ -103,6 +107,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   d_colind_.upload(h_colind_);
   has_graph_ = true;
   ro_ = RowOwnerData();
+  has_elem_slot_ = false;
 }
 
 void AssemblyManager::selectPhysics(int physics_id) {
@@ -192,6 +197,33 @@ void AssemblyManager::bindState(const double *u, const double *u_prev, const dou
   wkset_.stream = stream_;
 }
 
+// element-major slot map: position of (row LIDs[e][si], col LIDs[e][sj]) inside the CRS row -- replaces the
+// column search of sumIntoValues (assemblyManager.cpp:4138) in the general-element kernel
+void AssemblyManager::prepareElemSlots() {
+  if (has_elem_slot_) return;
+  int max_row = 0;
+  for (int r = 0; r < nrows_; ++r) max_row = std::max(max_row, h_rowptr_[r + 1] - h_rowptr_[r]);
+  MHA_REQUIRE(max_row <= 65536, MHA_ERR_INVALID, "CRS rows longer than 65536 entries are not supported");
+  elem_slot_bytes_ = max_row <= 256 ? 1 : 2;
+  d_elem_slot_.resize(static_cast<size_t>(nelem_) * n_ * n_ * elem_slot_bytes_);
+  launch_build_elem_slot_map(blockDev(), d_elem_slot_.data(), elem_slot_bytes_, stream_);
+  has_elem_slot_ = true;
+}
+
+void AssemblyManager::useGeneralKernel(bool need_slots) {
+  const char *off = std::getenv("MHA_BASELINE_ELEMENT_KERNEL");  // cross-check knob: force the baseline kernel
+  wkset_.use_general = !(off && off[0] == '1') && thermal_row_owner_supported(dim_, order_, ref_.nq1);
+  if (!wkset_.use_general) return;
+  if (need_slots) prepareElemSlots();
+  wkset_.tables = AffineDev();
+  wkset_.tables.phi1d = d_phi1d_.data();
+  wkset_.tables.dphi1d = d_dphi1d_.data();
+  wkset_.tables.gw1d = d_gw1d_.data();
+  wkset_.tables.gp1d = d_gp1d_.data();
+  wkset_.elem_slot = need_slots ? d_elem_slot_.data() : nullptr;
+  wkset_.elem_slot_bytes = elem_slot_bytes_;
+}
+
 void AssemblyManager::timedBegin() {
   if (timing_) MHA_HIP(hipEventRecord(ev0_, stream_));
 }
@@ -243,6 +275,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
       wkset_.res.compute_jacobian = compute_jacobian ? 1 : 0;
       wkset_.res.res = res;
       wkset_.res.crs_vals = compute_jacobian ? crs_vals : nullptr;
+      useGeneralKernel(compute_jacobian != 0);
       physics_->volumeResidual();
       break;
     }
@@ -263,6 +296,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         wkset_.res.local_base = e0;
         wkset_.res.local_J = d_local_J_.data();
         wkset_.res.local_res = d_local_res_.data();
+        wkset_.use_general = false;  // this path keeps the baseline element kernel: an independent implementation
         physics_->volumeResidual();
         BlockDev b = blockDev();
         b.e_begin = e0;
@@ -292,6 +326,7 @@ void AssemblyManager::computeLocalJacRes(int compute_jacobian, const double *u, 
   wkset_.res.compute_jacobian = compute_jacobian ? 1 : 0;
   wkset_.res.local_J = compute_jacobian ? local_J : nullptr;
   wkset_.res.local_res = local_res;
+  useGeneralKernel(false);
   timedBegin();
   physics_->volumeResidual();
   timedEnd();

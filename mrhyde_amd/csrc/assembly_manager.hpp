@@ -70,6 +70,12 @@ class AssemblyManager {
 
   RefTables ref_;
   DeviceBuffer<double> d_ref_basis_, d_ref_grad_, d_ref_wts_, d_nodeval_, d_nodegrad_;
+  DeviceBuffer<double> d_phi1d_, d_dphi1d_, d_gw1d_, d_gp1d_;
+  DeviceBuffer<uint8_t> d_elem_slot_;  // element-major CRS slot map of the general-element kernel (lazy)
+  int elem_slot_bytes_ = 1;
+  bool has_elem_slot_ = false;
+  void prepareElemSlots();
+  void useGeneralKernel(bool need_slots);
   DeviceBuffer<double> d_nodes_;
   DeviceBuffer<int32_t> d_lids_, d_offsets_, d_rowptr_, d_colind_;
   DeviceBuffer<uint8_t> d_fixed_;

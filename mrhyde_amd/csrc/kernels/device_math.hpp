@@ -63,6 +63,56 @@ __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int
   return s;
 }
 
+// reference-space gradient and value of sum_j c[j] N_j at integration point q (tensor basis)
+template <int DIM, int P, int NQ1>
+__device__ __forceinline__ void eval_ref(const double *c, const double *phi, const double *dphi, int q,
+                                         double *grad, double &val) {
+  constexpr int M = P + 1;
+  const int q0 = q % NQ1, q1 = (q / NQ1) % NQ1, q2 = q / (NQ1 * NQ1);
+  if constexpr (DIM == 2) {
+    double g0 = 0, g1 = 0, v = 0;
+#pragma unroll
+    for (int b1 = 0; b1 < M; ++b1) {
+      double s = 0, sd = 0;
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        const double u = c[b1 * M + a];
+        s += u * phi[a * NQ1 + q0];
+        sd += u * dphi[a * NQ1 + q0];
+      }
+      g0 += sd * phi[b1 * NQ1 + q1];
+      g1 += s * dphi[b1 * NQ1 + q1];
+      v += s * phi[b1 * NQ1 + q1];
+    }
+    grad[0] = g0; grad[1] = g1; val = v;
+    (void)q2;
+  } else {
+    double g0 = 0, g1 = 0, g2 = 0, v = 0;
+#pragma unroll
+    for (int c2 = 0; c2 < M; ++c2) {
+      double t = 0, tx = 0, ty = 0;
+#pragma unroll
+      for (int b1 = 0; b1 < M; ++b1) {
+        double s = 0, sd = 0;
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+          const double u = c[(c2 * M + b1) * M + a];
+          s += u * phi[a * NQ1 + q0];
+          sd += u * dphi[a * NQ1 + q0];
+        }
+        t += s * phi[b1 * NQ1 + q1];
+        tx += sd * phi[b1 * NQ1 + q1];
+        ty += s * dphi[b1 * NQ1 + q1];
+      }
+      g0 += tx * phi[c2 * NQ1 + q2];
+      g1 += ty * phi[c2 * NQ1 + q2];
+      g2 += t * dphi[c2 * NQ1 + q2];
+      v += t * phi[c2 * NQ1 + q2];
+    }
+    grad[0] = g0; grad[1] = g1; grad[DIM - 1] = g2; val = v;
+  }
+}
+
 // Position of column `col` in CRS row [lo,hi) (ascending colind), or -1.
 // Plays the role of the column search inside KokkosSparse sumIntoValues
 // (reference call site: src/managers/assemblyManager.cpp:4138).

@@ -43,4 +43,9 @@ void launch_thermal_affine_element(int dim, int order, int nq1, const BlockDev &
 void launch_row_owner_jacobian(int dim, int n, const RowBlocksDev &rb, const AffineDev &af, const RowOut &out,
                                double scale_u, double scale_t, hipStream_t stream);
 
+// thermal_general.hip: general elements (non-affine geometry / per-ip coefficients)
+void launch_build_elem_slot_map(const BlockDev &b, void *slot, int slot_bytes, hipStream_t stream);
+void launch_thermal_general(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph, const AffineDev &af,
+                            const void *slot, int slot_bytes, const ElemOut &out, hipStream_t stream);
+
 }  // namespace mha

@@ -37,7 +37,11 @@ void thermal::volumeResidual() {
   BlockDev b = w.dev;
   b.e_begin = w.first_elem;
   b.e_count = w.numElem;
-  launch_thermal_element(w.dimension, w.order, w.nq1, b, device_params(), w.res, w.stream);
+  if (w.use_general)
+    launch_thermal_general(w.dimension, w.order, w.nq1, b, device_params(), w.tables, w.elem_slot, w.elem_slot_bytes,
+                           w.res, w.stream);
+  else
+    launch_thermal_element(w.dimension, w.order, w.nq1, b, device_params(), w.res, w.stream);
 }
 
 std::unique_ptr<PhysicsBase> import_physics(int physics_id) {

@@ -44,6 +44,12 @@ class Workset {
   BlockDev dev;          // device pointers of the whole block
   TimeDev time_dev;      // seeding coefficients (Workset::computeSolnTransientSeeded)
   ElemOut res;           // where volumeResidual()'s result is accumulated
+  // general-element kernel (kernels/thermal_general.hip): 1-D tables and the element-major slot map;
+  // elem_slot == nullptr selects the baseline one-wave-per-element kernel (kernels/thermal_element.hip)
+  AffineDev tables;
+  const void *elem_slot = nullptr;
+  int elem_slot_bytes = 1;
+  bool use_general = false;
   hipStream_t stream = nullptr;
   int order = 0, nq1 = 0;
 
