@@ -561,24 +561,34 @@ __global__ __launch_bounds__(NT, (NT == 384 ? 5 : (NT == 256 ? 4 : 1))) void row
 
     if (next < nwork) tables_to_lds(nxt);  // the prefetch has had the whole accumulation phase to land
 
-    // stream the finished rows: each wave takes whole contiguous runs; stores are issued and left in flight
+    // stream the finished rows: each wave takes whole contiguous runs, reads four 512-byte pieces out of the
+    // accumulator, issues their stores (left in flight) and zeroes what it has just read -- no other wave
+    // touches these runs until the next block's accumulation, so one barrier per block suffices here
     for (int j = 0; wave + NW * j < ((DBG & 2) ? 0 : NS); ++j) {
       int len = __builtin_amdgcn_readlane(sg_len, j);
-      if (len < 0) {  // run of fixed rows: zeros when storing, untouched when accumulating
-        if (!out.overwrite) continue;
-        len = -len;
-      }
+      const bool fixed_run = len < 0;  // run of fixed rows: zeros when storing, untouched when accumulating
+      if (fixed_run) len = -len;
       double *dst = out.vals + __builtin_amdgcn_readlane(sg_base, j);
-      const double *src = acc + __builtin_amdgcn_readlane(sg_acc, j);
-      if (out.overwrite) {
-        for (int k = lane; k < len; k += 64) dst[k] = src[k];
-      } else {
-        for (int k = lane; k < len; k += 64) dst[k] += src[k];
+      double *src = acc + __builtin_amdgcn_readlane(sg_acc, j);
+      if (fixed_run && !out.overwrite) continue;
+      for (int k0 = 0; k0 < len; k0 += 256) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u * 64 + lane;
+          v[u] = (k < len) ? src[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u * 64 + lane;
+          if (k < len) {
+            if (out.overwrite) dst[k] = v[u]; else dst[k] += v[u];
+            src[k] = 0.0;
+          }
+        }
       }
     }
-    lds_barrier();  // every wave has read its runs out of the accumulator
-    zero_acc();
-    lds_barrier();
+    lds_barrier();  // accumulator read out and zeroed, next block's tables in place
     cur = nxt;
   }
 }
