@@ -7,7 +7,7 @@ R=/root/reference/regression
 D="$(dirname "$0")/reference"
 mkdir -p "$D"
 cp $R/discretization/HGRAD/mrhyde.gold                 $D/discretization_HGRAD.gold
-for c in 2D_verification 3D_verification 2D_verification_highorder 2D_verification_mpi; do
+for c in 2D_verification 3D_verification 2D_verification_highorder 2D_verification_mpi 2D_verification_transient 2D_mixed_bcs; do
   cp $R/thermal/$c/mrhyde.gold  $D/thermal_$c.gold
   cp $R/thermal/$c/input.yaml   $D/thermal_$c.input.yaml
 done

@@ -148,3 +148,58 @@ def test_q2_hex_invariants(oracle):
     for e in range(E):
         dense[np.ix_(m["lids"][e], m["lids"][e])] += out["local_J"][e]
     assert np.abs(dense - J.toarray()).max() < 1e-13
+
+
+def _transient_golds():
+    txt = open(os.path.join(GOLD, "thermal_2D_verification_transient.gold")).read()
+    return [(float(t), float(v)) for v, t in re.findall(r"for e = ([-0-9.e]+)\s+\(time = ([-0-9.e]+)\)", txt)]
+
+
+def run_transient_bwe(assemble, oracle, nsteps=20):
+    """regression/thermal/2D_verification_transient: backward Euler (Butcher 'BWE', BDF order 1), 20 steps on
+    [0,1]; source (8 pi^2 sin 2pi t + 2pi cos 2pi t) sin 2pi x sin 2pi y evaluated at the stage time
+    t_n + c*dt with c = 1 (solverManager.cpp:500-503).  `assemble(u, u_prev, t, dt)` -> (J csr, rhs)."""
+    dim, order, qdeg = 2, 1, 2
+    m = oracle.mesh_structured(dim, order, (40, 40))
+    pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+    freq = [2 * np.pi] * 2
+    dt = 1.0 / nsteps
+    u = np.zeros(m["ndof"])
+    errs = [(0.0, 0.0)]
+    for n in range(nsteps):
+        t = (n + 1) * dt
+        u_prev = u.copy()
+        for _ in range(3):  # Newton: the problem is linear, the second pass only confirms convergence
+            J, rhs = assemble(m, pb, u, u_prev, t, dt)
+            if np.abs(rhs).max() < 1e-10:
+                break
+            u = u + spla.spsolve(J.tocsc(), rhs)
+        # L2 error at the assembly quadrature points (postprocessManager.cpp:1255-1268)
+        uh = np.einsum("ed,edp->ep", u[m["lids"][:, m["offsets"]]], pb["basis"])
+        ut = np.sin(2 * np.pi * t) * np.prod(np.sin(2 * np.pi * pb["ip"]), axis=2)
+        errs.append((t, float(np.sqrt(np.sum((uh - ut) ** 2 * pb["wts"])))))
+    return errs
+
+
+def test_thermal_2d_transient_gold(oracle):
+    """Pins the transient seeding (workset.cpp:589-623: alpha_u, alpha_t, beta_t) end to end: 20 printed L2 errors."""
+    A, b, bdf = np.array([[1.0]]), np.array([1.0]), np.array([1.0, -1.0])
+
+    def assemble(m, pb, u, u_prev, t, dt):
+        amp = 8 * np.pi ** 2 * np.sin(2 * np.pi * t) + 2 * np.pi * np.cos(2 * np.pi * t)
+        tr = dict(u_prev=u_prev[:, None].copy(), u_stage=u[:, None].copy(), stage=0, butcher_A=A, butcher_b=b, bdf=bdf,
+                  dt=dt)
+        out = oracle.assemble_thermal(2, 1, 2, m["nodes"], m["lids"], m["offsets"], u, fixed=m["boundary"], pb=pb,
+                                      transient=tr, source=("sinprod", amp, [2 * np.pi] * 2))
+        oracle.apply_dbc_diag(m["boundary"], out["rowptr"], out["colind"], out["crs_vals"])
+        return sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]), shape=(m["ndof"],) * 2), out["res"]
+
+    errs = run_transient_bwe(assemble, oracle)
+    gold = _transient_golds()
+    assert len(gold) == 21 and len(errs) == 21
+    for (t, e), (tg, eg) in zip(errs, gold):
+        assert abs(t - tg) < 1e-12
+        if tg == 0.0:
+            assert eg == 0.0
+            continue
+        assert "%.6g" % e == "%.6g" % eg, (t, e, eg)

@@ -388,3 +388,39 @@ def test_error_behaviour_on_device():
     with pytest.raises(mrhyde_amd.MhaError) as ei:
         blk.set_mesh(m["nodes"], bad, m["offsets"], m["ndof"])
     assert ei.value.code == 1
+
+
+def test_thermal_transient_gold_end_to_end(oracle):
+    """regression/thermal/2D_verification_transient with the GPU assembling every Newton step: all 20 printed
+    L2 errors (backward Euler, BDF-1).  Pins the transient seeding of the HIP path against the reference's gold."""
+    torch = _torch()
+    import scipy.sparse as sp
+    import mrhyde_amd
+    from test_oracle_golden import _transient_golds, run_transient_bwe
+    A, b, bdf = np.array([[1.0]]), np.array([1.0]), np.array([1.0, -1.0])
+    state = {}
+
+    def assemble(m, pb, u, u_prev, t, dt):
+        if "blk" not in state:
+            blk = make_block(m, 2, 1, 2, fixed=m["boundary"])
+            state["blk"], state["graph"] = blk, blk.get_graph()
+            state["res"] = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+            state["vals"] = torch.zeros(len(state["graph"][1]), dtype=torch.float64, device="cuda")
+        blk = state["blk"]
+        rowptr, colind = state["graph"]
+        amp = 8 * np.pi ** 2 * np.sin(2 * np.pi * t) + 2 * np.pi * np.cos(2 * np.pi * t)
+        blk.set_function("thermal source", ("sinprod", amp, [2 * np.pi] * 2))
+        blk.set_time_integration(True, 1, 1, 0, dt, A, b, bdf)
+        tt = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+        blk.assemble_jacres(tt(u), state["res"], state["vals"], u_prev=tt(u_prev[:, None]), u_stage=tt(u[:, None]),
+                            overwrite=True)
+        blk.apply_dbc_diag(state["vals"])
+        torch.cuda.synchronize()
+        J = sp.csr_matrix((state["vals"].cpu().numpy(), colind, rowptr), shape=(m["ndof"],) * 2)
+        return J, state["res"].cpu().numpy()
+
+    errs = run_transient_bwe(assemble, oracle)
+    assert state["blk"].info("last_path") == mrhyde_amd.PATH_ROW_OWNER
+    for (t, e), (tg, eg) in zip(errs, _transient_golds()):
+        if tg > 0.0:
+            assert "%.6g" % e == "%.6g" % eg, (t, e, eg)
