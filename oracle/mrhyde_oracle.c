@@ -557,3 +557,257 @@ double orc_l2_error_sinprod(int dim, int order, int qdeg, int nelem, const int *
     }
   return sqrt(tot);
 }
+
+/* ------------------------------------------------------------------------ */
+/* boundary (side) terms                                                     */
+/* ------------------------------------------------------------------------ */
+
+static const int QUAD_SIDE[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}};
+static const int HEX_SIDE[6][4] = {{0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {0, 4, 7, 3}, {0, 3, 2, 1}, {4, 5, 6, 7}};
+
+int orc_side_sizes(int dim, int qdeg, int *nsides, int *nqs) {
+  if (dim < 2 || dim > 3) return -1;
+  *nsides = 2 * dim;
+  *nqs = ipow(orc_gauss_npts(qdeg), dim - 1);
+  return 0;
+}
+
+int orc_side_tables(int dim, int order, int qdeg, double *sip, double *swts, double *tanU, double *tanV,
+                    double *sbasis, double *sgrad, double *snodeval, double *snodegrad) {
+  int nb, nq, nn, ns, nqs;
+  if (orc_ref_sizes(dim, order, qdeg, &nb, &nq, &nn) || orc_side_sizes(dim, qdeg, &ns, &nqs)) return -1;
+  const int nq1 = orc_gauss_npts(qdeg), p1 = order + 1;
+  double gp[64], gw[64];
+  orc_gauss_line(nq1, gp, gw);
+  for (int q = 0; q < nqs; ++q) swts[q] = (dim == 2) ? gw[q] : gw[q % nq1] * gw[q / nq1];
+  for (int s = 0; s < ns; ++s) {
+    double v[4][3] = {{0}};
+    const int nsv = (dim == 2) ? 2 : 4;
+    for (int k = 0; k < nsv; ++k) {
+      const double *c = (dim == 2) ? QUAD_NODE[QUAD_SIDE[s][k]] : HEX_NODE[HEX_SIDE[s][k]];
+      for (int d = 0; d < dim; ++d) v[k][d] = c[d];
+    }
+    for (int d = 0; d < dim; ++d) {
+      if (dim == 2) {
+        tanU[s * dim + d] = 0.5 * (v[1][d] - v[0][d]); /* getReferenceEdgeTangent */
+        tanV[s * dim + d] = 0.0;
+      } else {                                         /* getReferenceFaceTangents */
+        tanU[s * dim + d] = 0.25 * (-v[0][d] + v[1][d] + v[2][d] - v[3][d]);
+        tanV[s * dim + d] = 0.25 * (-v[0][d] - v[1][d] + v[2][d] + v[3][d]);
+      }
+    }
+    for (int q = 0; q < nqs; ++q) {
+      double x[3] = {0, 0, 0};
+      if (dim == 2) {
+        const double t = gp[q];
+        for (int d = 0; d < dim; ++d) x[d] = 0.5 * (1 - t) * v[0][d] + 0.5 * (1 + t) * v[1][d];
+      } else {
+        const double a = gp[q % nq1], b = gp[q / nq1];
+        for (int d = 0; d < dim; ++d)
+          x[d] = 0.25 * ((1 - a) * (1 - b) * v[0][d] + (1 + a) * (1 - b) * v[1][d] + (1 + a) * (1 + b) * v[2][d] +
+                         (1 - a) * (1 + b) * v[3][d]);
+      }
+      for (int d = 0; d < dim; ++d) sip[(s * nqs + q) * dim + d] = x[d];
+      double bv[3][ORC_MAXP + 1], bd[3][ORC_MAXP + 1];
+      for (int d = 0; d < dim; ++d) orc_lagrange_1d(order, x[d], bv[d], bd[d]);
+      for (int f = 0; f < nb; ++f) {
+        int fi[3] = {f % p1, (f / p1) % p1, f / (p1 * p1)};
+        double val = 1.0;
+        for (int d = 0; d < dim; ++d) val *= bv[d][fi[d]];
+        sbasis[(s * nb + f) * nqs + q] = val;
+        for (int d = 0; d < dim; ++d) {
+          double g = 1.0;
+          for (int e = 0; e < dim; ++e) g *= (e == d) ? bd[e][fi[e]] : bv[e][fi[e]];
+          sgrad[((s * nb + f) * nqs + q) * dim + d] = g;
+        }
+      }
+      for (int n = 0; n < nn; ++n) {
+        const double *c = (dim == 2) ? QUAD_NODE[n] : HEX_NODE[n];
+        double val = 1.0;
+        for (int d = 0; d < dim; ++d) val *= 0.5 * (1.0 + c[d] * x[d]);
+        snodeval[(s * nn + n) * nqs + q] = val;
+        for (int d = 0; d < dim; ++d) {
+          double g = 1.0;
+          for (int e = 0; e < dim; ++e) g *= (e == d) ? 0.5 * c[e] : 0.5 * (1.0 + c[e] * x[e]);
+          snodegrad[((s * nn + n) * nqs + q) * dim + d] = g;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+typedef struct {
+  int nb, nq, nn, ns, nqs;
+  double *sip, *swts, *tanU, *tanV, *sbasis, *sgrad, *snv, *sng;
+} side_tab;
+
+static int side_tab_make(int dim, int order, int qdeg, side_tab *t) {
+  if (orc_ref_sizes(dim, order, qdeg, &t->nb, &t->nq, &t->nn) || orc_side_sizes(dim, qdeg, &t->ns, &t->nqs)) return -1;
+  t->sip = malloc(sizeof(double) * t->ns * t->nqs * dim);
+  t->swts = malloc(sizeof(double) * t->nqs);
+  t->tanU = malloc(sizeof(double) * t->ns * dim);
+  t->tanV = malloc(sizeof(double) * t->ns * dim);
+  t->sbasis = malloc(sizeof(double) * t->ns * t->nb * t->nqs);
+  t->sgrad = malloc(sizeof(double) * t->ns * t->nb * t->nqs * dim);
+  t->snv = malloc(sizeof(double) * t->ns * t->nn * t->nqs);
+  t->sng = malloc(sizeof(double) * t->ns * t->nn * t->nqs * dim);
+  return orc_side_tables(dim, order, qdeg, t->sip, t->swts, t->tanU, t->tanV, t->sbasis, t->sgrad, t->snv, t->sng);
+}
+
+static void side_tab_free(side_tab *t) {
+  free(t->sip); free(t->swts); free(t->tanU); free(t->tanV); free(t->sbasis); free(t->sgrad); free(t->snv); free(t->sng);
+}
+
+int orc_physical_side_basis(int dim, int order, int qdeg, int nbnd, const double *nodes, const int *belem,
+                            const int *bside, double *wts, double *normals, double *ip, double *basis,
+                            double *basis_grad) {
+  side_tab t;
+  if (side_tab_make(dim, order, qdeg, &t)) return -1;
+  const int n = t.nb, nn = t.nn, nqs = t.nqs;
+  for (int k = 0; k < nbnd; ++k) {
+    const double *xn = nodes + (size_t)belem[k] * nn * dim;
+    const int s = bside[k];
+    for (int q = 0; q < nqs; ++q) {
+      double J[9] = {0}, Ji[9] = {0}, det;
+      for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < dim; ++c) {
+          double sum = 0.0;
+          for (int v = 0; v < nn; ++v) sum += xn[v * dim + r] * t.sng[((s * nn + v) * nqs + q) * dim + c];
+          J[r * dim + c] = sum;
+        }
+      jac_inv_det(dim, J, Ji, &det);
+      double nrm[3] = {0, 0, 0}, w;
+      if (dim == 2) { /* t = J t_ref; n = R t, R = [[0,1],[-1,0]]; w = |t| w_ref (:1684-1697) */
+        double tx = J[0] * t.tanU[s * 2] + J[1] * t.tanU[s * 2 + 1], ty = J[2] * t.tanU[s * 2] + J[3] * t.tanU[s * 2 + 1];
+        nrm[0] = ty; nrm[1] = -tx;
+        w = sqrt(tx * tx + ty * ty) * t.swts[q];
+      } else {        /* n = (J tU) x (J tV); w = |n| w_ref (:1699-1710) */
+        double a[3], b[3];
+        for (int r = 0; r < 3; ++r) {
+          a[r] = J[r * 3] * t.tanU[s * 3] + J[r * 3 + 1] * t.tanU[s * 3 + 1] + J[r * 3 + 2] * t.tanU[s * 3 + 2];
+          b[r] = J[r * 3] * t.tanV[s * 3] + J[r * 3 + 1] * t.tanV[s * 3 + 1] + J[r * 3 + 2] * t.tanV[s * 3 + 2];
+        }
+        nrm[0] = a[1] * b[2] - a[2] * b[1]; nrm[1] = a[2] * b[0] - a[0] * b[2]; nrm[2] = a[0] * b[1] - a[1] * b[0];
+        w = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]) * t.swts[q];
+      }
+      double len = 0.0;
+      for (int d = 0; d < dim; ++d) len += nrm[d] * nrm[d];
+      len = sqrt(len);
+      if (wts) wts[(size_t)k * nqs + q] = w;
+      for (int d = 0; d < dim; ++d) {
+        if (normals) normals[((size_t)k * nqs + q) * dim + d] = nrm[d] * (1.0 / len); /* rescale (:1760-1786) */
+        if (ip) {
+          double sum = 0.0;
+          for (int v = 0; v < nn; ++v) sum += xn[v * dim + d] * t.snv[(s * nn + v) * nqs + q];
+          ip[((size_t)k * nqs + q) * dim + d] = sum;
+        }
+      }
+      for (int f = 0; f < n; ++f) {
+        if (basis) basis[((size_t)k * n + f) * nqs + q] = t.sbasis[(s * n + f) * nqs + q];
+        if (basis_grad)
+          for (int d = 0; d < dim; ++d) {
+            double sum = 0.0;
+            for (int c = 0; c < dim; ++c) sum += Ji[c * dim + d] * t.sgrad[((s * n + f) * nqs + q) * dim + c];
+            basis_grad[(((size_t)k * n + f) * nqs + q) * dim + d] = sum;
+          }
+      }
+    }
+  }
+  side_tab_free(&t);
+  return 0;
+}
+
+int orc_assemble_thermal_boundary(const orc_thermal_bnd_args *a) {
+  int n, nq, nn, ns, nqs;
+  if (orc_ref_sizes(a->dim, a->order, a->qdeg, &n, &nq, &nn) || orc_side_sizes(a->dim, a->qdeg, &ns, &nqs)) return -1;
+  const int dim = a->dim, W = orc_ad_width(n), W1 = W + 1, nb = a->nb;
+  if (nb <= 0) return 0;
+  double *wts = malloc(sizeof(double) * (size_t)nb * nqs), *nrm = malloc(sizeof(double) * (size_t)nb * nqs * dim);
+  double *ip = malloc(sizeof(double) * (size_t)nb * nqs * dim);
+  double *bas = malloc(sizeof(double) * (size_t)nb * n * nqs), *bgr = malloc(sizeof(double) * (size_t)nb * n * nqs * dim);
+  orc_physical_side_basis(dim, a->order, a->qdeg, nb, a->nodes, a->belem, a->bside, wts, nrm, ip, bas, bgr);
+  double *uAD = malloc(sizeof(double) * (size_t)n * W1), *res = malloc(sizeof(double) * (size_t)n * W1);
+  double *fld = malloc(sizeof(double) * (size_t)(1 + dim) * nqs * W1);
+  const double epen = 10.0, sf = a->form_param; /* thermal.cpp:236, 197 */
+  for (int k = 0; k < nb; ++k) {
+    const int *L = a->lids + (size_t)a->belem[k] * n;
+    /* performBoundaryGather + seeding (same rules as the volume loop) */
+    for (int dof = 0; dof < n; ++dof) {
+      double *ua = uAD + (size_t)dof * W1;
+      memset(ua, 0, sizeof(double) * W1);
+      const int off = a->offsets[dof], row = L[off];
+      const double cu = a->u[row];
+      if (!a->transient) {
+        ua[0] = cu;
+        if (a->compute_jacobian) ua[1 + off] = 1.0;
+      } else {
+        const int st = a->stage, S = a->nstages, NS = a->nsteps;
+        const double *cu_prev = a->u_prev + (size_t)row * NS, *cu_stage = a->u_stage + (size_t)row * S;
+        const double alpha_u = a->butcher_A[st * S + st] / a->butcher_b[st];
+        double beta_u = (1.0 - alpha_u) * cu_prev[0];
+        for (int s = 0; s < st; ++s) beta_u += a->butcher_A[st * S + s] / a->butcher_b[s] * (cu_stage[s] - cu_prev[0]);
+        ua[0] = alpha_u * cu + beta_u;
+        if (a->compute_jacobian) ua[1 + off] = alpha_u;
+      }
+    }
+    memset(res, 0, sizeof(double) * (size_t)n * W1);
+    /* side fields: e, grad(e)[x..] (evaluateSideSolutionField, workset.cpp:1069-1176) */
+    for (int f = 0; f <= dim; ++f)
+      for (int pt = 0; pt < nqs; ++pt) {
+        double *o = fld + ((size_t)f * nqs + pt) * W1;
+        for (int dof = 0; dof < n; ++dof) {
+          const double b = (f == 0) ? bas[((size_t)k * n + dof) * nqs + pt] : bgr[(((size_t)k * n + dof) * nqs + pt) * dim + (f - 1)];
+          const double *s = uAD + (size_t)dof * W1;
+          if (dof == 0) for (int j = 0; j < W1; ++j) o[j] = s[j] * b;
+          else for (int j = 0; j < W1; ++j) o[j] += s[j] * b;
+        }
+      }
+    /* getSideElementSize (workset.cpp:2682-2696) */
+    double vol = 0.0;
+    for (int pt = 0; pt < nqs; ++pt) vol += wts[(size_t)k * nqs + pt];
+    const double h = pow(vol, 1.0 / ((double)dim - 1.0));
+    for (int dof = 0; dof < n; ++dof) {
+      double *r = res + (size_t)a->offsets[dof] * W1;
+      for (int pt = 0; pt < nqs; ++pt) {
+        const double w = wts[(size_t)k * nqs + pt], bv = bas[((size_t)k * n + dof) * nqs + pt];
+        double g;
+        switch (a->data_kind) {
+          case 1: g = a->data_ip[(size_t)k * nqs + pt]; break;
+          case 2: g = a->data_amp; for (int d = 0; d < dim; ++d) g *= sin(a->data_freq[d] * ip[((size_t)k * nqs + pt) * dim + d]); break;
+          default: g = a->data_amp;
+        }
+        if (a->bc_type == ORC_BC_NEUMANN) { /* thermal.cpp:217-226 */
+          r[0] += -g * w * bv;
+        } else {                             /* weak Dirichlet, thermal.cpp:237-273 */
+          const double *T = fld + (size_t)pt * W1;
+          double bgn = 0.0;
+          for (int d = 0; d < dim; ++d) bgn += bgr[(((size_t)k * n + dof) * nqs + pt) * dim + d] * nrm[((size_t)k * nqs + pt) * dim + d];
+          for (int j = 0; j < W1; ++j) {
+            const double Tj = T[j] - (j == 0 ? g : 0.0);
+            double gTn = 0.0;
+            for (int d = 0; d < dim; ++d) gTn += fld[((size_t)(1 + d) * nqs + pt) * W1 + j] * nrm[((size_t)k * nqs + pt) * dim + d];
+            r[j] += epen / h * a->diff * Tj * w * bv;
+            r[j] += -a->diff * gTn * w * bv;
+            r[j] += -sf * a->diff * Tj * w * bgn;
+          }
+        }
+      }
+    }
+    /* scatter (same conventions as the volume scatter) */
+    for (int j = 0; j < n; ++j) {
+      const int row = a->offsets[j], rowIndex = L[row];
+      if (a->fixed && a->fixed[rowIndex]) continue;
+      const double *r = res + (size_t)row * W1;
+      if (a->res) a->res[rowIndex] += -r[0];
+      if (a->crs_vals && a->compute_jacobian)
+        for (int c = 0; c < n; ++c) {
+          const int col = a->offsets[c], gcol = L[col];
+          for (int p = a->rowptr[rowIndex]; p < a->rowptr[rowIndex + 1]; ++p)
+            if (a->colind[p] == gcol) { a->crs_vals[p] += r[1 + col]; break; }
+        }
+    }
+  }
+  free(wts); free(nrm); free(ip); free(bas); free(bgr); free(uAD); free(res); free(fld);
+  return 0;
+}

@@ -119,6 +119,50 @@ double orc_l2_error_sinprod(int dim, int order, int qdeg, int nelem, const int *
                             const int *offsets, const double *basis, const double *wts,
                             const double *ip, const double *u, const double *freq);
 
+/* ---- boundary (side) terms ----------------------------------------------------------------
+ * Reference side data (setReferenceData, discretizationInterface.cpp:523-548): side cubature mapped to
+ * the cell by CellTools::mapToReferenceSubcell, reference edge tangent (2-D) / face tangents (3-D), basis
+ * values and gradients at the side points.  Sides in shards order (quad edges {0,1},{1,2},{2,3},{3,0};
+ * hex faces {0,1,5,4},{1,2,6,5},{2,3,7,6},{0,4,7,3},{0,3,2,1},{4,5,6,7}).
+ * sip[ns][nqs][dim], swts[nqs], tanU[ns][dim], tanV[ns][dim], sbasis[ns][n][nqs], sgrad[ns][n][nqs][dim],
+ * snodeval[ns][nn][nqs], snodegrad[ns][nn][nqs][dim].                                              */
+int orc_side_sizes(int dim, int qdeg, int *nsides, int *nqs);
+int orc_side_tables(int dim, int order, int qdeg, double *sip, double *swts, double *tanU, double *tanV,
+                    double *sbasis, double *sgrad, double *snodeval, double *snodegrad);
+/* physical side data of boundary entries (getPhysicalBoundaryIntegrationData/Basis,
+ * discretizationInterface.cpp:1608-1790, 1810-1955): wts[nb][nqs], normals[nb][nqs][dim] (unit),
+ * ip[nb][nqs][dim], basis[nb][n][nqs], basis_grad[nb][n][nqs][dim]                                   */
+int orc_physical_side_basis(int dim, int order, int qdeg, int nb, const double *nodes, const int *belem,
+                            const int *bside, double *wts, double *normals, double *ip, double *basis,
+                            double *basis_grad);
+
+#define ORC_BC_NEUMANN 1
+#define ORC_BC_WEAK_DIRICHLET 2
+typedef struct orc_thermal_bnd_args {
+  int dim, order, qdeg, nrows;
+  const double *nodes;          /* [E][nnodes][dim] (all elements of the block)   */
+  const int *lids, *offsets;
+  const unsigned char *fixed;
+  const double *u;
+  int transient, nsteps, nstages, stage;
+  const double *u_prev, *u_stage, *butcher_A, *butcher_b, *bdf;
+  double dt;
+  int nb;                       /* boundary entries (element, local side)          */
+  const int *belem, *bside;
+  int bc_type;                  /* ORC_BC_*                                         */
+  int data_kind;                /* "Neumann e <side>" / "Dirichlet e <side>": 0 const, 1 array [nb][nqs], 2 sinprod */
+  double data_amp, data_freq[3];
+  const double *data_ip;
+  double diff;                  /* "thermal diffusion" at side ip (constant)        */
+  double form_param;            /* thermal.cpp:35, default 1                        */
+  int compute_jacobian;
+  const int *rowptr, *colind;
+  double *crs_vals, *res;
+} orc_thermal_bnd_args;
+/* thermal::boundaryResidual (src/physics/thermal.cpp:172-281) inside the boundary-group loop of
+ * assembleJacRes (assemblyManager.cpp:2518-2638): gather, seed, side fields, residual, scatter.      */
+int orc_assemble_thermal_boundary(const orc_thermal_bnd_args *a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,3 +222,120 @@ def l2_error_sinprod(dim, order, qdeg, lids, offsets, pb, u, freq):
     fr[:dim] = freq
     return lib().orc_l2_error_sinprod(dim, order, qdeg, lids.shape[0], _i(lids), _i(offsets), _d(pb["basis"]),
                                       _d(pb["wts"]), _d(pb["ip"]), _d(u), _d(fr))
+
+
+# ---- boundary (side) terms ------------------------------------------------------------------------------------
+class ThermalBndArgs(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int), ("order", C.c_int), ("qdeg", C.c_int), ("nrows", C.c_int),
+        ("nodes", _dp), ("lids", _ip), ("offsets", _ip), ("fixed", _up), ("u", _dp),
+        ("transient", C.c_int), ("nsteps", C.c_int), ("nstages", C.c_int), ("stage", C.c_int),
+        ("u_prev", _dp), ("u_stage", _dp), ("butcher_A", _dp), ("butcher_b", _dp), ("bdf", _dp),
+        ("dt", C.c_double),
+        ("nb", C.c_int), ("belem", _ip), ("bside", _ip),
+        ("bc_type", C.c_int), ("data_kind", C.c_int), ("data_amp", C.c_double), ("data_freq", C.c_double * 3),
+        ("data_ip", _dp),
+        ("diff", C.c_double), ("form_param", C.c_double),
+        ("compute_jacobian", C.c_int),
+        ("rowptr", _ip), ("colind", _ip), ("crs_vals", _dp), ("res", _dp),
+    ]
+
+
+BC_NEUMANN, BC_WEAK_DIRICHLET = 1, 2
+
+
+def side_sizes(dim, qdeg):
+    ns, nqs = C.c_int(), C.c_int()
+    assert lib().orc_side_sizes(dim, qdeg, C.byref(ns), C.byref(nqs)) == 0
+    return ns.value, nqs.value
+
+
+def side_tables(dim, order, qdeg):
+    nb, _, nn = ref_sizes(dim, order, qdeg)
+    ns, nqs = side_sizes(dim, qdeg)
+    t = dict(sip=np.zeros((ns, nqs, dim)), swts=np.zeros(nqs), tanU=np.zeros((ns, dim)), tanV=np.zeros((ns, dim)),
+             sbasis=np.zeros((ns, nb, nqs)), sgrad=np.zeros((ns, nb, nqs, dim)), snodeval=np.zeros((ns, nn, nqs)),
+             snodegrad=np.zeros((ns, nn, nqs, dim)))
+    rc = lib().orc_side_tables(dim, order, qdeg, _d(t["sip"]), _d(t["swts"]), _d(t["tanU"]), _d(t["tanV"]),
+                               _d(t["sbasis"]), _d(t["sgrad"]), _d(t["snodeval"]), _d(t["snodegrad"]))
+    assert rc == 0
+    return t
+
+
+def physical_side_basis(dim, order, qdeg, nodes, belem, bside):
+    nb, _, _ = ref_sizes(dim, order, qdeg)
+    _, nqs = side_sizes(dim, qdeg)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    belem = np.ascontiguousarray(belem, dtype=np.int32)
+    bside = np.ascontiguousarray(bside, dtype=np.int32)
+    k = len(belem)
+    out = dict(wts=np.zeros((k, nqs)), normals=np.zeros((k, nqs, dim)), ip=np.zeros((k, nqs, dim)),
+               basis=np.zeros((k, nb, nqs)), basis_grad=np.zeros((k, nb, nqs, dim)))
+    rc = lib().orc_physical_side_basis(dim, order, qdeg, k, _d(nodes), _i(belem), _i(bside), _d(out["wts"]),
+                                       _d(out["normals"]), _d(out["ip"]), _d(out["basis"]), _d(out["basis_grad"]))
+    assert rc == 0
+    return out
+
+
+def boundary_sides(dim, ncell, which):
+    """(element ids, local side ids) of a named side of the structured mesh: left/right (x), bottom/top (y),
+    back/front (z, 3-D) -- the panzer SquareQuad/CubeHex side-set names the reference's decks use.  Elements are
+    numbered x-fastest; local side ids are shards' (see oracle header)."""
+    nc = list(ncell) + [1] * (3 - len(ncell))
+    ix, iy, iz = np.meshgrid(np.arange(nc[0]), np.arange(nc[1]), np.arange(nc[2]), indexing="ij")
+    eid = (ix + nc[0] * (iy + nc[1] * iz)).astype(np.int32)
+    if dim == 2:
+        sel = {"bottom": (iy == 0, 0), "right": (ix == nc[0] - 1, 1), "top": (iy == nc[1] - 1, 2), "left": (ix == 0, 3)}
+    else:
+        sel = {"bottom": (iy == 0, 0), "right": (ix == nc[0] - 1, 1), "top": (iy == nc[1] - 1, 2), "left": (ix == 0, 3),
+               "back": (iz == 0, 4), "front": (iz == nc[2] - 1, 5)}
+    mask, side = sel[which]
+    e = np.sort(eid[mask])
+    return e, np.full(len(e), side, dtype=np.int32)
+
+
+def assemble_thermal_boundary(dim, order, qdeg, nodes, lids, offsets, u, belem, bside, bc_type, data, *, rowptr, colind,
+                              crs_vals=None, res=None, fixed=None, transient=None, diff=1.0, form_param=1.0,
+                              compute_jacobian=True):
+    """Accumulates the boundary contribution of one boundary group into crs_vals / res (both optional)."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    lids = np.ascontiguousarray(lids, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    belem = np.ascontiguousarray(belem, dtype=np.int32)
+    bside = np.ascontiguousarray(bside, dtype=np.int32)
+    a = ThermalBndArgs()
+    a.dim, a.order, a.qdeg, a.nrows = dim, order, qdeg, u.shape[0]
+    keep = [nodes, lids, offsets, u, belem, bside]
+    a.nodes, a.lids, a.offsets, a.u = _d(nodes), _i(lids), _i(offsets), _d(u)
+    if fixed is not None:
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        keep.append(fixed)
+        a.fixed = _u(fixed)
+    if transient is not None:
+        t = {k: np.ascontiguousarray(v, dtype=np.float64) if isinstance(v, np.ndarray) else v
+             for k, v in transient.items()}
+        keep.append(t)
+        a.transient = 1
+        a.nsteps, a.nstages, a.stage = t["u_prev"].shape[1], t["u_stage"].shape[1], t["stage"]
+        a.u_prev, a.u_stage = _d(t["u_prev"]), _d(t["u_stage"])
+        a.butcher_A, a.butcher_b, a.bdf = _d(t["butcher_A"]), _d(t["butcher_b"]), _d(t["bdf"])
+        a.dt = t["dt"]
+    a.nb, a.belem, a.bside, a.bc_type = len(belem), _i(belem), _i(bside), bc_type
+    kind = data[0]
+    if kind == "const":
+        a.data_kind, a.data_amp = 0, float(data[1])
+    elif kind == "array":
+        s = np.ascontiguousarray(data[1], dtype=np.float64)
+        keep.append(s)
+        a.data_kind, a.data_ip = 1, _d(s)
+    elif kind == "sinprod":
+        a.data_kind, a.data_amp = 2, float(data[1])
+        fr = list(data[2]) + [0.0] * (3 - len(data[2]))
+        a.data_freq = (C.c_double * 3)(*fr)
+    else:
+        raise ValueError(kind)
+    a.diff, a.form_param, a.compute_jacobian = diff, form_param, int(compute_jacobian)
+    a.rowptr, a.colind, a.crs_vals, a.res = _i(rowptr), _i(colind), _d(crs_vals), _d(res)
+    rc = lib().orc_assemble_thermal_boundary(C.byref(a))
+    assert rc == 0, rc

@@ -203,3 +203,107 @@ def test_thermal_2d_transient_gold(oracle):
             assert eg == 0.0
             continue
         assert "%.6g" % e == "%.6g" % eg, (t, e, eg)
+
+
+# ---- boundary terms ---------------------------------------------------------------------------------------------
+def test_side_tables_unit_square_and_cube(oracle):
+    """Side weights sum to the side measure, normals point outward, side ip lie on the side."""
+    for dim, ncell in ((2, (3, 2)), (3, (2, 3, 2))):
+        m = oracle.mesh_structured(dim, 1, ncell)
+        names = ["bottom", "right", "top", "left"] + (["back", "front"] if dim == 3 else [])
+        expect = {"bottom": (1, 0.0, -1), "top": (1, 1.0, 1), "left": (0, 0.0, -1), "right": (0, 1.0, 1),
+                  "back": (2, 0.0, -1), "front": (2, 1.0, 1)}
+        for name in names:
+            be, bs = oracle.boundary_sides(dim, ncell, name)
+            sb = oracle.physical_side_basis(dim, 1, 2, m["nodes"], be, bs)
+            axis, coord, sign = expect[name]
+            assert abs(sb["wts"].sum() - 1.0) < 1e-14
+            n_expect = np.zeros(dim)
+            n_expect[axis] = sign
+            assert np.abs(sb["normals"] - n_expect).max() < 1e-14, name
+            assert np.abs(sb["ip"][..., axis] - coord).max() < 1e-14
+            assert np.abs(sb["basis"].sum(axis=1) - 1.0).max() < 1e-14      # partition of unity on the side
+            assert np.abs(sb["basis_grad"].sum(axis=1)).max() < 1e-12
+
+
+def solve_mixed_bcs(assemble, oracle):
+    """regression/thermal/2D_mixed_bcs: Dirichlet left/right, Neumann top (2 pi sin 2pi x cos 2pi y) and bottom
+    (minus that), two Newton iterations.  `assemble(m, u, groups)` -> (J csr with DBC diag, rhs); groups =
+    [(elements, sides, data[nb][nqs])]."""
+    dim, order, qdeg, ncell = 2, 1, 2, (40, 40)
+    m = oracle.mesh_structured(dim, order, ncell)
+    pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+    x = np.zeros((m["ndof"], 2))
+    x[m["lids"][:, m["offsets"]].ravel()] = np.repeat(m["nodes"][:, [0, 1, 3, 2]], 1, axis=0).reshape(-1, 2)
+    fixed = ((np.abs(x[:, 0]) < 1e-12) | (np.abs(x[:, 0] - 1) < 1e-12)).astype(np.uint8)
+    groups = []
+    for name, sgn in (("top", 1.0), ("bottom", -1.0)):
+        be, bs = oracle.boundary_sides(dim, ncell, name)
+        sb = oracle.physical_side_basis(dim, order, qdeg, m["nodes"], be, bs)
+        g = sgn * 2 * np.pi * np.sin(2 * np.pi * sb["ip"][..., 0]) * np.cos(2 * np.pi * sb["ip"][..., 1])
+        groups.append((be, bs, g))
+    m["fixed"] = fixed
+    u = np.zeros(m["ndof"])
+    for _ in range(4):  # "max nonlinear iters: 4", converges in one
+        J, rhs = assemble(m, pb, u, groups)
+        u = u + spla.spsolve(J.tocsc(), rhs)
+        if np.max(np.abs(rhs)) < 1e-10:
+            break
+    return oracle.l2_error_sinprod(dim, order, qdeg, m["lids"], m["offsets"], pb, u, [2 * np.pi] * 2)
+
+
+def test_thermal_2d_mixed_bcs_gold(oracle):
+    """Pins the Neumann branch of thermal::boundaryResidual (thermal.cpp:217-226) + side integration data."""
+    def assemble(m, pb, u, groups):
+        out = oracle.assemble_thermal(2, 1, 2, m["nodes"], m["lids"], m["offsets"], u, fixed=m["fixed"], pb=pb,
+                                      source=("sinprod", 8 * np.pi ** 2, [2 * np.pi] * 2))
+        for be, bs, g in groups:
+            oracle.assemble_thermal_boundary(2, 1, 2, m["nodes"], m["lids"], m["offsets"], u, be, bs, oracle.BC_NEUMANN,
+                                             ("array", g), rowptr=out["rowptr"], colind=out["colind"],
+                                             crs_vals=out["crs_vals"], res=out["res"], fixed=m["fixed"])
+        oracle.apply_dbc_diag(m["fixed"], out["rowptr"], out["colind"], out["crs_vals"])
+        return sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]), shape=(m["ndof"],) * 2), out["res"]
+
+    err = solve_mixed_bcs(assemble, oracle)
+    assert "%.6g" % err == "%.6g" % _gold_l2("thermal_2D_mixed_bcs.gold") == "0.00102733"
+
+
+def test_weak_dirichlet_consistency(oracle):
+    """Weak Dirichlet (Nitsche, thermal.cpp:237-273) has no reference gold: check that the exact Jacobian from the AD
+    restatement matches finite differences of the residual, that it is symmetric for form_param = 1, and that a weakly
+    imposed problem converges to the same manufactured solution."""
+    dim, order, qdeg, ncell = 2, 2, 4, (8, 8)
+    m = oracle.mesh_structured(dim, order, ncell)
+    pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    rng = np.random.default_rng(5)
+    sides = [oracle.boundary_sides(dim, ncell, s) for s in ("left", "right", "bottom", "top")]
+
+    def bnd(u, jac=True, sf=1.0):
+        vals, res = np.zeros(rowptr[-1]), np.zeros(m["ndof"])
+        for be, bs in sides:
+            oracle.assemble_thermal_boundary(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, be, bs,
+                                             oracle.BC_WEAK_DIRICHLET, ("const", 0.3), rowptr=rowptr, colind=colind,
+                                             crs_vals=vals, res=res, diff=1.7, form_param=sf, compute_jacobian=jac)
+        return sp.csr_matrix((vals, colind, rowptr), shape=(m["ndof"],) * 2), res
+
+    u = rng.uniform(-1, 1, m["ndof"])
+    J, r0 = bnd(u)
+    assert abs(J - J.T).max() < 1e-11
+    Jm, _ = bnd(u, sf=-1.0)
+    assert abs(Jm - Jm.T).max() > 1e-3  # the non-symmetric variant really differs
+    du = rng.uniform(-1, 1, m["ndof"])
+    _, r1 = bnd(u + du, jac=False)
+    # residual is affine in u: res(u+du) - res(u) = -(J du)   (scatter stores -res.val())
+    assert np.abs((r1 - r0) + J @ du).max() < 1e-10 * max(1.0, np.abs(J @ du).max())
+    # full weakly-imposed solve: -lap u = 8 pi^2 sin sin, u = 0 on the boundary
+    vol = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], np.zeros(m["ndof"]), pb=pb,
+                                  source=("sinprod", 8 * np.pi ** 2, [2 * np.pi] * 2), rowptr=rowptr, colind=colind)
+    for be, bs in sides:
+        oracle.assemble_thermal_boundary(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], np.zeros(m["ndof"]), be,
+                                         bs, oracle.BC_WEAK_DIRICHLET, ("const", 0.0), rowptr=rowptr, colind=colind,
+                                         crs_vals=vol["crs_vals"], res=vol["res"])
+    Jf = sp.csr_matrix((vol["crs_vals"], colind, rowptr), shape=(m["ndof"],) * 2)
+    uh = spla.spsolve(Jf.tocsc(), vol["res"])
+    err = oracle.l2_error_sinprod(dim, order, qdeg, m["lids"], m["offsets"], pb, uh, [2 * np.pi] * 2)
+    assert err < 5e-3
