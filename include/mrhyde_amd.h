@@ -100,7 +100,8 @@ int mha_physics_select(mha_context *ctx, int physics_id);
 #define MHA_FUNC_CONSTANT 0
 #define MHA_FUNC_IP_ARRAY 1     /* dev pointer to [E][numip] f64                    */
 #define MHA_FUNC_SINPROD 2      /* amp * prod_d sin(freq[d]*x_d), evaluated at ip   */
-/* name in {"thermal source","thermal diffusion","specific heat","density"}         */
+/* name in {"thermal source","thermal diffusion","specific heat","density"} or a boundary
+ * data function "Neumann e <sidename>" / "Dirichlet e <sidename>" (see boundary groups)    */
 int mha_set_function(mha_context *ctx, const char *name, int kind, double amp, const double *freq3,
                      const double *ip_array_dev);
 
@@ -162,6 +163,38 @@ int mha_gather(mha_context *ctx, const double *vec_dev, double *elem_vals_dev);
 int mha_num_worksets(mha_context *ctx);
 int mha_workset_update(mha_context *ctx, int index);
 int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t extents[4], int *rank);
+
+/* ---- boundary groups -----------------------------------------------------------
+ * replaces: BoundaryGroup (src/tools/boundaryGroup.hpp:23-186, boundaryGroup.cpp:25-178), the
+ * boundary-group loop of assembleJacRes (assemblyManager.cpp:2518-2638: updateWorksetBoundary :5646-5710,
+ * performBoundaryGather :3650-3700, boundaryResidual, scatter), side integration data
+ * (discretizationInterface.cpp:1608-1790, 1810-1955) and thermal::boundaryResidual
+ * (src/physics/thermal.cpp:172-281).
+ * A group = the (element, local side) entries of one side set that carry one boundary-condition
+ * type for the variable; local side ids are the cell topology's (shards): quad edges
+ * {0,1},{1,2},{2,3},{3,0}; hex faces {0,1,5,4},{1,2,6,5},{2,3,7,6},{0,4,7,3},{0,3,2,1},{4,5,6,7}.
+ * The boundary data is the function "Neumann e <sidename>" / "Dirichlet e <sidename>"
+ * (thermal.cpp:217,238) registered with mha_set_function; an MHA_FUNC_IP_ARRAY for it is a
+ * dev array [num_sides][side numip].  Strong Dirichlet needs no group (is_fixed rows).
+ * mha_assemble_boundary ACCUMULATES all groups into res / crs_vals (call after the volume
+ * assembly of the same Newton step; MHA_ASSEMBLE_OVERWRITE is rejected).
+ * mha_boundary_update / mha_boundary_view expose the side data the reference keeps in the
+ * workset: "wts side" (num,numip) "x","y","z" (num,numip) "n[x]","n[y]","n[z]" (num,numip)
+ * "basis side" (num,n,numip,1) "basis_grad side" (num,n,numip,dim).                        */
+#define MHA_BC_NEUMANN 1
+#define MHA_BC_WEAK_DIRICHLET 2
+int mha_add_boundary_group(mha_context *ctx, const char *sidename, int bc_type, int num_sides,
+                           const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id);
+int mha_clear_boundary_groups(mha_context *ctx);
+int mha_num_boundary_groups(mha_context *ctx);
+int mha_assemble_boundary(mha_context *ctx, int flags, const double *u_dev, const double *u_prev_dev,
+                          const double *u_stage_dev, double *res_dev, double *crs_vals_dev);
+int mha_boundary_update(mha_context *ctx, int group_id);
+int mha_boundary_view(mha_context *ctx, int group_id, const char *name, void **dev_ptr, int64_t extents[4],
+                      int *rank);
+/* scalar settings of the physics module; thermal: "form_param" (thermal.cpp:35, default 1:
+ * symmetric Nitsche; -1 the non-symmetric variant)                                        */
+int mha_set_physics_parameter(mha_context *ctx, const char *name, double value);
 
 /* ---- structured mesh helper (input generation, not part of the hot path) ------
  * 2-D order 1 = SimpleMeshManager_Rectangle (src/tools/simplemeshmanager.hpp:639-675)

@@ -21,8 +21,10 @@ EXPORTS = [
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
     "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_get_info", "mha_set_timing",
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
-    "mha_row_partition_destroy",
+    "mha_row_partition_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
+    "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
 ]
+BC_NEUMANN, BC_WEAK_DIRICHLET = 1, 2
 
 
 class MhaError(RuntimeError):
@@ -79,6 +81,14 @@ def load_library():
         _lib.mha_set_timing.argtypes = [C.c_void_p, C.c_int]
         _lib.mha_get_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mha_block_destroy.argtypes = [C.c_void_p]
+        _lib.mha_add_boundary_group.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]
+        _lib.mha_clear_boundary_groups.argtypes = [C.c_void_p]
+        _lib.mha_num_boundary_groups.argtypes = [C.c_void_p]
+        _lib.mha_assemble_boundary.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        _lib.mha_boundary_update.argtypes = [C.c_void_p, C.c_int]
+        _lib.mha_boundary_view.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_set_physics_parameter.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     return _lib
 
 
@@ -249,6 +259,46 @@ class Block:
 
     def gather(self, vec, out):
         _check(load_library().mha_gather(self._h, _ptr(vec), _ptr(out)))
+
+    # -- boundary groups -------------------------------------------------------
+    def add_boundary_group(self, sidename, bc_type, elem_ids, side_ids):
+        e, s_ = _np(elem_ids, np.int32), _np(side_ids, np.int32)
+        gid = C.c_int()
+        _check(load_library().mha_add_boundary_group(self._h, sidename.encode(), bc_type, len(e),
+                                                     e.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p),
+                                                     C.byref(gid)))
+        return gid.value
+
+    def clear_boundary_groups(self):
+        _check(load_library().mha_clear_boundary_groups(self._h))
+
+    def num_boundary_groups(self):
+        return load_library().mha_num_boundary_groups(self._h)
+
+    def assemble_boundary(self, u, res, crs_vals=None, compute_jacobian=True, u_prev=None, u_stage=None, flags=None):
+        flags = (1 if compute_jacobian else 0) if flags is None else flags
+        _check(load_library().mha_assemble_boundary(self._h, flags, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(res),
+                                                    _ptr(crs_vals)))
+
+    def boundary_update(self, gid):
+        _check(load_library().mha_boundary_update(self._h, gid))
+
+    def boundary_view(self, gid, name):
+        p, ext, rank = C.c_void_p(), (C.c_int64 * 4)(), C.c_int()
+        _check(load_library().mha_boundary_view(self._h, gid, name.encode(), C.byref(p), ext, C.byref(rank)))
+        return p.value, tuple(ext[k] for k in range(rank.value))
+
+    def boundary_view_numpy(self, gid, name):
+        import torch
+        ptr, shape = self.boundary_view(gid, name)
+        out = np.zeros(shape, np.float64)
+        torch.cuda.synchronize()
+        rc = _hip_memcpy_dtoh(out.ctypes.data, ptr, out.size * out.itemsize)
+        assert rc == 0, rc
+        return out
+
+    def set_physics_parameter(self, name, value):
+        _check(load_library().mha_set_physics_parameter(self._h, name.encode(), float(value)))
 
     # -- workset views ---------------------------------------------------------
     def num_worksets(self):

@@ -61,6 +61,7 @@ AssemblyManager::~AssemblyManager() {
 // createGroups' copies of LIDs / nodes (reference: assemblyManager.cpp:656-688) + createFixedDOFs (:185-265)
 void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lids, const int32_t *offsets,
                               int nrows, const uint8_t *fixed) {
+  boundary_groups_.clear();  // entries refer to the previous mesh's element ids
   MHA_REQUIRE(nelem > 0 && nrows > 0 && nodes && lids && offsets, MHA_ERR_INVALID, "mha_set_mesh: null or empty input");
   const size_t nl = static_cast<size_t>(nelem) * n_;
   for (size_t k = 0; k < nl; ++k)
@@ -365,6 +366,152 @@ void AssemblyManager::worksetUpdate(int index) {
   wkset_.first_elem = index * wkset_.maxElem;
   wkset_.numElem = std::min(wkset_.maxElem, nelem_ - wkset_.first_elem);
   wkset_.update_views();
+}
+
+// ---------------------------------------------------------------------------------------------
+// boundary groups
+// ---------------------------------------------------------------------------------------------
+
+void AssemblyManager::prepareSideTables() {
+  if (has_side_tables_) return;
+  side_ref_ = make_side_tables(ref_);
+  d_side_wts_.upload(side_ref_.wts);
+  d_side_tanU_.upload(side_ref_.tanU);
+  d_side_tanV_.upload(side_ref_.tanV);
+  d_side_basis_.upload(side_ref_.basis);
+  d_side_grad_.upload(side_ref_.grad);
+  d_side_nodeval_.upload(side_ref_.nodeval);
+  d_side_nodegrad_.upload(side_ref_.nodegrad);
+  has_side_tables_ = true;
+}
+
+SideTablesDev AssemblyManager::sideTablesDev() const {
+  SideTablesDev t;
+  t.nsides = side_ref_.nsides;
+  t.nqs = side_ref_.nqs;
+  t.wts = d_side_wts_.data();
+  t.tanU = d_side_tanU_.data();
+  t.tanV = d_side_tanV_.data();
+  t.basis = d_side_basis_.data();
+  t.grad = d_side_grad_.data();
+  t.nodeval = d_side_nodeval_.data();
+  t.nodegrad = d_side_nodegrad_.data();
+  return t;
+}
+
+BoundaryDev AssemblyManager::boundaryDev(const BoundaryGroupData &g) const {
+  BoundaryDev b;
+  b.num = g.num;
+  b.elem = g.elem.data();
+  b.side = g.side.data();
+  b.bc_type = g.bc_type;
+  return b;
+}
+
+// reference: the BoundaryGroup constructor keeps (localElemID, localSideID, sidename) of one side set
+// (src/tools/boundaryGroup.cpp:25-108); the BC type is what bcs(var, side) holds for it.
+int AssemblyManager::addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,
+                                      const int32_t *side_ids) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  MHA_REQUIRE(bc_type == MHA_BC_NEUMANN || bc_type == MHA_BC_WEAK_DIRICHLET, MHA_ERR_INVALID,
+              "boundary-condition type must be MHA_BC_NEUMANN or MHA_BC_WEAK_DIRICHLET");
+  MHA_REQUIRE(num >= 0 && (num == 0 || (elem_ids && side_ids)), MHA_ERR_INVALID, "bad boundary entry arrays");
+  MHA_REQUIRE(!sidename.empty(), MHA_ERR_INVALID, "side name is empty");
+  prepareSideTables();
+  for (int k = 0; k < num; ++k) {
+    MHA_REQUIRE(elem_ids[k] >= 0 && elem_ids[k] < nelem_, MHA_ERR_INVALID,
+                "boundary entry " << k << ": element id " << elem_ids[k] << " out of range");
+    MHA_REQUIRE(side_ids[k] >= 0 && side_ids[k] < side_ref_.nsides, MHA_ERR_INVALID,
+                "boundary entry " << k << ": local side id " << side_ids[k] << " out of range");
+  }
+  MHA_REQUIRE(thermal_boundary_supported(n_, side_ref_.nqs), MHA_ERR_INVALID,
+              "boundary terms are not available for " << n_ << " dofs per element with " << side_ref_.nqs
+                                                      << " side integration points");
+  std::unique_ptr<BoundaryGroupData> g(new BoundaryGroupData());
+  g->sidename = sidename;
+  g->bc_type = bc_type;
+  g->num = num;
+  g->elem.upload(elem_ids, num);
+  g->side.upload(side_ids, num);
+  boundary_groups_.push_back(std::move(g));
+  return static_cast<int>(boundary_groups_.size()) - 1;
+}
+
+// reference: the boundary-group loop of assembleJacRes (assemblyManager.cpp:2518-2638): per group
+// updateWorksetBoundary, performBoundaryGather, physics boundaryResidual, scatter.  Accumulates.
+void AssemblyManager::assembleBoundary(int flags, const double *u, const double *u_prev, const double *u_stage,
+                                       double *res, double *crs_vals) {
+  const int compute_jacobian = (flags & MHA_ASSEMBLE_JACOBIAN) ? 1 : 0;
+  requireReady(true);
+  MHA_REQUIRE(!(flags & MHA_ASSEMBLE_OVERWRITE), MHA_ERR_INVALID,
+              "boundary terms are accumulated after the volume terms: MHA_ASSEMBLE_OVERWRITE is not valid here");
+  MHA_REQUIRE(res != nullptr, MHA_ERR_INVALID, "residual vector is null");
+  MHA_REQUIRE(!compute_jacobian || crs_vals, MHA_ERR_INVALID, "compute_jacobian set but crs_vals is null");
+  bindState(u, u_prev, u_stage);
+  timedBegin();
+  for (const auto &g : boundary_groups_) {
+    wkset_.sidename = g->sidename;
+    wkset_.current_bc = g->bc_type;
+    wkset_.bnd = boundaryDev(*g);
+    wkset_.side_tables = sideTablesDev();
+    wkset_.res = ElemOut();
+    wkset_.res.compute_jacobian = compute_jacobian;
+    wkset_.res.res = res;
+    wkset_.res.crs_vals = compute_jacobian ? crs_vals : nullptr;
+    physics_->boundaryResidual();
+  }
+  timedEnd();
+}
+
+// reference: BoundaryGroup::computeBasis -> getPhysicalBoundaryIntegrationData / getPhysicalBoundaryBasis
+// (src/tools/boundaryGroup.cpp:110-178)
+void AssemblyManager::boundaryUpdate(int group) {
+  MHA_REQUIRE(group >= 0 && group < numBoundaryGroups(), MHA_ERR_INVALID, "boundary group id out of range");
+  BoundaryGroupData &g = *boundary_groups_[group];
+  const size_t nqs = side_ref_.nqs, num = g.num;
+  g.wts.resize(num * nqs);
+  for (int d = 0; d < dim_; ++d) { g.xyz[d].resize(num * nqs); g.nrm[d].resize(num * nqs); }
+  g.basis.resize(num * n_ * nqs);
+  g.basis_grad.resize(num * n_ * nqs * dim_);
+  BoundaryViewsDev v;
+  v.wts = g.wts.data();
+  for (int d = 0; d < dim_; ++d) { v.xyz[d] = g.xyz[d].data(); v.nrm[d] = g.nrm[d].data(); }
+  v.basis = g.basis.data();
+  v.basis_grad = g.basis_grad.data();
+  launch_boundary_views(blockDev(), sideTablesDev(), boundaryDev(g), v, stream_);
+  g.has_views = true;
+}
+
+View AssemblyManager::boundaryView(int group, const std::string &name) const {
+  MHA_REQUIRE(group >= 0 && group < numBoundaryGroups(), MHA_ERR_INVALID, "boundary group id out of range");
+  const BoundaryGroupData &g = *boundary_groups_[group];
+  MHA_REQUIRE(g.has_views, MHA_ERR_STATE, "boundary views requested before mha_boundary_update");
+  View v;
+  const int64_t num = g.num, nqs = side_ref_.nqs;
+  auto comp = [&](char c) {
+    const int k = c - 'x';
+    MHA_REQUIRE(k >= 0 && k < dim_, MHA_ERR_UNKNOWN_FIELD, "side field '" << name << "' does not exist in " << dim_ << "-D");
+    return k;
+  };
+  if (name == "wts side") {
+    v.ptr = g.wts.data(); v.rank = 2; v.extent[0] = num; v.extent[1] = nqs;
+  } else if (name == "x" || name == "y" || name == "z") {
+    v.ptr = g.xyz[comp(name[0])].data(); v.rank = 2; v.extent[0] = num; v.extent[1] = nqs;
+  } else if (name == "n[x]" || name == "n[y]" || name == "n[z]") {
+    v.ptr = g.nrm[comp(name[2])].data(); v.rank = 2; v.extent[0] = num; v.extent[1] = nqs;
+  } else if (name == "basis side") {
+    v.ptr = g.basis.data(); v.rank = 4; v.extent[0] = num; v.extent[1] = n_; v.extent[2] = nqs; v.extent[3] = 1;
+  } else if (name == "basis_grad side") {
+    v.ptr = g.basis_grad.data(); v.rank = 4; v.extent[0] = num; v.extent[1] = n_; v.extent[2] = nqs; v.extent[3] = dim_;
+  } else {
+    throw Error(MHA_ERR_UNKNOWN_FIELD, "unknown boundary view '" + name + "'");
+  }
+  return v;
+}
+
+void AssemblyManager::setPhysicsParameter(const std::string &name, double value) {
+  MHA_REQUIRE(physics_ != nullptr, MHA_ERR_STATE, "no physics module: call mha_physics_select first");
+  physics_->setParameter(name, value);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -36,6 +36,16 @@ class AssemblyManager {
   void computeLocalJacRes(int compute_jacobian, const double *u, const double *u_prev, const double *u_stage,
                           double *local_J, double *local_res);
   void scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals);
+  // boundary groups (reference: src/tools/boundaryGroup.hpp, assemblyManager.cpp:2518-2638)
+  int addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,
+                       const int32_t *side_ids);
+  void clearBoundaryGroups() { boundary_groups_.clear(); }
+  int numBoundaryGroups() const { return static_cast<int>(boundary_groups_.size()); }
+  void assembleBoundary(int flags, const double *u, const double *u_prev, const double *u_stage, double *res,
+                        double *crs_vals);
+  void boundaryUpdate(int group);
+  View boundaryView(int group, const std::string &name) const;
+  void setPhysicsParameter(const std::string &name, double value);
   void applyDbcDiag(double *crs_vals);
   void gather(const double *vec, double *elem_vals);
 
@@ -101,6 +111,23 @@ class AssemblyManager {
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
     bool all_rows_covered = false;
   } ro_;
+
+  // host mirror of BoundaryGroup: entries + the side views evaluated on request
+  struct BoundaryGroupData {
+    std::string sidename;
+    int bc_type = 0, num = 0;
+    DeviceBuffer<int32_t> elem, side;
+    DeviceBuffer<double> wts, xyz[3], nrm[3], basis, basis_grad;
+    bool has_views = false;
+  };
+  std::vector<std::unique_ptr<BoundaryGroupData>> boundary_groups_;
+  SideTables side_ref_;
+  DeviceBuffer<double> d_side_wts_, d_side_tanU_, d_side_tanV_, d_side_basis_, d_side_grad_, d_side_nodeval_,
+      d_side_nodegrad_;
+  bool has_side_tables_ = false;
+  void prepareSideTables();
+  SideTablesDev sideTablesDev() const;
+  BoundaryDev boundaryDev(const BoundaryGroupData &g) const;
 
   // scratch of the two-step (updateJac/scatterJac) path, one workset wide
   DeviceBuffer<double> d_local_J_, d_local_res_;

@@ -150,6 +150,46 @@ int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t
   });
 }
 
+int mha_add_boundary_group(mha_context *ctx, const char *sidename, int bc_type, int num_sides,
+                           const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id) {
+  return guarded([&] {
+    MHA_REQUIRE(sidename && group_id, MHA_ERR_INVALID, "null argument");
+    *group_id = mgr(ctx).addBoundaryGroup(sidename, bc_type, num_sides, elem_ids_host, local_side_ids_host);
+  });
+}
+
+int mha_clear_boundary_groups(mha_context *ctx) {
+  return guarded([&] { mgr(ctx).clearBoundaryGroups(); });
+}
+
+int mha_num_boundary_groups(mha_context *ctx) { return ctx ? ctx->mgr.numBoundaryGroups() : 0; }
+
+int mha_assemble_boundary(mha_context *ctx, int flags, const double *u, const double *u_prev, const double *u_stage,
+                          double *res, double *crs_vals) {
+  return guarded([&] { mgr(ctx).assembleBoundary(flags, u, u_prev, u_stage, res, crs_vals); });
+}
+
+int mha_boundary_update(mha_context *ctx, int group_id) {
+  return guarded([&] { mgr(ctx).boundaryUpdate(group_id); });
+}
+
+int mha_boundary_view(mha_context *ctx, int group_id, const char *name, void **dev_ptr, int64_t extents[4], int *rank) {
+  return guarded([&] {
+    MHA_REQUIRE(name && dev_ptr && extents && rank, MHA_ERR_INVALID, "null argument");
+    const mha::View v = mgr(ctx).boundaryView(group_id, name);
+    *dev_ptr = v.ptr;
+    *rank = v.rank;
+    for (int k = 0; k < 4; ++k) extents[k] = v.extent[k];
+  });
+}
+
+int mha_set_physics_parameter(mha_context *ctx, const char *name, double value) {
+  return guarded([&] {
+    MHA_REQUIRE(name, MHA_ERR_INVALID, "null argument");
+    mgr(ctx).setPhysicsParameter(name, value);
+  });
+}
+
 int mha_mesh_sizes(int dim, int order, const int *ncell, int *nverts, int *nelem, int64_t *ndof) {
   return guarded([&] {
     MHA_REQUIRE(ncell && nverts && nelem && ndof, MHA_ERR_INVALID, "null argument");

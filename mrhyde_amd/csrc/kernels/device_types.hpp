@@ -94,6 +94,32 @@ struct AffineDev {
   int slot_bytes = 1;              // 1 (uint8) or 2 (uint16)
 };
 
+// Side reference tables on the device (ref_tables.hpp: SideTables).
+struct SideTablesDev {
+  int nsides = 0, nqs = 0;
+  const double *wts = nullptr, *tanU = nullptr, *tanV = nullptr;
+  const double *basis = nullptr, *grad = nullptr, *nodeval = nullptr, *nodegrad = nullptr;
+};
+
+// One boundary group: (element, local side) entries that share a side name and a boundary-condition type
+// (reference: src/tools/boundaryGroup.hpp; wkset->sidename, bcs(var,side), thermal.cpp:188-216).
+struct BoundaryDev {
+  int num = 0;
+  const int32_t *elem = nullptr, *side = nullptr;
+  int bc_type = 0;       // MHA_BC_*
+  FuncDesc data;         // "Neumann e <side>" or "Dirichlet e <side>" at the side ip: ip array is [num][nqs]
+  FuncDesc diff;         // "thermal diffusion" at the side ip (constant or closed form)
+  double form_param = 1.0;
+};
+
+// Side views of one boundary group (getPhysicalBoundaryIntegrationData / getPhysicalBoundaryBasis).
+struct BoundaryViewsDev {
+  double *wts = nullptr;                          // [num][nqs]
+  double *xyz[3] = {nullptr, nullptr, nullptr};   // [num][nqs]
+  double *nrm[3] = {nullptr, nullptr, nullptr};   // [num][nqs] unit outward normals
+  double *basis = nullptr, *basis_grad = nullptr; // [num][n][nqs], [num][n][nqs][dim]
+};
+
 // Destination of the row-owner kernels.
 struct RowOut {
   double *res = nullptr;

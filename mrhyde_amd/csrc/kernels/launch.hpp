@@ -48,4 +48,11 @@ void launch_build_elem_slot_map(const BlockDev &b, void *slot, int slot_bytes, h
 void launch_thermal_general(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph, const AffineDev &af,
                             const void *slot, int slot_bytes, const ElemOut &out, hipStream_t stream);
 
+// thermal_boundary.hip: boundary groups
+bool thermal_boundary_supported(int n, int nqs);
+void launch_boundary_views(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const BoundaryViewsDev &v,
+                           hipStream_t stream);
+void launch_thermal_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const TimeDev &tm,
+                             const ElemOut &out, hipStream_t stream);
+
 }  // namespace mha

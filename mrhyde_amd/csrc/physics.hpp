@@ -43,6 +43,10 @@ class PhysicsBase {
   virtual void faceResidual() { notImplemented("faceResidual"); }
   virtual void computeFlux() { notImplemented("computeFlux"); }
   virtual void setWorkset(Workset *w) { wkset = w; }
+  // scalar settings a module reads from its parameter list in the reference constructor
+  virtual void setParameter(const std::string &name, double) {
+    throw Error(MHA_ERR_INVALID, "physics module '" + label + "' has no parameter '" + name + "'");
+  }
 
   std::string label;
   Workset *wkset = nullptr;
@@ -63,7 +67,10 @@ class thermal : public PhysicsBase {
   thermal();
   void defineFunctions(FunctionManager &fm) override;
   void volumeResidual() override;
+  void boundaryResidual() override;
+  void setParameter(const std::string &name, double value) override;
   ThermalDev device_params() const;
+  double formparam = 1.0;  // settings "form_param" (reference: thermal.cpp:35)
 };
 
 // PhysicsImporter::import equivalent (reference: src/physics/physicsImporter.cpp:48-204)

@@ -132,4 +132,79 @@ RefTables make_ref_tables(int dim, int order, int quad_degree) {
   return t;
 }
 
+SideTables make_side_tables(const RefTables &ref) {
+  static const int quad_side[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}};
+  static const int hex_side[6][4] = {{0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {0, 4, 7, 3}, {0, 3, 2, 1}, {4, 5, 6, 7}};
+  const int dim = ref.dim, nq1 = ref.nq1, m = ref.order + 1, n = ref.nbasis, nn = ref.nnodes;
+  SideTables t;
+  t.nsides = 2 * dim;
+  t.nqs = (dim == 2) ? nq1 : nq1 * nq1;
+  const int ns = t.nsides, nqs = t.nqs, nsv = (dim == 2) ? 2 : 4;
+  t.ip.assign(ns * nqs * dim, 0.0);
+  t.wts.assign(nqs, 0.0);
+  t.tanU.assign(ns * dim, 0.0);
+  t.tanV.assign(ns * dim, 0.0);
+  t.basis.assign(ns * n * nqs, 0.0);
+  t.grad.assign(ns * n * nqs * dim, 0.0);
+  t.nodeval.assign(ns * nn * nqs, 0.0);
+  t.nodegrad.assign(ns * nn * nqs * dim, 0.0);
+  for (int q = 0; q < nqs; ++q)
+    t.wts[q] = (dim == 2) ? ref.gauss_wts[q] : ref.gauss_wts[q % nq1] * ref.gauss_wts[q / nq1];
+  std::vector<double> bv(3 * m), bd(3 * m);
+  for (int s = 0; s < ns; ++s) {
+    double v[4][3] = {{0}};
+    for (int k = 0; k < nsv; ++k)
+      for (int d = 0; d < dim; ++d) v[k][d] = ref_vertex_sign(dim, dim == 2 ? quad_side[s][k] : hex_side[s][k], d);
+    for (int d = 0; d < dim; ++d) {
+      if (dim == 2) {
+        t.tanU[s * dim + d] = 0.5 * (v[1][d] - v[0][d]);
+      } else {
+        t.tanU[s * dim + d] = 0.25 * (-v[0][d] + v[1][d] + v[2][d] - v[3][d]);
+        t.tanV[s * dim + d] = 0.25 * (-v[0][d] - v[1][d] + v[2][d] + v[3][d]);
+      }
+    }
+    for (int q = 0; q < nqs; ++q) {
+      double x[3] = {0, 0, 0};
+      if (dim == 2) {
+        const double a = ref.gauss_pts[q];
+        for (int d = 0; d < dim; ++d) x[d] = 0.5 * (1 - a) * v[0][d] + 0.5 * (1 + a) * v[1][d];
+      } else {
+        const double a = ref.gauss_pts[q % nq1], b = ref.gauss_pts[q / nq1];
+        for (int d = 0; d < dim; ++d)
+          x[d] = 0.25 * ((1 - a) * (1 - b) * v[0][d] + (1 + a) * (1 - b) * v[1][d] + (1 + a) * (1 + b) * v[2][d] +
+                         (1 - a) * (1 + b) * v[3][d]);
+      }
+      for (int d = 0; d < dim; ++d) {
+        t.ip[(s * nqs + q) * dim + d] = x[d];
+        lagrange_equispaced(ref.order, x[d], &bv[d * m], &bd[d * m]);
+      }
+      for (int f = 0; f < n; ++f) {
+        const int fi[3] = {f % m, (f / m) % m, f / (m * m)};
+        double val = 1.0;
+        for (int d = 0; d < dim; ++d) val *= bv[d * m + fi[d]];
+        t.basis[(s * n + f) * nqs + q] = val;
+        for (int d = 0; d < dim; ++d) {
+          double g = 1.0;
+          for (int e = 0; e < dim; ++e) g *= (e == d) ? bd[e * m + fi[e]] : bv[e * m + fi[e]];
+          t.grad[((s * n + f) * nqs + q) * dim + d] = g;
+        }
+      }
+      for (int k = 0; k < nn; ++k) {
+        double val = 1.0;
+        for (int d = 0; d < dim; ++d) val *= 0.5 * (1.0 + ref_vertex_sign(dim, k, d) * x[d]);
+        t.nodeval[(s * nn + k) * nqs + q] = val;
+        for (int d = 0; d < dim; ++d) {
+          double g = 1.0;
+          for (int e = 0; e < dim; ++e) {
+            const double sg = ref_vertex_sign(dim, k, e);
+            g *= (e == d) ? 0.5 * sg : 0.5 * (1.0 + sg * x[e]);
+          }
+          t.nodegrad[((s * nn + k) * nqs + q) * dim + d] = g;
+        }
+      }
+    }
+  }
+  return t;
+}
+
 }  // namespace mha

@@ -22,10 +22,26 @@ struct RefTables {
   std::vector<double> nodegrad;                 // [nnodes][nq][dim]
 };
 
+// Reference data of the cell's sides (setReferenceData, reference: src/interfaces/discretizationInterface.cpp:523-548):
+// the (dim-1)-cubature mapped onto each side by CellTools::mapToReferenceSubcell, the reference edge tangent (2-D) or
+// face tangents (3-D), and the cell basis / geometry basis evaluated at those points.  Sides in shards order:
+// quad edges {0,1},{1,2},{2,3},{3,0}; hex faces {0,1,5,4},{1,2,6,5},{2,3,7,6},{0,4,7,3},{0,3,2,1},{4,5,6,7}.
+struct SideTables {
+  int nsides = 0, nqs = 0;
+  std::vector<double> ip;         // [ns][nqs][dim] in cell reference coordinates
+  std::vector<double> wts;        // [nqs]
+  std::vector<double> tanU, tanV; // [ns][dim]
+  std::vector<double> basis;      // [ns][nbasis][nqs]
+  std::vector<double> grad;       // [ns][nbasis][nqs][dim]
+  std::vector<double> nodeval;    // [ns][nnodes][nqs]
+  std::vector<double> nodegrad;   // [ns][nnodes][nqs][dim]
+};
+
 int gauss_points_for_degree(int degree);
 void gauss_legendre_descending(int n, std::vector<double> &pts, std::vector<double> &wts);
 void lagrange_equispaced(int order, double x, double *val, double *der);
 RefTables make_ref_tables(int dim, int order, int quad_degree);
+SideTables make_side_tables(const RefTables &ref);
 // sign (+1/-1) of reference vertex v of the cell topology in direction d (shards order)
 double ref_vertex_sign(int dim, int v, int d);
 

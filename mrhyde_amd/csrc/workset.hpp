@@ -53,6 +53,13 @@ class Workset {
   hipStream_t stream = nullptr;
   int order = 0, nq1 = 0;
 
+  // --- boundary state (reference: wkset->sidename / currentside / var_bcs, set by updateWorksetBoundary,
+  // assemblyManager.cpp:5646-5710) ---
+  std::string sidename;     // side-set name of the boundary group being processed
+  int current_bc = 0;       // MHA_BC_* of variable "e" on that side
+  BoundaryDev bnd;          // entries of the group (data/diff/form_param are filled by the physics module)
+  SideTablesDev side_tables;
+
   // reference: Workset::setTime / setDeltat / setStage (workset.hpp:127-137)
   void setTime(double t) { time = t; }
   void setDeltat(double dt) { deltat = dt; }
