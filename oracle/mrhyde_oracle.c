@@ -16,7 +16,8 @@
 #include <omp.h>
 #endif
 
-#define ORC_MAXP 8
+#include "orc_internal.h"
+
 
 /* ------------------------------------------------------------------------ */
 /* reference tables                                                          */
@@ -84,11 +85,12 @@ void orc_lagrange_1d(int p, double x, double *val, double *der) {
   }
 }
 
-static int ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
+int orc__ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
+#define ipow orc__ipow
 
 /* shards vertex order (Quadrilateral_4 / Hexahedron_8) */
-static const double QUAD_NODE[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
-static const double HEX_NODE[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1},
+const double orc__quad_node[4][2] = {{-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+const double orc__hex_node[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1},
                                       {-1, -1, 1},  {1, -1, 1},  {1, 1, 1},  {-1, 1, 1}};
 
 int orc_ref_sizes(int dim, int order, int qdeg, int *nbasis, int *nq, int *nnodes) {
@@ -218,7 +220,7 @@ int orc_mesh_structured(int dim, int order, const int *nc, const double *lo, con
 /* physical basis (discretizationInterface.cpp:732-776, 898-981)             */
 /* ------------------------------------------------------------------------ */
 
-static void jac_inv_det(int dim, const double *J, double *Ji, double *det) {
+void orc__jac_inv_det(int dim, const double *J, double *Ji, double *det) {
   if (dim == 2) {
     double d = J[0] * J[3] - J[1] * J[2];
     *det = d;
@@ -562,8 +564,8 @@ double orc_l2_error_sinprod(int dim, int order, int qdeg, int nelem, const int *
 /* boundary (side) terms                                                     */
 /* ------------------------------------------------------------------------ */
 
-static const int QUAD_SIDE[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}};
-static const int HEX_SIDE[6][4] = {{0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {0, 4, 7, 3}, {0, 3, 2, 1}, {4, 5, 6, 7}};
+const int orc__quad_side[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}};
+const int orc__hex_side[6][4] = {{0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {0, 4, 7, 3}, {0, 3, 2, 1}, {4, 5, 6, 7}};
 
 int orc_side_sizes(int dim, int qdeg, int *nsides, int *nqs) {
   if (dim < 2 || dim > 3) return -1;

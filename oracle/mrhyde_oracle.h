@@ -163,6 +163,94 @@ typedef struct orc_thermal_bnd_args {
  * assembleJacRes (assemblyManager.cpp:2518-2638): gather, seed, side fields, residual, scatter.      */
 int orc_assemble_thermal_boundary(const orc_thermal_bnd_args *a);
 
+/* ================================================================================================
+ * Multi-variable blocks (porousMixed: p HVOL + u HDIV; navierstokes: ux, pr, uy[, uz] HGRAD; thermal)
+ * ================================================================================================
+ * Bases (getBasis, discretizationInterface.cpp:346-462): HGRAD = tensor Lagrange (as above); HVOL =
+ * Basis_HVOL_C0_FEM, the constant 1 (:372-374), transformed like an HGRAD value (no 1/detJ, :1003-1012);
+ * HDIV = Basis_HDIV_{QUAD,HEX}_In_FEM of degree 1 (:381-393): 2*dim functions, dof 2c = (1-x_c)/2 e_c,
+ * dof 2c+1 = (1+x_c)/2 e_c (tensor line(x_c) x bubble(others), component-major), value J phi/detJ, div
+ * div_hat/detJ (:1014-1065).  modifyBasisByOrientation for the lowest-order face dofs is a sign: phi.n_out of the
+ * reference face (-1 for dof 2c, +1 for dof 2c+1) times -1 if the face's global vertex ids are a flipped
+ * permutation (edges: id0 > id1; quads: after rotating the smallest id first, next > previous).
+ * Trilinos is not vendored: the In_FEM ordering/normalisation and the orientation rule restate Intrepid2's
+ * published definitions; they are pinned only through the porous L2 golds (consistency), not entry by entry. */
+#define ORC_BASIS_HGRAD 0
+#define ORC_BASIS_HVOL 1
+#define ORC_BASIS_HDIV 2
+#define ORC_PHYS_THERMAL 1
+#define ORC_PHYS_POROUS_MIXED 2
+#define ORC_PHYS_NAVIERSTOKES 3
+#define ORC_MAX_VARS 8
+#define ORC_MAX_FUNCS 8
+int orc_basis_card(int dim, int type, int order);
+/* reference basis of one variable at npts reference points x[npts][dim]:
+ * val[n][npts][ncomp] (ncomp = dim for HDIV, else 1), grad[n][npts][dim] (HGRAD, else untouched), div[n][npts] (HDIV) */
+int orc_ref_basis_var(int dim, int type, int order, int npts, const double *x, double *val, double *grad, double *div);
+
+/* Structured mesh + multi-variable dof map.  HGRAD orders must divide the largest HGRAD order.  Element LID
+ * list: vertex sites in shards order, remaining tensor sites of the finest HGRAD lattice in tensor order, the
+ * cell site (HVOL), the face sites in HDIV dof order; at every site the variables that live there in variable
+ * order (the subcell-major layout panzer::DOFManager produces).  Global ids follow the same site-major rule on
+ * the global lattices.  offsets: ragged [var][dof] flattened (var v starts at sum of cards before it), values =
+ * positions in the LID list.  orient[E][n_tot]: sign per flattened (var,dof).  side_mask[ndof]: bit s set if
+ * the dof lies on side s (0 left x-, 1 right x+, 2 bottom y-, 3 top y+, 4 back z-, 5 front z+).           */
+int orc_mesh_multi_sizes(int dim, const int *ncell, int nvars, const int *types, const int *orders, int *nverts,
+                         int *nelem, int *n_tot, long long *ndof);
+int orc_mesh_multi(int dim, const int *ncell, const double *lo, const double *hi, int nvars, const int *types,
+                   const int *orders, double *verts, int *cell2vert, int *lids, int *offsets, signed char *orient,
+                   unsigned char *side_mask, int *dof_var);
+/* physical basis of one variable at the volume integration points: basis[E][n][q][ncomp], grad[E][n][q][dim]
+ * (HGRAD), div[E][n][q] (HDIV), wts[E][q], ip[E][q][dim]; orient_var[E][n] or NULL; any output may be NULL  */
+int orc_physical_basis_var(int dim, int type, int order, int qdeg, int nelem, const double *nodes,
+                           const signed char *orient, int orient_stride, int orient_off, double *basis, double *grad,
+                           double *div, double *wts, double *ip);
+
+typedef struct orc_func {
+  int kind;              /* 0 constant amp, 1 per-ip array [E][q] (boundary: [nb][nqs]), 2 amp*prod sin(freq_d x_d) */
+  double amp, freq[3];
+  const double *ip;
+} orc_func;
+
+/* function slots: thermal {source, diffusion, specific heat, density}; porousMixed {source, Kinv_xx, Kinv_yy,
+ * Kinv_zz, total_mobility}; navierstokes {source ux, source pr, source uy, source uz, density, viscosity}.
+ * params: navierstokes {useSUPG, usePSPG, fix_uz_offsets}: the reference writes the 3-D uz momentum residual through
+ * uy's offsets (navierstokes.cpp:688); params[2] = 0 reproduces that, 1 uses uz's offsets.                          */
+typedef struct orc_block_args {
+  int dim, qdeg, nvars;
+  int types[ORC_MAX_VARS], orders[ORC_MAX_VARS];
+  int physics;
+  int nelem, nrows;
+  const double *nodes;          /* [E][nnodes][dim] */
+  const int *lids;              /* [E][n_tot]       */
+  const int *offsets;           /* ragged [var][dof] */
+  const signed char *orient;    /* [E][n_tot] or NULL */
+  const unsigned char *fixed;
+  const double *u;
+  int transient, nsteps, nstages, stage;
+  const double *u_prev, *u_stage, *butcher_A, *butcher_b, *bdf;
+  double dt;
+  orc_func funcs[ORC_MAX_FUNCS];
+  double params[8];
+  int compute_jacobian;
+  const int *rowptr, *colind;
+  double *crs_vals, *res;
+  double *local_J, *local_res;  /* [E][n_tot][n_tot] / [E][n_tot] in LID-position order, or NULL */
+  /* boundary entries (orc_assemble_block_boundary only) */
+  int nb;
+  const int *belem, *bside;
+  int bc_type;                  /* porousMixed: 1 = "Dirichlet" on p (weak, porousMixed.cpp:400-418) */
+  orc_func bdata;               /* "Dirichlet p <side>" at the side ip */
+} orc_block_args;
+/* volume terms: gather -> seed -> fields -> <physics>::volumeResidual -> scatter, AD arrays of width n_tot
+ * (porousMixed.cpp:158-338, navierstokes.cpp:82-849, thermal.cpp:71-165)                                  */
+int orc_assemble_block(const orc_block_args *a);
+/* boundary terms (porousMixed::boundaryResidual, porousMixed.cpp:345-432)                                  */
+int orc_assemble_block_boundary(const orc_block_args *a);
+/* HDIV side basis of boundary entries: basis[nb][n][nqs][dim] = J phi/detJ at the side points (with orientation) */
+int orc_physical_side_basis_hdiv(int dim, int qdeg, int nb, const double *nodes, const int *belem, const int *bside,
+                                 const signed char *orient, int orient_stride, int orient_off, double *basis);
+
 #ifdef __cplusplus
 }
 #endif

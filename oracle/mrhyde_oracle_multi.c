@@ -1,0 +1,763 @@
+/*
+ * mrhyde_oracle_multi.c -- TEST INFRASTRUCTURE ONLY (see mrhyde_oracle.h).
+ *
+ * Multi-variable part of the CPU oracle: HVOL / HDIV bases next to HGRAD, the subcell-major dof map of a
+ * structured mesh, and the reference's data flow for porousMixed, navierstokes and thermal with width-n_tot
+ * derivative arrays (one pass per solution field, one loop nest per residual block, exactly as the functors in
+ * src/physics/{porousMixed,navierstokes,thermal}.cpp do it).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mrhyde_oracle.h"
+#include "orc_internal.h"
+
+/* ------------------------------------------------------------------------ */
+/* bases                                                                     */
+/* ------------------------------------------------------------------------ */
+
+int orc_basis_card(int dim, int type, int order) {
+  if (type == ORC_BASIS_HGRAD) return (order >= 1 && order <= ORC_MAXP) ? orc__ipow(order + 1, dim) : -1;
+  if (type == ORC_BASIS_HVOL) return order == 0 ? 1 : -1;
+  if (type == ORC_BASIS_HDIV) return (order == 1 && dim >= 2) ? 2 * dim : -1;
+  return -1;
+}
+
+static int ncomp_of(int dim, int type) { return type == ORC_BASIS_HDIV ? dim : 1; }
+
+int orc_ref_basis_var(int dim, int type, int order, int npts, const double *x, double *val, double *grad, double *div) {
+  const int n = orc_basis_card(dim, type, order);
+  if (n < 0) return -1;
+  for (int pt = 0; pt < npts; ++pt) {
+    const double *xp = x + (size_t)pt * dim;
+    if (type == ORC_BASIS_HGRAD) {
+      const int p1 = order + 1;
+      double bv[3][ORC_MAXP + 1], bd[3][ORC_MAXP + 1];
+      for (int d = 0; d < dim; ++d) orc_lagrange_1d(order, xp[d], bv[d], bd[d]);
+      for (int f = 0; f < n; ++f) {
+        const int fi[3] = {f % p1, (f / p1) % p1, f / (p1 * p1)};
+        double v = 1.0;
+        for (int d = 0; d < dim; ++d) v *= bv[d][fi[d]];
+        val[(size_t)f * npts + pt] = v;
+        if (grad)
+          for (int d = 0; d < dim; ++d) {
+            double g = 1.0;
+            for (int e = 0; e < dim; ++e) g *= (e == d) ? bd[e][fi[e]] : bv[e][fi[e]];
+            grad[((size_t)f * npts + pt) * dim + d] = g;
+          }
+      }
+    } else if (type == ORC_BASIS_HVOL) {
+      val[pt] = 1.0; /* Basis_HVOL_C0_FEM */
+    } else {
+      for (int c = 0; c < dim; ++c)
+        for (int s = 0; s < 2; ++s) {
+          const int f = 2 * c + s;
+          for (int d = 0; d < dim; ++d) val[((size_t)f * npts + pt) * dim + d] = 0.0;
+          val[((size_t)f * npts + pt) * dim + c] = s ? 0.5 * (1.0 + xp[c]) : 0.5 * (1.0 - xp[c]);
+          if (div) div[(size_t)f * npts + pt] = s ? 0.5 : -0.5;
+        }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* structured mesh + subcell-major multi-variable dof map                    */
+/* ------------------------------------------------------------------------ */
+
+static int max_hgrad_order(int nvars, const int *types, const int *orders) {
+  int K = 0;
+  for (int v = 0; v < nvars; ++v)
+    if (types[v] == ORC_BASIS_HGRAD && orders[v] > K) K = orders[v];
+  return K;
+}
+
+int orc_mesh_multi_sizes(int dim, const int *nc, int nvars, const int *types, const int *orders, int *nverts,
+                         int *nelem, int *n_tot, long long *ndof) {
+  if (dim < 2 || dim > 3 || nvars < 1 || nvars > ORC_MAX_VARS) return -1;
+  const int K = max_hgrad_order(nvars, types, orders);
+  long long nd = 0;
+  int nt = 0, ne = 1, nv = 1;
+  for (int d = 0; d < dim; ++d) { ne *= nc[d]; nv *= nc[d] + 1; }
+  for (int v = 0; v < nvars; ++v) {
+    const int card = orc_basis_card(dim, types[v], orders[v]);
+    if (card < 0) return -1;
+    nt += card;
+    if (types[v] == ORC_BASIS_HGRAD) {
+      if (K % orders[v]) return -1;
+      long long m = 1;
+      for (int d = 0; d < dim; ++d) m *= (long long)orders[v] * nc[d] + 1;
+      nd += m;
+    } else if (types[v] == ORC_BASIS_HVOL) {
+      nd += ne;
+    } else {
+      for (int c = 0; c < dim; ++c) {
+        long long m = 1;
+        for (int d = 0; d < dim; ++d) m *= nc[d] + (d == c);
+        nd += m;
+      }
+    }
+  }
+  *nverts = nv; *nelem = ne; *n_tot = nt; *ndof = nd;
+  return 0;
+}
+
+int orc_mesh_multi(int dim, const int *nc, const double *lo, const double *hi, int nvars, const int *types,
+                   const int *orders, double *verts, int *cell2vert, int *lids, int *offsets, signed char *orient,
+                   unsigned char *side_mask, int *dof_var) {
+  int nverts, nelem, n_tot;
+  long long ndof;
+  if (orc_mesh_multi_sizes(dim, nc, nvars, types, orders, &nverts, &nelem, &n_tot, &ndof)) return -1;
+  const int K = max_hgrad_order(nvars, types, orders);
+  const int nn = 1 << dim;
+  int varptr[ORC_MAX_VARS + 1] = {0};
+  for (int v = 0; v < nvars; ++v) varptr[v + 1] = varptr[v] + orc_basis_card(dim, types[v], orders[v]);
+  { /* vertices + cell -> vertex map from the single-variable generator */
+    int *tl = malloc(sizeof(int) * (size_t)nelem * nn), to[8];
+    if (orc_mesh_structured(dim, 1, nc, lo, hi, verts, cell2vert, tl, to, NULL)) { free(tl); return -1; }
+    free(tl);
+  }
+  /* ---- global ids ---- */
+  int fd[3] = {1, 1, 1}; /* fine lattice extents */
+  size_t nfine = 1;
+  for (int d = 0; d < dim; ++d) { fd[d] = K * nc[d] + 1; nfine *= (size_t)fd[d]; }
+  int *gnode = NULL; /* [nvars][nfine] */
+  int next = 0;
+  if (K > 0) {
+    gnode = malloc(sizeof(int) * nvars * nfine);
+    for (size_t s = 0; s < nfine; ++s) {
+      const int a[3] = {(int)(s % fd[0]), (int)((s / fd[0]) % fd[1]), (int)(s / ((size_t)fd[0] * fd[1]))};
+      for (int v = 0; v < nvars; ++v) {
+        gnode[(size_t)v * nfine + s] = -1;
+        if (types[v] != ORC_BASIS_HGRAD) continue;
+        const int st = K / orders[v];
+        int in = 1;
+        for (int d = 0; d < dim; ++d) in &= (a[d] % st == 0);
+        if (!in) continue;
+        unsigned char m = 0;
+        for (int d = 0; d < dim; ++d) {
+          if (a[d] == 0) m |= 1u << (2 * d);
+          if (a[d] == fd[d] - 1) m |= 1u << (2 * d + 1);
+        }
+        if (side_mask) side_mask[next] = m;
+        if (dof_var) dof_var[next] = v;
+        gnode[(size_t)v * nfine + s] = next++;
+      }
+    }
+  }
+  int gcell0[ORC_MAX_VARS], gface0[ORC_MAX_VARS][3];
+  const int ncx = nc[0], ncy = nc[1], ncz = dim == 3 ? nc[2] : 1;
+  /* cells: interleaved over HVOL variables per cell */
+  int nhvol = 0, hvol_rank[ORC_MAX_VARS];
+  for (int v = 0; v < nvars; ++v) { hvol_rank[v] = nhvol; if (types[v] == ORC_BASIS_HVOL) ++nhvol; }
+  const int cell_base = next;
+  for (int e = 0; e < nelem && nhvol; ++e)
+    for (int v = 0; v < nvars; ++v)
+      if (types[v] == ORC_BASIS_HVOL) {
+        if (side_mask) side_mask[next] = 0;
+        if (dof_var) dof_var[next] = v;
+        ++next;
+      }
+  (void)gcell0;
+  /* faces: direction by direction, interleaved over HDIV variables per face */
+  int nhdiv = 0, hdiv_rank[ORC_MAX_VARS];
+  for (int v = 0; v < nvars; ++v) { hdiv_rank[v] = nhdiv; if (types[v] == ORC_BASIS_HDIV) ++nhdiv; }
+  int face_base[3] = {0, 0, 0};
+  for (int c = 0; c < dim && nhdiv; ++c) {
+    face_base[c] = next;
+    const int ex[3] = {ncx + (c == 0), ncy + (c == 1), dim == 3 ? ncz + (c == 2) : 1};
+    for (int k = 0; k < ex[2]; ++k)
+      for (int j = 0; j < ex[1]; ++j)
+        for (int i = 0; i < ex[0]; ++i)
+          for (int v = 0; v < nvars; ++v)
+            if (types[v] == ORC_BASIS_HDIV) {
+              const int idx[3] = {i, j, k};
+              unsigned char m = 0;
+              if (idx[c] == 0) m |= 1u << (2 * c);
+              if (idx[c] == ex[c] - 1) m |= 1u << (2 * c + 1);
+              if (side_mask) side_mask[next] = m;
+              if (dof_var) dof_var[next] = v;
+              ++next;
+            }
+  }
+  (void)gface0;
+  if (next != (int)ndof) { free(gnode); return -2; }
+  /* ---- element LID lists + offsets ---- */
+  const int kp = K + 1;
+  const int nsite = K > 0 ? orc__ipow(kp, dim) : 0;
+  int *site_order = malloc(sizeof(int) * (nsite + 1));
+  { /* vertices in shards order, then the remaining tensor sites */
+    int cnt = 0;
+    unsigned char *isv = calloc(nsite + 1, 1);
+    for (int v = 0; v < nn && K > 0; ++v) {
+      const double *cn = dim == 2 ? QUAD_NODE[v] : HEX_NODE[v];
+      int t = 0, mul = 1;
+      for (int d = 0; d < dim; ++d) { t += (cn[d] > 0 ? K : 0) * mul; mul *= kp; }
+      site_order[cnt++] = t;
+      isv[t] = 1;
+    }
+    for (int t = 0; t < nsite; ++t)
+      if (!isv[t]) site_order[cnt++] = t;
+    free(isv);
+  }
+  for (int e = 0; e < nelem; ++e) {
+    const int ci[3] = {e % ncx, (e / ncx) % ncy, e / (ncx * ncy)};
+    int *L = lids + (size_t)e * n_tot;
+    int pos = 0;
+    for (int so = 0; so < nsite; ++so) {
+      const int t = site_order[so];
+      const int a[3] = {t % kp, (t / kp) % kp, t / (kp * kp)};
+      size_t s = 0, mul = 1;
+      for (int d = 0; d < dim; ++d) { s += (size_t)(ci[d] * K + a[d]) * mul; mul *= (size_t)fd[d]; }
+      for (int v = 0; v < nvars; ++v) {
+        if (types[v] != ORC_BASIS_HGRAD) continue;
+        const int st = K / orders[v], p1 = orders[v] + 1;
+        int in = 1;
+        for (int d = 0; d < dim; ++d) in &= (a[d] % st == 0);
+        if (!in) continue;
+        int dof = 0, m2 = 1;
+        for (int d = 0; d < dim; ++d) { dof += (a[d] / st) * m2; m2 *= p1; }
+        if (e == 0) offsets[varptr[v] + dof] = pos;
+        L[pos++] = gnode[(size_t)v * nfine + s];
+      }
+    }
+    for (int v = 0; v < nvars; ++v)
+      if (types[v] == ORC_BASIS_HVOL) {
+        if (e == 0) offsets[varptr[v]] = pos;
+        L[pos++] = cell_base + e * nhvol + hvol_rank[v];
+      }
+    for (int f = 0; f < 2 * dim && nhdiv; ++f) {
+      const int c = f / 2, s = f % 2;
+      const int ex[3] = {ncx + (c == 0), ncy + (c == 1), dim == 3 ? ncz + (c == 2) : 1};
+      int idx[3] = {ci[0], ci[1], ci[2]};
+      idx[c] += s;
+      const int lin = idx[0] + ex[0] * (idx[1] + ex[1] * idx[2]);
+      for (int v = 0; v < nvars; ++v)
+        if (types[v] == ORC_BASIS_HDIV) {
+          if (e == 0) offsets[varptr[v] + f] = pos;
+          L[pos++] = face_base[c] + lin * nhdiv + hdiv_rank[v];
+        }
+    }
+    if (pos != n_tot) { free(gnode); free(site_order); return -3; }
+    /* orientation signs */
+    if (orient) {
+      signed char *o = orient + (size_t)e * n_tot;
+      for (int k = 0; k < n_tot; ++k) o[k] = 1;
+      static const int face_of_dof3[6] = {3, 1, 0, 2, 4, 5}, edge_of_dof2[4] = {3, 1, 0, 2};
+      const int *cv = cell2vert + (size_t)e * nn;
+      for (int v = 0; v < nvars; ++v) {
+        if (types[v] != ORC_BASIS_HDIV) continue;
+        for (int f = 0; f < 2 * dim; ++f) {
+          int flip;
+          if (dim == 2) {
+            const int *sn = QUAD_SIDE[edge_of_dof2[f]];
+            flip = cv[sn[0]] > cv[sn[1]];
+          } else {
+            const int *sn = HEX_SIDE[face_of_dof3[f]];
+            int rot = 0;
+            for (int k = 1; k < 4; ++k)
+              if (cv[sn[k]] < cv[sn[rot]]) rot = k;
+            flip = cv[sn[(rot + 1) % 4]] > cv[sn[(rot + 3) % 4]];
+          }
+          const int sigma = (f % 2) ? 1 : -1; /* phi_raw . n_out on its own face */
+          o[varptr[v] + f] = (signed char)(flip ? -sigma : sigma);
+        }
+      }
+    }
+  }
+  free(gnode);
+  free(site_order);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* physical basis of one variable                                            */
+/* ------------------------------------------------------------------------ */
+
+int orc_physical_basis_var(int dim, int type, int order, int qdeg, int nelem, const double *nodes,
+                           const signed char *orient, int orient_stride, int orient_off, double *basis, double *grad,
+                           double *div, double *wts, double *ip) {
+  int n1, nq, nn;
+  if (orc_ref_sizes(dim, 1, qdeg, &n1, &nq, &nn)) return -1;
+  const int n = orc_basis_card(dim, type, order), nc = ncomp_of(dim, type);
+  if (n < 0) return -1;
+  double *rip = malloc(sizeof(double) * nq * dim), *rw = malloc(sizeof(double) * nq);
+  double *rb1 = malloc(sizeof(double) * n1 * nq), *rg1 = malloc(sizeof(double) * n1 * nq * dim);
+  double *nv = malloc(sizeof(double) * nn * nq), *ng = malloc(sizeof(double) * nn * nq * dim);
+  orc_ref_tables(dim, 1, qdeg, rip, rw, rb1, rg1, nv, ng);
+  double *rv = malloc(sizeof(double) * n * nq * nc), *rg = malloc(sizeof(double) * n * nq * dim);
+  double *rd = malloc(sizeof(double) * n * nq);
+  orc_ref_basis_var(dim, type, order, nq, rip, rv, rg, rd);
+  for (int e = 0; e < nelem; ++e) {
+    const double *xn = nodes + (size_t)e * nn * dim;
+    for (int q = 0; q < nq; ++q) {
+      double J[9] = {0}, Ji[9] = {0}, det;
+      for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < dim; ++c) {
+          double s = 0.0;
+          for (int v = 0; v < nn; ++v) s += xn[v * dim + r] * ng[(v * nq + q) * dim + c];
+          J[r * dim + c] = s;
+        }
+      jac_inv_det(dim, J, Ji, &det);
+      if (wts) wts[(size_t)e * nq + q] = rw[q] * det;
+      if (ip)
+        for (int d = 0; d < dim; ++d) {
+          double s = 0.0;
+          for (int v = 0; v < nn; ++v) s += xn[v * dim + d] * nv[v * nq + q];
+          ip[((size_t)e * nq + q) * dim + d] = s;
+        }
+      for (int f = 0; f < n; ++f) {
+        const double sg = orient ? (double)orient[(size_t)e * orient_stride + orient_off + f] : 1.0;
+        const size_t o = ((size_t)e * n + f) * nq + q;
+        if (type == ORC_BASIS_HDIV) {
+          /* HDIVtransformVALUE: J phi / detJ; HDIVtransformDIV: div / detJ (discretizationInterface.cpp:1019,1053) */
+          for (int d = 0; d < dim; ++d) {
+            double s = 0.0;
+            for (int c = 0; c < dim; ++c) s += J[d * dim + c] * rv[((size_t)f * nq + q) * dim + c];
+            if (basis) basis[o * dim + d] = sg * s / det;
+          }
+          if (div) div[o] = sg * rd[(size_t)f * nq + q] / det;
+        } else {
+          if (basis) basis[o] = rv[(size_t)f * nq + q];
+          if (grad && type == ORC_BASIS_HGRAD)
+            for (int d = 0; d < dim; ++d) {
+              double s = 0.0;
+              for (int c = 0; c < dim; ++c) s += Ji[c * dim + d] * rg[((size_t)f * nq + q) * dim + c];
+              grad[o * dim + d] = s;
+            }
+        }
+      }
+    }
+  }
+  free(rip); free(rw); free(rb1); free(rg1); free(nv); free(ng); free(rv); free(rg); free(rd);
+  return 0;
+}
+
+int orc_physical_side_basis_hdiv(int dim, int qdeg, int nb, const double *nodes, const int *belem, const int *bside,
+                                 const signed char *orient, int orient_stride, int orient_off, double *basis) {
+  int n1, nq, nn, ns, nqs;
+  if (orc_ref_sizes(dim, 1, qdeg, &n1, &nq, &nn) || orc_side_sizes(dim, qdeg, &ns, &nqs)) return -1;
+  const int n = 2 * dim;
+  double *sip = malloc(sizeof(double) * ns * nqs * dim), *sw = malloc(sizeof(double) * nqs);
+  double *tu = malloc(sizeof(double) * ns * dim), *tv = malloc(sizeof(double) * ns * dim);
+  double *sb = malloc(sizeof(double) * ns * n1 * nqs), *sg = malloc(sizeof(double) * ns * n1 * nqs * dim);
+  double *snv = malloc(sizeof(double) * ns * nn * nqs), *sng = malloc(sizeof(double) * ns * nn * nqs * dim);
+  orc_side_tables(dim, 1, qdeg, sip, sw, tu, tv, sb, sg, snv, sng);
+  double *rv = malloc(sizeof(double) * n * nqs * dim);
+  for (int k = 0; k < nb; ++k) {
+    const int e = belem[k], s = bside[k];
+    const double *xn = nodes + (size_t)e * nn * dim;
+    orc_ref_basis_var(dim, ORC_BASIS_HDIV, 1, nqs, sip + (size_t)s * nqs * dim, rv, NULL, NULL);
+    for (int q = 0; q < nqs; ++q) {
+      double J[9] = {0}, Ji[9] = {0}, det;
+      for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < dim; ++c) {
+          double sum = 0.0;
+          for (int v = 0; v < nn; ++v) sum += xn[v * dim + r] * sng[((s * nn + v) * nqs + q) * dim + c];
+          J[r * dim + c] = sum;
+        }
+      jac_inv_det(dim, J, Ji, &det);
+      for (int f = 0; f < n; ++f) {
+        const double sgn = orient ? (double)orient[(size_t)e * orient_stride + orient_off + f] : 1.0;
+        for (int d = 0; d < dim; ++d) {
+          double sum = 0.0;
+          for (int c = 0; c < dim; ++c) sum += J[d * dim + c] * rv[((size_t)f * nqs + q) * dim + c];
+          basis[(((size_t)k * n + f) * nqs + q) * dim + d] = sgn * sum / det;
+        }
+      }
+    }
+  }
+  free(sip); free(sw); free(tu); free(tv); free(sb); free(sg); free(snv); free(sng); free(rv);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* derivative-array arithmetic (Sacado SFad restated on plain arrays)         */
+/* ------------------------------------------------------------------------ */
+
+#define ADMAX 160
+typedef struct { double v[ADMAX]; } ad_t;  /* v[0] value, v[1+k] d/d(slot k) */
+static int g_w1;                           /* active width + 1 (set per call; the oracle is single-threaded here) */
+
+static ad_t ad_c(double c) { ad_t r; memset(r.v, 0, sizeof(double) * g_w1); r.v[0] = c; return r; }
+static ad_t ad_add(ad_t a, const ad_t *b) { for (int j = 0; j < g_w1; ++j) a.v[j] += b->v[j]; return a; }
+static ad_t ad_sub(ad_t a, const ad_t *b) { for (int j = 0; j < g_w1; ++j) a.v[j] -= b->v[j]; return a; }
+static ad_t ad_scale(ad_t a, double s) { for (int j = 0; j < g_w1; ++j) a.v[j] *= s; return a; }
+static ad_t ad_mul(const ad_t *a, const ad_t *b) {
+  ad_t r;
+  r.v[0] = a->v[0] * b->v[0];
+  for (int j = 1; j < g_w1; ++j) r.v[j] = a->v[j] * b->v[0] + a->v[0] * b->v[j];
+  return r;
+}
+static ad_t ad_div(const ad_t *a, const ad_t *b) {
+  ad_t r;
+  r.v[0] = a->v[0] / b->v[0];
+  for (int j = 1; j < g_w1; ++j) r.v[j] = (a->v[j] * b->v[0] - a->v[0] * b->v[j]) / (b->v[0] * b->v[0]);
+  return r;
+}
+static ad_t ad_sqrt(const ad_t *a) {
+  ad_t r;
+  r.v[0] = sqrt(a->v[0]);
+  for (int j = 1; j < g_w1; ++j) r.v[j] = a->v[j] / (2.0 * r.v[0]);
+  return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* block assembly                                                            */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+  const orc_block_args *a;
+  int n_tot, nq, nn, varptr[ORC_MAX_VARS + 1];
+  /* physical basis of the current element, per variable */
+  double *basis[ORC_MAX_VARS], *grad[ORC_MAX_VARS], *div[ORC_MAX_VARS];
+  double *wts, *ip;
+  ad_t *uAD, *udAD; /* [n_tot] flattened (var,dof) */
+} blk_ctx;
+
+static double eval_func(const orc_func *f, int dim, size_t e, int q, int nq, const double *x) {
+  if (f->kind == 0) return f->amp;
+  if (f->kind == 1) return f->ip[e * nq + q];
+  double s = f->amp;
+  for (int d = 0; d < dim; ++d) s *= sin(f->freq[d] * x[d]);
+  return s;
+}
+
+enum { F_VAL = 0, F_GRAD = 1, F_DIV = 2, F_DOT = 3 };
+
+/* Workset::evaluateSolutionField (workset.cpp:937-1062): f(pt) = sum_dof u_AD(dof) * basis(dof, pt, comp) */
+static void eval_field(const blk_ctx *c, int var, int kind, int comp, ad_t *out /*[nq]*/) {
+  const orc_block_args *a = c->a;
+  const int n = c->varptr[var + 1] - c->varptr[var], nq = c->nq, dim = a->dim;
+  const int nc = ncomp_of(dim, a->types[var]);
+  for (int pt = 0; pt < nq; ++pt) {
+    ad_t acc = ad_c(0.0);
+    for (int dof = 0; dof < n; ++dof) {
+      double b;
+      const size_t o = (size_t)dof * nq + pt;
+      if (kind == F_GRAD) b = c->grad[var][o * dim + comp];
+      else if (kind == F_DIV) b = c->div[var][o];
+      else b = c->basis[var][o * nc + comp];
+      const ad_t *s = (kind == F_DOT ? c->udAD : c->uAD) + c->varptr[var] + dof;
+      for (int j = 0; j < g_w1; ++j) acc.v[j] += s->v[j] * b;
+    }
+    out[pt] = acc;
+  }
+}
+
+/* res(elem, off(dof)) += F * b */
+static void res_add(ad_t *res, int pos, const ad_t *F, double b) {
+  for (int j = 0; j < g_w1; ++j) res[pos].v[j] += F->v[j] * b;
+}
+
+static void porous_volume(const blk_ctx *c, size_t e, ad_t *res) {
+  const orc_block_args *a = c->a;
+  const int dim = a->dim, nq = c->nq, pnum = 0, unum = 1;
+  const int nu = c->varptr[unum + 1] - c->varptr[unum], np = c->varptr[pnum + 1] - c->varptr[pnum];
+  ad_t *psol = malloc(sizeof(ad_t) * nq), *udiv = malloc(sizeof(ad_t) * nq);
+  ad_t *ucomp[3] = {NULL, NULL, NULL};
+  eval_field(c, pnum, F_VAL, 0, psol);
+  for (int d = 0; d < dim; ++d) { ucomp[d] = malloc(sizeof(ad_t) * nq); eval_field(c, unum, F_VAL, d, ucomp[d]); }
+  eval_field(c, unum, F_DIV, 0, udiv);
+  /* ((mobility K)^-1 u, v) - (p, div v)   (porousMixed.cpp:236-313) */
+  for (int pt = 0; pt < nq; ++pt) {
+    const double w = c->wts[pt], *x = c->ip + (size_t)pt * dim;
+    const double mob = eval_func(&a->funcs[4], dim, e, pt, nq, x);
+    ad_t p = ad_scale(psol[pt], w), Kiu[3];
+    for (int d = 0; d < dim; ++d) {
+      const double Kinv = eval_func(&a->funcs[1 + d], dim, e, pt, nq, x);
+      Kiu[d] = ad_scale(ad_scale(ucomp[d][pt], Kinv), w);
+      Kiu[d] = ad_scale(Kiu[d], 1.0 / mob);
+    }
+    for (int dof = 0; dof < nu; ++dof) {
+      const int pos = a->offsets[c->varptr[unum] + dof];
+      const size_t o = (size_t)dof * nq + pt;
+      for (int d = 0; d < dim; ++d) res_add(res, pos, &Kiu[d], c->basis[unum][o * dim + d]);
+      res_add(res, pos, &p, -c->div[unum][o]);
+    }
+  }
+  /* -(div u, q) + (src, q)   (porousMixed.cpp:316-337) */
+  for (int pt = 0; pt < nq; ++pt) {
+    const double *x = c->ip + (size_t)pt * dim;
+    ad_t F = ad_c(eval_func(&a->funcs[0], dim, e, pt, nq, x));
+    F = ad_scale(ad_sub(F, &udiv[pt]), c->wts[pt]);
+    for (int dof = 0; dof < np; ++dof)
+      res_add(res, a->offsets[c->varptr[pnum] + dof], &F, c->basis[pnum][(size_t)dof * nq + pt]);
+  }
+  free(psol); free(udiv);
+  for (int d = 0; d < dim; ++d) free(ucomp[d]);
+}
+
+/* navierstokes::computeTau (navierstokes.cpp:1054-1079) */
+static ad_t ns_tau(double visc, const ad_t *vel, int dim, double h, double dt, int transient) {
+  const double C1 = 4.0, C2 = 2.0, C3 = transient ? 2.0 : 0.0;
+  ad_t nvel = ad_c(0.0);
+  for (int d = 0; d < dim; ++d) { ad_t sq = ad_mul(&vel[d], &vel[d]); nvel = ad_add(nvel, &sq); }
+  if (nvel.v[0] > 1e-12) nvel = ad_sqrt(&nvel);
+  ad_t t2 = ad_scale(nvel, C2 / h);
+  ad_t tau = ad_mul(&t2, &t2);
+  tau.v[0] += (C1 * visc / h / h) * (C1 * visc / h / h) + (C3 / dt) * (C3 / dt);
+  ad_t rt = ad_sqrt(&tau), one = ad_c(1.0);
+  return ad_div(&one, &rt);
+}
+
+static void ns_volume(const blk_ctx *c, size_t e, ad_t *res) {
+  const orc_block_args *a = c->a;
+  const int dim = a->dim, nq = c->nq;
+  /* myvars = ux, pr, uy[, uz] (navierstokes.cpp:27-34) */
+  const int vnum[3] = {0, 2, 3}, prnum = 1;
+  const int useSUPG = a->params[0] != 0.0, usePSPG = a->params[1] != 0.0, fix_uz = a->params[2] != 0.0;
+  ad_t *U[3], *Ut[3], *dU[3][3], *pr = malloc(sizeof(ad_t) * nq), *dpr[3] = {NULL, NULL, NULL};
+  for (int i = 0; i < dim; ++i) {
+    U[i] = malloc(sizeof(ad_t) * nq); Ut[i] = malloc(sizeof(ad_t) * nq);
+    eval_field(c, vnum[i], F_VAL, 0, U[i]);
+    eval_field(c, vnum[i], F_DOT, 0, Ut[i]);
+    for (int d = 0; d < dim; ++d) { dU[i][d] = malloc(sizeof(ad_t) * nq); eval_field(c, vnum[i], F_GRAD, d, dU[i][d]); }
+  }
+  eval_field(c, prnum, F_VAL, 0, pr);
+  if (useSUPG || usePSPG)
+    for (int d = 0; d < dim; ++d) { dpr[d] = malloc(sizeof(ad_t) * nq); eval_field(c, prnum, F_GRAD, d, dpr[d]); }
+  double vol = 0.0; /* Workset::getElementSize (workset.cpp:2666-2679) */
+  for (int pt = 0; pt < nq; ++pt) vol += c->wts[pt];
+  const double h = pow(vol, 1.0 / (double)dim);
+  for (int pt = 0; pt < nq; ++pt) {
+    const double w = c->wts[pt], *x = c->ip + (size_t)pt * dim;
+    const double src[3] = {eval_func(&a->funcs[0], dim, e, pt, nq, x), eval_func(&a->funcs[2], dim, e, pt, nq, x),
+                           eval_func(&a->funcs[3], dim, e, pt, nq, x)};
+    const double dens = eval_func(&a->funcs[4], dim, e, pt, nq, x), visc = eval_func(&a->funcs[5], dim, e, pt, nq, x);
+    ad_t vel[3];
+    for (int d = 0; d < dim; ++d) vel[d] = U[d][pt];
+    ad_t tau = ad_c(0.0);
+    if (useSUPG || usePSPG) tau = ns_tau(visc, vel, dim, h, a->dt, a->transient);
+    ad_t stab[3]; /* strong momentum residual of component i */
+    for (int i = 0; i < dim; ++i) {
+      /* F_d = visc * d u_i/dx_d (- pr if d == i), * wts ; F = (u_i_t + u . grad u_i - source_i) dens wts */
+      ad_t conv = ad_c(0.0);
+      for (int d = 0; d < dim; ++d) { ad_t t = ad_mul(&vel[d], &dU[i][d][pt]); conv = ad_add(conv, &t); }
+      ad_t F = ad_add(Ut[i][pt], &conv);
+      F.v[0] -= src[i];
+      F = ad_scale(F, dens * w);
+      ad_t Fd[3];
+      for (int d = 0; d < dim; ++d) {
+        Fd[d] = ad_scale(dU[i][d][pt], visc);
+        if (d == i) Fd[d] = ad_sub(Fd[d], &pr[pt]);
+        Fd[d] = ad_scale(Fd[d], w);
+      }
+      /* the reference's 3-D uz block scatters through uy's offsets (navierstokes.cpp:688) */
+      const int rowvar = (dim == 3 && i == 2 && !fix_uz) ? vnum[1] : vnum[i];
+      const int v = vnum[i], n = c->varptr[v + 1] - c->varptr[v];
+      for (int dof = 0; dof < n; ++dof) {
+        const int pos = a->offsets[c->varptr[rowvar] + dof];
+        const size_t o = (size_t)dof * nq + pt;
+        for (int d = 0; d < dim; ++d) res_add(res, pos, &Fd[d], c->grad[v][o * dim + d]);
+        res_add(res, pos, &F, c->basis[v][o]);
+      }
+      if (useSUPG || usePSPG) {
+        stab[i] = ad_scale(ad_add(Ut[i][pt], &conv), dens);
+        stab[i] = ad_add(stab[i], &dpr[i][pt]);
+        stab[i].v[0] -= dens * src[i];
+      }
+      if (useSUPG) { /* S_d = tau * stabres * u_d * wts */
+        ad_t ts = ad_mul(&tau, &stab[i]);
+        for (int dof = 0; dof < n; ++dof) {
+          const int pos = a->offsets[c->varptr[rowvar] + dof];
+          for (int d = 0; d < dim; ++d) {
+            ad_t S = ad_scale(ad_mul(&ts, &vel[d]), w);
+            res_add(res, pos, &S, c->grad[v][((size_t)dof * nq + pt) * dim + d]);
+          }
+        }
+      }
+    }
+    { /* pressure equation: div u * wts (+ PSPG) */
+      ad_t divu = ad_c(0.0);
+      for (int d = 0; d < dim; ++d) divu = ad_add(divu, &dU[d][d][pt]);
+      divu = ad_scale(divu, w);
+      const int n = c->varptr[prnum + 1] - c->varptr[prnum];
+      for (int dof = 0; dof < n; ++dof) {
+        const int pos = a->offsets[c->varptr[prnum] + dof];
+        res_add(res, pos, &divu, c->basis[prnum][(size_t)dof * nq + pt]);
+        if (usePSPG)
+          for (int d = 0; d < dim; ++d) {
+            ad_t S = ad_scale(ad_mul(&stab[d], &tau), w / dens);
+            res_add(res, pos, &S, c->grad[prnum][((size_t)dof * nq + pt) * dim + d]);
+          }
+      }
+    }
+  }
+  for (int i = 0; i < dim; ++i) {
+    free(U[i]); free(Ut[i]);
+    for (int d = 0; d < dim; ++d) free(dU[i][d]);
+    free(dpr[i]);
+  }
+  free(pr);
+}
+
+static void thermal_volume(const blk_ctx *c, size_t e, ad_t *res) {
+  const orc_block_args *a = c->a;
+  const int dim = a->dim, nq = c->nq, n = c->varptr[1];
+  ad_t *T = malloc(sizeof(ad_t) * nq), *Tt = malloc(sizeof(ad_t) * nq), *dT[3];
+  eval_field(c, 0, F_VAL, 0, T);
+  eval_field(c, 0, F_DOT, 0, Tt);
+  for (int d = 0; d < dim; ++d) { dT[d] = malloc(sizeof(ad_t) * nq); eval_field(c, 0, F_GRAD, d, dT[d]); }
+  for (int pt = 0; pt < nq; ++pt) {
+    const double w = c->wts[pt], *x = c->ip + (size_t)pt * dim;
+    const double f = eval_func(&a->funcs[0], dim, e, pt, nq, x), kap = eval_func(&a->funcs[1], dim, e, pt, nq, x);
+    const double cp = eval_func(&a->funcs[2], dim, e, pt, nq, x), rho = eval_func(&a->funcs[3], dim, e, pt, nq, x);
+    ad_t F = ad_scale(Tt[pt], rho * cp);
+    F.v[0] -= f;
+    F = ad_scale(F, w);
+    for (int dof = 0; dof < n; ++dof) {
+      const int pos = a->offsets[dof];
+      const size_t o = (size_t)dof * nq + pt;
+      res_add(res, pos, &F, c->basis[0][o]);
+      for (int d = 0; d < dim; ++d) {
+        ad_t G = ad_scale(dT[d][pt], kap * w);
+        res_add(res, pos, &G, c->grad[0][o * dim + d]);
+      }
+    }
+  }
+  free(T); free(Tt);
+  for (int d = 0; d < dim; ++d) free(dT[d]);
+}
+
+static int ctx_init(blk_ctx *c, const orc_block_args *a) {
+  int n1;
+  memset(c, 0, sizeof(*c));
+  c->a = a;
+  if (orc_ref_sizes(a->dim, 1, a->qdeg, &n1, &c->nq, &c->nn)) return -1;
+  for (int v = 0; v < a->nvars; ++v) {
+    const int card = orc_basis_card(a->dim, a->types[v], a->orders[v]);
+    if (card < 0) return -1;
+    c->varptr[v + 1] = c->varptr[v] + card;
+  }
+  c->n_tot = c->varptr[a->nvars];
+  if (c->n_tot + 1 > ADMAX) return -1;
+  for (int v = 0; v < a->nvars; ++v) {
+    const int n = c->varptr[v + 1] - c->varptr[v];
+    c->basis[v] = malloc(sizeof(double) * n * c->nq * ncomp_of(a->dim, a->types[v]));
+    c->grad[v] = malloc(sizeof(double) * n * c->nq * a->dim);
+    c->div[v] = malloc(sizeof(double) * n * c->nq);
+  }
+  c->wts = malloc(sizeof(double) * c->nq);
+  c->ip = malloc(sizeof(double) * c->nq * a->dim);
+  c->uAD = malloc(sizeof(ad_t) * c->n_tot);
+  c->udAD = malloc(sizeof(ad_t) * c->n_tot);
+  return 0;
+}
+
+static void ctx_free(blk_ctx *c) {
+  for (int v = 0; v < c->a->nvars; ++v) { free(c->basis[v]); free(c->grad[v]); free(c->div[v]); }
+  free(c->wts); free(c->ip); free(c->uAD); free(c->udAD);
+}
+
+/* performGather + computeSoln{Steady,Transient}Seeded (assemblyManager.cpp:3598-3643, workset.cpp:823-859, 559-623) */
+static void gather_seed(blk_ctx *c, size_t e) {
+  const orc_block_args *a = c->a;
+  const int *L = a->lids + e * c->n_tot;
+  for (int f = 0; f < c->n_tot; ++f) {
+    const int off = a->offsets[f], row = L[off];
+    const double cu = a->u[row];
+    ad_t ua = ad_c(0.0), ud = ad_c(0.0);
+    if (!a->transient) {
+      ua.v[0] = cu;
+      if (a->compute_jacobian) ua.v[1 + off] = 1.0;
+    } else {
+      const int st = a->stage, S = a->nstages, NS = a->nsteps;
+      const double *cp = a->u_prev + (size_t)row * NS, *cs = a->u_stage + (size_t)row * S;
+      const double alpha_u = a->butcher_A[st * S + st] / a->butcher_b[st];
+      const double timewt = 1.0 / a->dt / a->butcher_b[st];
+      const double alpha_t = a->bdf[0] * timewt;
+      double beta_u = (1.0 - alpha_u) * cp[0];
+      for (int s = 0; s < st; ++s) beta_u += a->butcher_A[st * S + s] / a->butcher_b[s] * (cs[s] - cp[0]);
+      double beta_t = 0.0;
+      for (int s = 1; s < NS + 1; ++s) beta_t += a->bdf[s] * cp[s - 1];
+      beta_t *= timewt;
+      ua.v[0] = alpha_u * cu + beta_u;
+      ud.v[0] = alpha_t * cu + beta_t;
+      if (a->compute_jacobian) { ua.v[1 + off] = alpha_u; ud.v[1 + off] = alpha_t; }
+    }
+    c->uAD[f] = ua;
+    c->udAD[f] = ud;
+  }
+}
+
+/* scatter (assemblyManager.cpp:4031-4145): residual gets -val, Jacobian +dx, fixed rows skipped */
+static void scatter(const blk_ctx *c, size_t e, const ad_t *res) {
+  const orc_block_args *a = c->a;
+  const int n = c->n_tot;
+  const int *L = a->lids + e * n;
+  for (int row = 0; row < n; ++row) {
+    const ad_t *r = &res[row];
+    if (a->local_res) a->local_res[e * n + row] -= r->v[0];
+    if (a->local_J && a->compute_jacobian)
+      for (int col = 0; col < n; ++col) a->local_J[(e * n + row) * n + col] += r->v[1 + col];
+    const int rowIndex = L[row];
+    if (a->fixed && a->fixed[rowIndex]) continue;
+    if (a->res) a->res[rowIndex] += -r->v[0];
+    if (a->crs_vals && a->compute_jacobian)
+      for (int col = 0; col < n; ++col) {
+        const int gcol = L[col];
+        for (int p = a->rowptr[rowIndex]; p < a->rowptr[rowIndex + 1]; ++p)
+          if (a->colind[p] == gcol) { a->crs_vals[p] += r->v[1 + col]; break; }
+      }
+  }
+}
+
+int orc_assemble_block(const orc_block_args *a) {
+  blk_ctx c;
+  if (ctx_init(&c, a)) return -1;
+  g_w1 = c.n_tot + 1;
+  ad_t *res = malloc(sizeof(ad_t) * c.n_tot);
+  for (size_t e = 0; e < (size_t)a->nelem; ++e) {
+    const double *xn = a->nodes + e * c.nn * a->dim;
+    for (int v = 0; v < a->nvars; ++v)
+      orc_physical_basis_var(a->dim, a->types[v], a->orders[v], a->qdeg, 1, xn,
+                             a->orient ? a->orient + e * c.n_tot : NULL, 0, c.varptr[v], c.basis[v], c.grad[v], c.div[v],
+                             v == 0 ? c.wts : NULL, v == 0 ? c.ip : NULL);
+    gather_seed(&c, e);
+    for (int k = 0; k < c.n_tot; ++k) res[k] = ad_c(0.0);
+    if (a->physics == ORC_PHYS_POROUS_MIXED) porous_volume(&c, e, res);
+    else if (a->physics == ORC_PHYS_NAVIERSTOKES) ns_volume(&c, e, res);
+    else if (a->physics == ORC_PHYS_THERMAL) thermal_volume(&c, e, res);
+    else { free(res); ctx_free(&c); return -2; }
+    scatter(&c, e, res);
+  }
+  free(res);
+  ctx_free(&c);
+  return 0;
+}
+
+int orc_assemble_block_boundary(const orc_block_args *a) {
+  blk_ctx c;
+  if (ctx_init(&c, a)) return -1;
+  if (a->physics != ORC_PHYS_POROUS_MIXED || a->bc_type != 1) { ctx_free(&c); return -2; }
+  g_w1 = c.n_tot + 1;
+  int ns, nqs;
+  orc_side_sizes(a->dim, a->qdeg, &ns, &nqs);
+  const int dim = a->dim, unum = 1, nu = 2 * dim, nb = a->nb;
+  double *wts = malloc(sizeof(double) * (size_t)nb * nqs), *nrm = malloc(sizeof(double) * (size_t)nb * nqs * dim);
+  double *ip = malloc(sizeof(double) * (size_t)nb * nqs * dim), *sb = malloc(sizeof(double) * (size_t)nb * nu * nqs * dim);
+  orc_physical_side_basis(dim, 1, a->qdeg, nb, a->nodes, a->belem, a->bside, wts, nrm, ip, NULL, NULL);
+  orc_physical_side_basis_hdiv(dim, a->qdeg, nb, a->nodes, a->belem, a->bside, a->orient, c.n_tot, c.varptr[unum], sb);
+  ad_t *res = malloc(sizeof(ad_t) * c.n_tot);
+  for (int k = 0; k < nb; ++k) {
+    const size_t e = (size_t)a->belem[k];
+    for (int j = 0; j < c.n_tot; ++j) res[j] = ad_c(0.0);
+    /* res(off_u(dof)) += bsource * wts * (v . n)   (porousMixed.cpp:400-418) */
+    for (int pt = 0; pt < nqs; ++pt) {
+      ad_t src = ad_c(eval_func(&a->bdata, dim, (size_t)k, pt, nqs, ip + ((size_t)k * nqs + pt) * dim) *
+                      wts[(size_t)k * nqs + pt]);
+      for (int dof = 0; dof < nu; ++dof) {
+        double vdotn = 0.0;
+        for (int d = 0; d < dim; ++d)
+          vdotn += sb[(((size_t)k * nu + dof) * nqs + pt) * dim + d] * nrm[((size_t)k * nqs + pt) * dim + d];
+        res_add(res, a->offsets[c.varptr[unum] + dof], &src, vdotn);
+      }
+    }
+    scatter(&c, e, res);
+  }
+  free(wts); free(nrm); free(ip); free(sb); free(res);
+  ctx_free(&c);
+  return 0;
+}

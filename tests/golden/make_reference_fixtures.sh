@@ -11,3 +11,9 @@ for c in 2D_verification 3D_verification 2D_verification_highorder 2D_verificati
   cp $R/thermal/$c/mrhyde.gold  $D/thermal_$c.gold
   cp $R/thermal/$c/input.yaml   $D/thermal_$c.input.yaml
 done
+for c in Mixed Mixed_3d; do
+  cp $R/porous/$c/mrhyde.gold  $D/porous_$c.gold
+  cp $R/porous/$c/input.yaml   $D/porous_$c.input.yaml
+done
+cp $R/navierstokes/channel/mrhyde.gold  $D/navierstokes_channel.gold
+cp $R/navierstokes/channel/input.yaml   $D/navierstokes_channel.input.yaml

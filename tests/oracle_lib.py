@@ -339,3 +339,194 @@ def assemble_thermal_boundary(dim, order, qdeg, nodes, lids, offsets, u, belem, 
     a.rowptr, a.colind, a.crs_vals, a.res = _i(rowptr), _i(colind), _d(crs_vals), _d(res)
     rc = lib().orc_assemble_thermal_boundary(C.byref(a))
     assert rc == 0, rc
+
+
+# ---- multi-variable blocks ----------------------------------------------------------------------------------------
+HGRAD, HVOL, HDIV = 0, 1, 2
+PHYS_THERMAL, PHYS_POROUS_MIXED, PHYS_NAVIERSTOKES = 1, 2, 3
+_sp = C.POINTER(C.c_byte)
+
+
+class Func(C.Structure):
+    _fields_ = [("kind", C.c_int), ("amp", C.c_double), ("freq", C.c_double * 3), ("ip", _dp)]
+
+
+class BlockArgs(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int), ("qdeg", C.c_int), ("nvars", C.c_int),
+        ("types", C.c_int * 8), ("orders", C.c_int * 8), ("physics", C.c_int),
+        ("nelem", C.c_int), ("nrows", C.c_int),
+        ("nodes", _dp), ("lids", _ip), ("offsets", _ip), ("orient", _sp), ("fixed", _up), ("u", _dp),
+        ("transient", C.c_int), ("nsteps", C.c_int), ("nstages", C.c_int), ("stage", C.c_int),
+        ("u_prev", _dp), ("u_stage", _dp), ("butcher_A", _dp), ("butcher_b", _dp), ("bdf", _dp),
+        ("dt", C.c_double),
+        ("funcs", Func * 8), ("params", C.c_double * 8),
+        ("compute_jacobian", C.c_int),
+        ("rowptr", _ip), ("colind", _ip), ("crs_vals", _dp), ("res", _dp), ("local_J", _dp), ("local_res", _dp),
+        ("nb", C.c_int), ("belem", _ip), ("bside", _ip), ("bc_type", C.c_int), ("bdata", Func),
+    ]
+
+
+def basis_card(dim, typ, order):
+    return lib().orc_basis_card(dim, typ, order)
+
+
+def mesh_multi(dim, ncell, types, orders, lo=None, hi=None):
+    ncell = np.asarray(ncell, dtype=np.int32)
+    lo = np.zeros(3) if lo is None else np.asarray(lo, dtype=np.float64)
+    hi = np.ones(3) if hi is None else np.asarray(hi, dtype=np.float64)
+    types, orders = np.asarray(types, dtype=np.int32), np.asarray(orders, dtype=np.int32)
+    nv, ne, nt, nd = C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
+    rc = lib().orc_mesh_multi_sizes(dim, _i(ncell), len(types), _i(types), _i(orders), C.byref(nv), C.byref(ne),
+                                    C.byref(nt), C.byref(nd))
+    assert rc == 0, rc
+    nn = 2 ** dim
+    m = dict(verts=np.zeros((nv.value, dim)), cell2vert=np.zeros((ne.value, nn), np.int32),
+             lids=np.zeros((ne.value, nt.value), np.int32), offsets=np.zeros(nt.value, np.int32),
+             orient=np.ones((ne.value, nt.value), np.int8), side_mask=np.zeros(nd.value, np.uint8),
+             dof_var=np.zeros(nd.value, np.int32), ndof=nd.value, nelem=ne.value, n_tot=nt.value,
+             types=types, orders=orders, dim=dim, ncell=tuple(int(c) for c in ncell))
+    rc = lib().orc_mesh_multi(dim, _i(ncell), _d(lo), _d(hi), len(types), _i(types), _i(orders), _d(m["verts"]),
+                              _i(m["cell2vert"]), _i(m["lids"]), _i(m["offsets"]), m["orient"].ctypes.data_as(_sp),
+                              _u(m["side_mask"]), _i(m["dof_var"]))
+    assert rc == 0, rc
+    m["nodes"] = np.ascontiguousarray(m["verts"][m["cell2vert"]])
+    cards = [basis_card(dim, int(t), int(o)) for t, o in zip(types, orders)]
+    m["varptr"] = np.concatenate([[0], np.cumsum(cards)]).astype(np.int32)
+    return m
+
+
+def physical_basis_var(dim, typ, order, qdeg, nodes, orient=None):
+    """orient: int8 [E][n] signs of this variable's dofs (HDIV) or None."""
+    _, nq, _ = ref_sizes(dim, 1, qdeg)
+    n = basis_card(dim, typ, order)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    E = nodes.shape[0]
+    nc = dim if typ == HDIV else 1
+    out = dict(basis=np.zeros((E, n, nq, nc)), grad=np.zeros((E, n, nq, dim)), div=np.zeros((E, n, nq)),
+               wts=np.zeros((E, nq)), ip=np.zeros((E, nq, dim)))
+    op, stride = None, 0
+    if orient is not None:
+        orient = np.ascontiguousarray(orient, dtype=np.int8)
+        op, stride = orient.ctypes.data_as(_sp), orient.shape[1]
+    rc = lib().orc_physical_basis_var(dim, typ, order, qdeg, E, _d(nodes), op, stride, 0, _d(out["basis"]),
+                                      _d(out["grad"]), _d(out["div"]), _d(out["wts"]), _d(out["ip"]))
+    assert rc == 0, rc
+    return out
+
+
+def _func(spec, keep):
+    f = Func()
+    if isinstance(spec, (int, float)):
+        f.kind, f.amp = 0, float(spec)
+    elif spec[0] == "const":
+        f.kind, f.amp = 0, float(spec[1])
+    elif spec[0] == "array":
+        arr = np.ascontiguousarray(spec[1], dtype=np.float64)
+        keep.append(arr)
+        f.kind, f.ip = 1, _d(arr)
+    elif spec[0] == "sinprod":
+        f.kind, f.amp = 2, float(spec[1])
+        fr = list(spec[2]) + [0.0] * (3 - len(spec[2]))
+        f.freq = (C.c_double * 3)(*fr)
+    else:
+        raise ValueError(spec)
+    return f
+
+
+PHYS_FUNCS = {
+    PHYS_THERMAL: ["thermal source", "thermal diffusion", "specific heat", "density"],
+    PHYS_POROUS_MIXED: ["source", "Kinv_xx", "Kinv_yy", "Kinv_zz", "total_mobility"],
+    PHYS_NAVIERSTOKES: ["source ux", "source pr", "source uy", "source uz", "density", "viscosity"],
+}
+PHYS_DEFAULTS = {
+    PHYS_THERMAL: [0.0, 1.0, 1.0, 1.0],
+    PHYS_POROUS_MIXED: [0.0, 1.0, 1.0, 1.0, 1.0],
+    PHYS_NAVIERSTOKES: [0.0, 0.0, 0.0, 0.0, 1.0, 1.0],
+}
+
+
+def _block_args(m, physics, qdeg, u, funcs, params, fixed, transient, compute_jacobian, keep):
+    a = BlockArgs()
+    a.dim, a.qdeg, a.nvars, a.physics = m["dim"], qdeg, len(m["types"]), physics
+    for v, (t, o) in enumerate(zip(m["types"], m["orders"])):
+        a.types[v], a.orders[v] = int(t), int(o)
+    nodes = np.ascontiguousarray(m["nodes"], dtype=np.float64)
+    lids = np.ascontiguousarray(m["lids"], dtype=np.int32)
+    offsets = np.ascontiguousarray(m["offsets"], dtype=np.int32)
+    orient = np.ascontiguousarray(m["orient"], dtype=np.int8)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    keep += [nodes, lids, offsets, orient, u]
+    a.nelem, a.nrows = lids.shape[0], u.shape[0]
+    a.nodes, a.lids, a.offsets, a.u = _d(nodes), _i(lids), _i(offsets), _d(u)
+    a.orient = orient.ctypes.data_as(_sp)
+    if fixed is not None:
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        keep.append(fixed)
+        a.fixed = _u(fixed)
+    if transient is not None:
+        t = {k: np.ascontiguousarray(v, dtype=np.float64) if isinstance(v, np.ndarray) else v
+             for k, v in transient.items()}
+        keep.append(t)
+        a.transient = 1
+        a.nsteps, a.nstages, a.stage = t["u_prev"].shape[1], t["u_stage"].shape[1], t["stage"]
+        a.u_prev, a.u_stage = _d(t["u_prev"]), _d(t["u_stage"])
+        a.butcher_A, a.butcher_b, a.bdf = _d(t["butcher_A"]), _d(t["butcher_b"]), _d(t["bdf"])
+        a.dt = t["dt"]
+    else:
+        a.dt = 1.0
+    names, defaults = PHYS_FUNCS[physics], PHYS_DEFAULTS[physics]
+    funcs = funcs or {}
+    assert set(funcs) <= set(names), set(funcs) - set(names)
+    for k, name in enumerate(names):
+        a.funcs[k] = _func(funcs.get(name, defaults[k]), keep)
+    for k, p in enumerate(params or []):
+        a.params[k] = float(p)
+    a.compute_jacobian = int(compute_jacobian)
+    return a
+
+
+def assemble_block(m, physics, qdeg, u, *, funcs=None, params=None, fixed=None, transient=None, compute_jacobian=True,
+                   rowptr=None, colind=None, want_local=False):
+    keep = []
+    a = _block_args(m, physics, qdeg, u, funcs, params, fixed, transient, compute_jacobian, keep)
+    if rowptr is None:
+        rowptr, colind = build_graph(a.nrows, m["lids"])
+    out = dict(rowptr=rowptr, colind=colind, crs_vals=np.zeros(rowptr[-1]), res=np.zeros(a.nrows))
+    a.rowptr, a.colind, a.crs_vals, a.res = _i(rowptr), _i(colind), _d(out["crs_vals"]), _d(out["res"])
+    if want_local:
+        E, n = m["lids"].shape
+        out["local_J"], out["local_res"] = np.zeros((E, n, n)), np.zeros((E, n))
+        a.local_J, a.local_res = _d(out["local_J"]), _d(out["local_res"])
+    rc = lib().orc_assemble_block(C.byref(a))
+    assert rc == 0, rc
+    return out
+
+
+def assemble_block_boundary(m, physics, qdeg, u, belem, bside, bc_type, data, *, rowptr, colind, crs_vals, res,
+                            funcs=None, params=None, fixed=None, transient=None, compute_jacobian=True):
+    keep = []
+    a = _block_args(m, physics, qdeg, u, funcs, params, fixed, transient, compute_jacobian, keep)
+    belem = np.ascontiguousarray(belem, dtype=np.int32)
+    bside = np.ascontiguousarray(bside, dtype=np.int32)
+    a.nb, a.belem, a.bside, a.bc_type = len(belem), _i(belem), _i(bside), bc_type
+    a.bdata = _func(data, keep)
+    a.rowptr, a.colind, a.crs_vals, a.res = _i(rowptr), _i(colind), _d(crs_vals), _d(res)
+    rc = lib().orc_assemble_block_boundary(C.byref(a))
+    assert rc == 0, rc
+
+
+def physical_side_basis_hdiv(dim, qdeg, nodes, belem, bside, orient=None):
+    _, nqs = side_sizes(dim, qdeg)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    belem = np.ascontiguousarray(belem, dtype=np.int32)
+    bside = np.ascontiguousarray(bside, dtype=np.int32)
+    out = np.zeros((len(belem), 2 * dim, nqs, dim))
+    op, stride = None, 0
+    if orient is not None:
+        orient = np.ascontiguousarray(orient, dtype=np.int8)
+        op, stride = orient.ctypes.data_as(_sp), orient.shape[1]
+    rc = lib().orc_physical_side_basis_hdiv(dim, qdeg, len(belem), _d(nodes), _i(belem), _i(bside), op, stride, 0,
+                                            _d(out))
+    assert rc == 0, rc
+    return out

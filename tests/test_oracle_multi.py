@@ -1,0 +1,182 @@
+"""Oracle (CPU restatement) of the multi-variable physics against the reference's golds:
+regression/porous/Mixed (2-D, weak Dirichlet p through porousMixed::boundaryResidual), porous/Mixed_3d (HVOL + HDIV hex)
+and navierstokes/channel (Q1/Q1 + PSPG, Newton).  Fixtures: tests/golden/reference (make_reference_fixtures.sh)."""
+import os
+import re
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference")
+
+
+def gold_errors(name):
+    txt = open(os.path.join(GOLD, name)).read()
+    return {k: float(v) for k, v in re.findall(r"L2 norm of the error for (\w+) = ([-0-9.e]+)", txt)}
+
+
+def fmt(x):
+    return "%.6g" % x
+
+
+def test_mesh_multi_maps(oracle):
+    """Dof-map invariants of the generator: every global dof reached, LIDs of a variable consistent across neighbours,
+    HGRAD single-variable map identical to the single-variable generator (bit-exact)."""
+    for dim, nc in ((2, (3, 2)), (3, (2, 3, 2))):
+        for order in (1, 2):
+            m1 = oracle.mesh_structured(dim, order, nc)
+            mm = oracle.mesh_multi(dim, nc, [oracle.HGRAD], [order])
+            assert np.array_equal(m1["lids"], mm["lids"]) and np.array_equal(m1["offsets"], mm["offsets"])
+            assert np.array_equal(m1["boundary"] != 0, mm["side_mask"] != 0)
+        m = oracle.mesh_multi(dim, nc, [oracle.HGRAD, oracle.HGRAD] + [oracle.HGRAD] * (dim - 1), [2, 1] + [2] * (dim - 1))
+        assert sorted(np.unique(m["lids"])) == list(range(m["ndof"]))
+        assert sorted(m["offsets"]) == list(range(m["n_tot"]))
+        # the first LID positions interleave the variables at vertex 0 (subcell-major layout)
+        assert list(m["dof_var"][m["lids"][0, :dim + 1]]) == list(range(dim + 1))
+        mp = oracle.mesh_multi(dim, nc, [oracle.HVOL, oracle.HDIV], [0, 1])
+        E = mp["nelem"]
+        assert mp["n_tot"] == 1 + 2 * dim and sorted(np.unique(mp["lids"])) == list(range(mp["ndof"]))
+        # a face dof is shared by at most two cells, and the two cells give the effective (sign x raw) function the same
+        # global direction: raw functions all point along +x_c, so the signs agree
+        u0 = mp["varptr"][1]
+        seen = {}
+        for e in range(E):
+            for f in range(2 * dim):
+                g = mp["lids"][e, mp["offsets"][u0 + f]]
+                seen.setdefault(g, []).append(mp["orient"][e, u0 + f])
+        assert all(len(v) <= 2 and len(set(v)) == 1 for v in seen.values())
+
+
+def _solve_porous(oracle, dim, ncell, pD):
+    m = oracle.mesh_multi(dim, ncell, [oracle.HVOL, oracle.HDIV], [0, 1])
+    qdeg = 2
+    funcs = {"source": ("sinprod", 4 * dim * np.pi ** 2, [2 * np.pi] * dim)}
+    u = np.zeros(m["ndof"])
+    out = None
+    for _ in range(2):  # "max nonlinear iters: 2" (linear problem: second residual ~ 0)
+        out = oracle.assemble_block(m, oracle.PHYS_POROUS_MIXED, qdeg, u, funcs=funcs)
+        if pD is not None:
+            names = ["left", "right", "bottom", "top"] + (["back", "front"] if dim == 3 else [])
+            for name in names:
+                be, bs = oracle.boundary_sides(dim, ncell, name)
+                oracle.assemble_block_boundary(m, oracle.PHYS_POROUS_MIXED, qdeg, u, be, bs, 1, ("const", pD),
+                                               rowptr=out["rowptr"], colind=out["colind"], crs_vals=out["crs_vals"],
+                                               res=out["res"], funcs=funcs)
+        if np.abs(out["res"]).max() < 1e-9:
+            break
+        J = sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]), shape=(m["ndof"],) * 2)
+        u = u + spla.spsolve(J.tocsc(), out["res"])
+    # errors (postprocessManager.cpp:1255-1268 "L2", :1358-1420 "L2 VECTOR")
+    pb = oracle.physical_basis_var(dim, oracle.HVOL, 0, qdeg, m["nodes"])
+    ub = oracle.physical_basis_var(dim, oracle.HDIV, 1, qdeg, m["nodes"], m["orient"][:, m["varptr"][1]:])
+    x, w = pb["ip"], pb["wts"]
+    s, c = np.sin(2 * np.pi * x), np.cos(2 * np.pi * x)
+    p_true = (pD or 0.0) + np.prod(s, axis=-1)
+    ph = u[m["lids"][:, m["offsets"][0]]][:, None]
+    ep = np.sqrt(np.sum((ph - p_true) ** 2 * w))
+    ue = u[m["lids"][:, m["offsets"][m["varptr"][1]:]]]                       # [E][2d] in basis order
+    uh = np.einsum("ef,efqd->eqd", ue, ub["basis"])
+    eu = 0.0
+    for d in range(dim):
+        others = [k for k in range(dim) if k != d]
+        ut = -2 * np.pi * c[..., d] * np.prod(s[..., others], axis=-1)
+        eu += np.sum((uh[..., d] - ut) ** 2 * w)
+    return ep, np.sqrt(eu), m, out
+
+
+def test_porous_mixed_2d_gold(oracle):
+    """regression/porous/Mixed: HVOL(0)+HDIV(1) quads, p = 1 imposed weakly on all four sides."""
+    ep, eu, _, _ = _solve_porous(oracle, 2, (8, 8), 1.0)
+    g = gold_errors("porous_Mixed.gold")
+    assert fmt(ep) == fmt(g["p"]) == "0.158697" and fmt(eu) == fmt(g["u"]) == "1.02259"
+
+
+def test_porous_mixed_3d_gold(oracle):
+    """regression/porous/Mixed_3d: HVOL(0)+HDIV(1) hexes, natural p = 0."""
+    ep, eu, m, out = _solve_porous(oracle, 3, (8, 8, 8), None)
+    g = gold_errors("porous_Mixed_3d.gold")
+    assert fmt(ep) == fmt(g["p"]) == "0.135175" and fmt(eu) == fmt(g["u"]) == "1.22176"
+    J = sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]))
+    assert abs(J - J.T).max() < 1e-13  # saddle-point system is symmetric
+
+
+def solve_ns_channel(assemble, oracle, ncell=(50, 10)):
+    """regression/navierstokes/channel: 5x1 channel, Q1/Q1 + PSPG, ux = uy = 0 on top/bottom, body force 1,
+    Newton from 0.  `assemble(m, u)` -> (J csr with DBC rows, rhs)."""
+    H, V = oracle.HGRAD, None
+    m = oracle.mesh_multi(2, ncell, [H, H, H], [1, 1, 1], hi=[5.0, 1.0, 1.0])
+    m["fixed"] = (((m["side_mask"] & 0b1100) != 0) & (m["dof_var"] != 1)).astype(np.uint8)
+    u = np.zeros(m["ndof"])
+    for it in range(10):  # defaults: "max nonlinear iters" 10, "nonlinear TOL" 1e-6 (solverManager.cpp)
+        J, rhs = assemble(m, u)
+        if it > 0 and np.linalg.norm(rhs) < 1e-12:
+            break
+        u = u + spla.spsolve(J.tocsc(), rhs)
+    errs = {}
+    pb = oracle.physical_basis_var(2, H, 1, 2, m["nodes"])
+    y, w = pb["ip"][..., 1], pb["wts"]
+    true = {0: 0.5 * y * (1 - y), 1: 0 * y, 2: 0 * y}
+    for v, name in ((0, "ux"), (1, "pr"), (2, "uy")):
+        ue = u[m["lids"][:, m["offsets"][m["varptr"][v]:m["varptr"][v + 1]]]]
+        uh = np.einsum("ef,efq->eq", ue, pb["basis"][..., 0])
+        errs[name] = np.sqrt(np.sum((uh - true[v]) ** 2 * w))
+    return errs
+
+
+def test_navierstokes_channel_gold(oracle):
+    def assemble(m, u):
+        out = oracle.assemble_block(m, oracle.PHYS_NAVIERSTOKES, 2, u, funcs={"source ux": 1.0}, params=[0, 1, 0],
+                                    fixed=m["fixed"])
+        oracle.apply_dbc_diag(m["fixed"], out["rowptr"], out["colind"], out["crs_vals"])
+        return sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]), shape=(m["ndof"],) * 2), out["res"]
+
+    errs = solve_ns_channel(assemble, oracle)
+    g = gold_errors("navierstokes_channel.gold")
+    for k in ("ux", "pr", "uy"):
+        assert fmt(errs[k]) == fmt(g[k]), (k, errs[k], g[k])
+
+
+def test_block_thermal_equals_single_variable_oracle(oracle):
+    """The multi-variable restatement run on thermal must equal the single-variable one entry for entry."""
+    rng = np.random.default_rng(4)
+    for dim, order, qdeg, nc in ((2, 2, 4, (3, 2)), (3, 1, 2, (2, 2, 3))):
+        m = oracle.mesh_multi(dim, nc, [oracle.HGRAD], [order])
+        u = rng.uniform(-1, 1, m["ndof"])
+        tr = dict(u_prev=rng.uniform(-1, 1, (m["ndof"], 1)), u_stage=u[:, None].copy(), stage=0,
+                  butcher_A=np.array([[1.0]]), butcher_b=np.array([1.0]), bdf=np.array([1.0, -1.0]), dt=0.1)
+        src = ("sinprod", 2.0, [1.0, 2.0, 3.0][:dim])
+        a = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, source=src, diff=1.3,
+                                    rho=0.7, cp=1.9, transient=tr, want_local=True)
+        b = oracle.assemble_block(m, oracle.PHYS_THERMAL, qdeg, u, transient=tr, want_local=True,
+                                  funcs={"thermal source": src, "thermal diffusion": 1.3, "density": 0.7,
+                                         "specific heat": 1.9})
+        for k in ("crs_vals", "res", "local_J", "local_res"):
+            assert np.abs(a[k] - b[k]).max() <= 1e-13 * np.abs(a[k]).max(), k
+
+
+def test_navierstokes_jacobian_is_derivative_of_residual(oracle):
+    """AD restatement self-check on a nonlinear module: J du matches the residual difference (SUPG + PSPG, 2-D and
+    3-D, transient), and the reference's uz-offset quirk (navierstokes.cpp:688) leaves the uz rows empty."""
+    rng = np.random.default_rng(9)
+    H = oracle.HGRAD
+    for dim, nc in ((2, (3, 2)), (3, (2, 2, 2))):
+        m = oracle.mesh_multi(dim, nc, [H] * (dim + 1), [2, 1] + [2] * (dim - 1))
+        u = rng.uniform(-1, 1, m["ndof"])
+        tr = dict(u_prev=rng.uniform(-1, 1, (m["ndof"], 1)), u_stage=u[:, None].copy(), stage=0,
+                  butcher_A=np.array([[1.0]]), butcher_b=np.array([1.0]), bdf=np.array([1.0, -1.0]), dt=0.1)
+        funcs = {"source ux": 0.3, "source uy": ("sinprod", 1.0, [1.0, 2.0, 0.5][:dim]), "viscosity": 0.05, "density": 1.3}
+        kw = dict(funcs=funcs, params=[1, 1, 1], transient=tr)
+        a = oracle.assemble_block(m, oracle.PHYS_NAVIERSTOKES, 4, u, **kw)
+        J = sp.csr_matrix((a["crs_vals"], a["colind"], a["rowptr"]), shape=(m["ndof"],) * 2)
+        du = 1e-6 * rng.uniform(-1, 1, m["ndof"])
+        tr2 = dict(tr, u_stage=(u + du)[:, None].copy())
+        b = oracle.assemble_block(m, oracle.PHYS_NAVIERSTOKES, 4, u + du, **dict(kw, transient=tr2))
+        lin = -(J @ du)
+        assert np.abs((b["res"] - a["res"]) - lin).max() < 1e-4 * np.abs(lin).max()
+        if dim == 3:
+            q = oracle.assemble_block(m, oracle.PHYS_NAVIERSTOKES, 4, u, funcs=funcs, params=[0, 0, 0])
+            uz_rows = np.flatnonzero(m["dof_var"] == 3)
+            assert np.all(q["res"][uz_rows] == 0.0)
+            f = oracle.assemble_block(m, oracle.PHYS_NAVIERSTOKES, 4, u, funcs=funcs, params=[0, 0, 1])
+            assert np.abs(f["res"][uz_rows]).max() > 0
