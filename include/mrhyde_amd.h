@@ -54,14 +54,17 @@ int mha_device_count(void);
  *   DiscretizationInterface::getBasis/getQuadrature  discretizationInterface.cpp:346-478 */
 #define MHA_TOPO_QUAD4 4
 #define MHA_TOPO_HEX8 8
-#define MHA_BASIS_HGRAD 0
+#define MHA_BASIS_HGRAD 0   /* Basis_HGRAD_{QUAD,HEX}_Cn_FEM, equispaced   (discretizationInterface.cpp:354-371) */
+#define MHA_BASIS_HVOL 1    /* Basis_HVOL_C0_FEM: order 0                   (:372-374)                             */
+#define MHA_BASIS_HDIV 2    /* Basis_HDIV_{QUAD,HEX}_In_FEM: order 1        (:375-393)                             */
 #define MHA_MAX_VARS 8
 
 typedef struct mha_block_desc {
   int dimension;                 /* 2 or 3                                      */
   int topology;                  /* MHA_TOPO_QUAD4 / MHA_TOPO_HEX8              */
-  int num_vars;                  /* 1 for thermal ("e")                         */
-  int basis_type[MHA_MAX_VARS];  /* MHA_BASIS_HGRAD                             */
+  int num_vars;                  /* thermal: 1 ("e"); porousMixed: 2 ("p","u");
+                                    navierstokes: dim+1 ("ux","pr","uy"[,"uz"])  */
+  int basis_type[MHA_MAX_VARS];  /* MHA_BASIS_*, in the module's myvars order    */
   int basis_order[MHA_MAX_VARS]; /* Discretization: order                       */
   int quadrature_degree;         /* Discretization: quadrature (0 => 2*max order,
                                     discretizationInterface.cpp:166)             */
@@ -83,6 +86,11 @@ int mha_set_stream(mha_context *ctx, void *hip_stream);
  * positions in the element's LID list; is_fixed[nrows] u8 (may be NULL).        */
 int mha_set_mesh(mha_context *ctx, int num_elems, const double *nodes_host, const int32_t *lids_host,
                  const int32_t *offsets_host, int num_rows, const uint8_t *is_fixed_host);
+/* replaces: OrientTools::modifyBasisByOrientation for lowest-order HDIV face dofs
+ * (discretizationInterface.cpp:1021-1027,1055-1061): signs[E][n] int8 (+1/-1) per element and flattened
+ * (variable, dof); the caller computes them from Intrepid2::Orientation (:2467).  NULL resets to +1.
+ * Call after mha_set_mesh.                                                           */
+int mha_set_orientation(mha_context *ctx, const int8_t *signs_host);
 /* overlapped CRS graph of the caller (Tpetra local graph: rowptr[nrows+1], colind sorted
  * ascending per row).  Pass NULL/NULL to build it by the reference rule
  * (linearAlgebraInterface.cpp:218-229).                                          */
@@ -95,12 +103,17 @@ int mha_get_graph(mha_context *ctx, int32_t *rowptr_host, int32_t *colind_host);
  *   src/physics/physicsImporter.cpp:48-204, src/physics/thermal.cpp:24-66
  * Coefficients are what FunctionManager::evaluate(name,"ip") would return
  * (functionManager.cpp:543-760): a constant, or a per-(elem,ip) array.            */
-#define MHA_PHYSICS_THERMAL 1
+#define MHA_PHYSICS_THERMAL 1        /* src/physics/thermal.cpp: e (HGRAD)                                   */
+#define MHA_PHYSICS_POROUS_MIXED 2   /* src/physics/porousMixed.cpp: p (HVOL 0), u (HDIV 1)                   */
+#define MHA_PHYSICS_NAVIERSTOKES 3   /* src/physics/navierstokes.cpp: ux, pr, uy[, uz] (HGRAD)                */
 int mha_physics_select(mha_context *ctx, int physics_id);
 #define MHA_FUNC_CONSTANT 0
 #define MHA_FUNC_IP_ARRAY 1     /* dev pointer to [E][numip] f64                    */
 #define MHA_FUNC_SINPROD 2      /* amp * prod_d sin(freq[d]*x_d), evaluated at ip   */
-/* name in {"thermal source","thermal diffusion","specific heat","density"} or a boundary
+/* thermal: "thermal source","thermal diffusion","specific heat","density" (thermal.cpp:52-63);
+ * porousMixed: "source","Kinv_xx","Kinv_yy","Kinv_zz","total_mobility" (porousMixed.cpp:141-151);
+ * navierstokes: "source ux","source pr","source uy","source uz","density","viscosity"
+ * (navierstokes.cpp:68-74); or a boundary
  * data function "Neumann e <sidename>" / "Dirichlet e <sidename>" (see boundary groups)    */
 int mha_set_function(mha_context *ctx, const char *name, int kind, double amp, const double *freq3,
                      const double *ip_array_dev);
@@ -132,6 +145,9 @@ int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int
                                      fused "assembly insert Jac" with useAtomics)     */
 #define MHA_PATH_ROW_OWNER 2      /* fused row-owner kernel, no global atomics           */
 #define MHA_PATH_LOCAL_THEN_SCATTER 3 /* updateJac/updateRes then scatterJac/scatterRes   */
+#define MHA_PATH_POINT_ENGINE 4   /* multi-variable kernel: point-level forward AD + B^T C B
+                                     contraction, atomic scatter; the path of porousMixed and
+                                     navierstokes, available to thermal as a cross-check    */
 int mha_assemble_jacres(mha_context *ctx, int flags, int path, const double *u_dev,
                         const double *u_prev_dev, const double *u_stage_dev, double *res_dev,
                         double *crs_vals_dev);
@@ -193,7 +209,9 @@ int mha_boundary_update(mha_context *ctx, int group_id);
 int mha_boundary_view(mha_context *ctx, int group_id, const char *name, void **dev_ptr, int64_t extents[4],
                       int *rank);
 /* scalar settings of the physics module; thermal: "form_param" (thermal.cpp:35, default 1:
- * symmetric Nitsche; -1 the non-symmetric variant)                                        */
+ * symmetric Nitsche; -1 the non-symmetric variant); navierstokes: "useSUPG", "usePSPG"
+ * (navierstokes.cpp:45-46) and "fix_uz_offsets": the reference scatters the 3-D uz momentum
+ * block through uy's offsets (navierstokes.cpp:688); 0 (default) reproduces that, 1 uses uz's. */
 int mha_set_physics_parameter(mha_context *ctx, const char *name, double value);
 
 /* ---- structured mesh helper (input generation, not part of the hot path) ------

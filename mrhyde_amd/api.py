@@ -23,7 +23,11 @@ EXPORTS = [
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
+    "mha_set_orientation",
 ]
+BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
+PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3}
+PATH_POINT_ENGINE = 4
 BC_NEUMANN, BC_WEAK_DIRICHLET = 1, 2
 
 
@@ -89,6 +93,7 @@ def load_library():
         _lib.mha_boundary_update.argtypes = [C.c_void_p, C.c_int]
         _lib.mha_boundary_view.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mha_set_physics_parameter.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        _lib.mha_set_orientation.argtypes = [C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -167,20 +172,23 @@ def row_partition(dim, nodes, lids, nrows, rowptr, caps=None):
 class Block:
     """One element block on one GPU (mha_context)."""
 
-    def __init__(self, dim, order, quadrature=0, workset_size=100, device=0, physics="thermal"):
+    def __init__(self, dim, order=1, quadrature=0, workset_size=100, device=0, physics="thermal", variables=None):
+        """variables: list of (basis type, order) in the module's myvars order; default one HGRAD variable of `order`."""
         lib = load_library()
         d = BlockDesc()
-        d.dimension, d.topology, d.num_vars = dim, (TOPO_QUAD4 if dim == 2 else TOPO_HEX8), 1
-        d.basis_type[0], d.basis_order[0] = 0, order
+        variables = [(BASIS_HGRAD, order)] if variables is None else list(variables)
+        d.dimension, d.topology, d.num_vars = dim, (TOPO_QUAD4 if dim == 2 else TOPO_HEX8), len(variables)
+        for v, (t, o) in enumerate(variables):
+            d.basis_type[v], d.basis_order[v] = int(t), int(o)
         d.quadrature_degree, d.workset_size, d.device = quadrature, workset_size, device
         self._h = C.c_void_p()
         _check(lib.mha_block_create(C.byref(d), C.byref(self._h)))
         self.dim, self.order = dim, order
         self._keep = []
-        if physics == "thermal":
-            _check(lib.mha_physics_select(self._h, PHYSICS_THERMAL))
-        elif physics is not None:
-            raise ValueError(physics)
+        if physics is not None:
+            if physics not in PHYSICS_IDS:
+                raise ValueError(physics)
+            _check(lib.mha_physics_select(self._h, PHYSICS_IDS[physics]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -204,6 +212,10 @@ class Block:
         _check(load_library().mha_set_mesh(self._h, lids.shape[0], vp(nodes), vp(lids), vp(offsets), int(nrows),
                                            vp(fixed)))
         self.nelem, self.n, self.nrows = lids.shape[0], lids.shape[1], int(nrows)
+
+    def set_orientation(self, signs):
+        signs = None if signs is None else _np(signs, np.int8)
+        _check(load_library().mha_set_orientation(self._h, None if signs is None else signs.ctypes.data_as(C.c_void_p)))
 
     def set_graph(self, rowptr=None, colind=None):
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)

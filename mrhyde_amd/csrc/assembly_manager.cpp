@@ -13,15 +13,40 @@ AssemblyManager::AssemblyManager(const mha_block_desc &desc) {
   MHA_REQUIRE((desc.dimension == 2 && desc.topology == MHA_TOPO_QUAD4) ||
                   (desc.dimension == 3 && desc.topology == MHA_TOPO_HEX8),
               MHA_ERR_INVALID, "supported cell topologies: Quadrilateral_4 (2-D), Hexahedron_8 (3-D)");
-  MHA_REQUIRE(desc.num_vars == 1, MHA_ERR_INVALID,
-              "this build assembles single-variable blocks (thermal); got num_vars = " << desc.num_vars);
-  MHA_REQUIRE(desc.basis_type[0] == MHA_BASIS_HGRAD, MHA_ERR_INVALID, "only HGRAD bases are available");
+  MHA_REQUIRE(desc.num_vars >= 1 && desc.num_vars <= MHA_MAX_VARS, MHA_ERR_INVALID,
+              "num_vars must be in [1," << MHA_MAX_VARS << "]; got " << desc.num_vars);
   dim_ = desc.dimension;
-  order_ = desc.basis_order[0];
+  n_ = 0;
+  for (int v = 0; v < desc.num_vars; ++v) {
+    VarInfo vi{desc.basis_type[v], desc.basis_order[v], 0};
+    switch (vi.type) {
+      case MHA_BASIS_HGRAD:
+        MHA_REQUIRE(vi.order >= 1 && vi.order <= 8, MHA_ERR_INVALID, "HGRAD order must be in [1,8]");
+        vi.card = ipow(vi.order + 1, dim_);
+        break;
+      case MHA_BASIS_HVOL:
+        MHA_REQUIRE(vi.order == 0, MHA_ERR_INVALID, "HVOL is available at order 0 (Basis_HVOL_C0_FEM)");
+        vi.card = 1;
+        break;
+      case MHA_BASIS_HDIV:
+        MHA_REQUIRE(vi.order == 1, MHA_ERR_INVALID, "HDIV is available at order 1 (lowest-order In_FEM)");
+        vi.card = 2 * dim_;
+        break;
+      default:
+        MHA_REQUIRE(false, MHA_ERR_INVALID, "unknown basis type " << vi.type << " for variable " << v);
+    }
+    vars_.push_back(vi);
+    n_ += vi.card;
+  }
+  single_hgrad_ = vars_.size() == 1 && vars_[0].type == MHA_BASIS_HGRAD;
+  int max_order = 0;
+  for (const auto &vi : vars_) max_order = std::max(max_order, vi.order);
+  order_ = single_hgrad_ ? vars_[0].order : std::max(1, max_order);
   // default quadrature = 2*max order (reference: discretizationInterface.cpp:166)
-  qdeg_ = desc.quadrature_degree > 0 ? desc.quadrature_degree : 2 * order_;
+  qdeg_ = desc.quadrature_degree > 0 ? desc.quadrature_degree : 2 * std::max(1, max_order);
+  // reference tables of the (first) HGRAD variable + the geometry basis; the other variables' tables are built in
+  // buildVarLayout()
   ref_ = make_ref_tables(dim_, order_, qdeg_);
-  n_ = ref_.nbasis;
   nq_ = ref_.nq;
   nnodes_ = ref_.nnodes;
   workset_size_ = desc.workset_size;
@@ -48,7 +73,8 @@ AssemblyManager::AssemblyManager(const mha_block_desc &desc) {
   wkset_.block = 0;
   wkset_.dimension = dim_;
   wkset_.numip = nq_;
-  wkset_.numVars = 1;
+  wkset_.numVars = static_cast<int>(vars_.size());
+  buildVarLayout();
   wkset_.order = order_;
   wkset_.nq1 = ref_.nq1;
 }
@@ -62,6 +88,8 @@ AssemblyManager::~AssemblyManager() {
 void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lids, const int32_t *offsets,
                               int nrows, const uint8_t *fixed) {
   boundary_groups_.clear();  // entries refer to the previous mesh's element ids
+  has_orient_ = false;
+  d_orient_.resize(0);
   MHA_REQUIRE(nelem > 0 && nrows > 0 && nodes && lids && offsets, MHA_ERR_INVALID, "mha_set_mesh: null or empty input");
   const size_t nl = static_cast<size_t>(nelem) * n_;
   for (size_t k = 0; k < nl; ++k)
@@ -89,6 +117,84 @@ void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lid
   wkset_.maxElem = ws;
 }
 
+// slot tables of the point engine: per distinct (type, order) the reference values [card][nq][nslot] of
+// value / gradient components (HGRAD), value (HVOL), vector components + divergence (HDIV, raw In_FEM functions:
+// dof 2c = (1-x_c)/2 e_c, dof 2c+1 = (1+x_c)/2 e_c)
+void AssemblyManager::buildVarLayout() {
+  VarLayoutDev &L = layout_;
+  L = VarLayoutDev();
+  L.nvars = static_cast<int>(vars_.size());
+  L.nq = nq_;
+  std::vector<double> tables;
+  std::vector<std::pair<std::pair<int, int>, int>> built;  // (type, order) -> offset
+  for (int v = 0; v < L.nvars; ++v) {
+    const VarInfo &vi = vars_[v];
+    L.type[v] = vi.type;
+    L.card[v] = vi.card;
+    L.nslot[v] = vi.type == MHA_BASIS_HVOL ? 1 : 1 + dim_;
+    L.varptr[v + 1] = L.varptr[v] + vi.card;
+    L.slotptr[v + 1] = L.slotptr[v] + L.nslot[v];
+    int off = -1;
+    for (const auto &b : built)
+      if (b.first == std::make_pair(vi.type, vi.order)) off = b.second;
+    if (off < 0) {
+      off = static_cast<int>(tables.size());
+      built.push_back({{vi.type, vi.order}, off});
+      const int ns = L.nslot[v];
+      tables.resize(tables.size() + static_cast<size_t>(vi.card) * nq_ * ns, 0.0);
+      double *T = tables.data() + off;
+      if (vi.type == MHA_BASIS_HGRAD) {
+        const RefTables rt = (vi.order == order_) ? ref_ : make_ref_tables(dim_, vi.order, qdeg_);
+        for (int f = 0; f < vi.card; ++f)
+          for (int q = 0; q < nq_; ++q) {
+            T[(f * nq_ + q) * ns] = rt.basis[f * nq_ + q];
+            for (int d = 0; d < dim_; ++d) T[(f * nq_ + q) * ns + 1 + d] = rt.grad[(f * nq_ + q) * dim_ + d];
+          }
+      } else if (vi.type == MHA_BASIS_HVOL) {
+        for (int q = 0; q < nq_; ++q) T[q] = 1.0;
+      } else {
+        for (int c = 0; c < dim_; ++c)
+          for (int sd = 0; sd < 2; ++sd)
+            for (int q = 0; q < nq_; ++q) {
+              const double x = ref_.ip[q * dim_ + c];
+              double *t = T + ((2 * c + sd) * nq_ + q) * ns;
+              t[c] = sd ? 0.5 * (1.0 + x) : 0.5 * (1.0 - x);
+              t[dim_] = sd ? 0.5 : -0.5;
+            }
+      }
+    }
+    L.table_off[v] = off;
+  }
+  L.n_tot = L.varptr[L.nvars];
+  L.ns_tot = L.slotptr[L.nvars];
+  MHA_REQUIRE(L.ns_tot <= kMaxSlots, MHA_ERR_INVALID, "too many field slots (" << L.ns_tot << ")");
+  L.tables_size = static_cast<int>(tables.size());
+  d_slot_tables_.upload(tables);
+  L.tables = d_slot_tables_.data();
+}
+
+void AssemblyManager::setOrientation(const int8_t *signs) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "mha_set_orientation before mha_set_mesh");
+  has_orient_ = signs != nullptr;
+  if (!signs) { d_orient_.resize(0); return; }
+  const size_t cnt = static_cast<size_t>(nelem_) * n_;
+  for (size_t k = 0; k < cnt; ++k)
+    MHA_REQUIRE(signs[k] == 1 || signs[k] == -1, MHA_ERR_INVALID, "orientation signs must be +1 or -1");
+  d_orient_.upload(signs, cnt);
+}
+
+void AssemblyManager::launchPointEngine(int compute_jacobian, const ElemOut &out, int e_begin, int e_count) {
+  (void)compute_jacobian;
+  wkset_.layout = layout_;
+  wkset_.layout.orient = has_orient_ ? d_orient_.data() : nullptr;
+  wkset_.use_point_engine = true;
+  wkset_.first_elem = e_begin;
+  wkset_.numElem = e_count;
+  wkset_.res = out;
+  physics_->volumeResidual();
+  wkset_.use_point_engine = false;
+}
+
 void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "mha_set_graph before mha_set_mesh");
   if (rowptr && colind) {
@@ -112,6 +218,23 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
 }
 
 void AssemblyManager::selectPhysics(int physics_id) {
+  // the module's myvars / mybasistypes must be what the block was created with (physicsInterface.cpp:537-610)
+  auto expect = [&](std::initializer_list<int> types) {
+    bool ok = types.size() == vars_.size();
+    size_t k = 0;
+    for (int t : types) { if (ok && vars_[k].type != t) ok = false; ++k; }
+    return ok;
+  };
+  if (physics_id == MHA_PHYSICS_THERMAL)
+    MHA_REQUIRE(expect({MHA_BASIS_HGRAD}), MHA_ERR_INVALID, "thermal needs one HGRAD variable (e)");
+  else if (physics_id == MHA_PHYSICS_POROUS_MIXED)
+    MHA_REQUIRE(expect({MHA_BASIS_HVOL, MHA_BASIS_HDIV}), MHA_ERR_INVALID,
+                "porousMixed needs the variables p (HVOL) and u (HDIV), in that order");
+  else if (physics_id == MHA_PHYSICS_NAVIERSTOKES)
+    MHA_REQUIRE(dim_ == 2 ? expect({MHA_BASIS_HGRAD, MHA_BASIS_HGRAD, MHA_BASIS_HGRAD})
+                          : expect({MHA_BASIS_HGRAD, MHA_BASIS_HGRAD, MHA_BASIS_HGRAD, MHA_BASIS_HGRAD}),
+                MHA_ERR_INVALID, "navierstokes needs the HGRAD variables ux, pr, uy[, uz], in that order");
+  physics_id_ = physics_id;
   physics_ = import_physics(physics_id);
   physics_->defineFunctions(functions_);
   physics_->setWorkset(&wkset_);
@@ -146,6 +269,7 @@ void AssemblyManager::setTimeIntegration(int transient, int nsteps, int nstages,
     t.stage = stage;
     t.alpha_u = A[stage * nstages + stage] / b[stage];
     t.timewt = 1.0 / dt / b[stage];
+    t.dt = dt;
     t.alpha_t = bdf[0] * t.timewt;
     for (int s = 0; s < stage; ++s) t.stage_ratio[s] = A[stage * nstages + s] / b[s];
     for (int s = 0; s <= nsteps; ++s) t.bdf[s] = bdf[s];
@@ -248,6 +372,12 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
   MHA_REQUIRE(res != nullptr, MHA_ERR_INVALID, "residual vector is null");
   MHA_REQUIRE(!compute_jacobian || crs_vals, MHA_ERR_INVALID, "compute_jacobian set but crs_vals is null");
   bindState(u, u_prev, u_stage);
+  if (physics_id_ != MHA_PHYSICS_THERMAL) {
+    // multi-variable modules run on the point engine
+    if (path == MHA_PATH_AUTO || path == MHA_PATH_ELEMENT_ATOMIC) path = MHA_PATH_POINT_ENGINE;
+    MHA_REQUIRE(path == MHA_PATH_POINT_ENGINE || path == MHA_PATH_LOCAL_THEN_SCATTER, MHA_ERR_INVALID,
+                "assembly path " << path << " is not available for this physics module");
+  }
   if (path == MHA_PATH_AUTO) {
     if (!ro_.ready && thermal_row_owner_supported(dim_, order_, ref_.nq1)) prepareRowOwner();
     path = rowOwnerUsable(nullptr) ? MHA_PATH_ROW_OWNER : MHA_PATH_ELEMENT_ATOMIC;
@@ -280,6 +410,14 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
       physics_->volumeResidual();
       break;
     }
+    case MHA_PATH_POINT_ENGINE: {
+      ElemOut o;
+      o.compute_jacobian = compute_jacobian ? 1 : 0;
+      o.res = res;
+      o.crs_vals = compute_jacobian ? crs_vals : nullptr;
+      launchPointEngine(compute_jacobian, o, 0, nelem_);
+      break;
+    }
     case MHA_PATH_LOCAL_THEN_SCATTER: {
       // the reference's two-step path, workset by workset (assemblyManager.cpp:2442-2509)
       const int ws = wkset_.maxElem;
@@ -298,7 +436,8 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         wkset_.res.local_J = d_local_J_.data();
         wkset_.res.local_res = d_local_res_.data();
         wkset_.use_general = false;  // this path keeps the baseline element kernel: an independent implementation
-        physics_->volumeResidual();
+        if (physics_id_ != MHA_PHYSICS_THERMAL) launchPointEngine(compute_jacobian, wkset_.res, e0, ne);
+        else physics_->volumeResidual();
         BlockDev b = blockDev();
         b.e_begin = e0;
         b.e_count = ne;
@@ -327,9 +466,13 @@ void AssemblyManager::computeLocalJacRes(int compute_jacobian, const double *u, 
   wkset_.res.compute_jacobian = compute_jacobian ? 1 : 0;
   wkset_.res.local_J = compute_jacobian ? local_J : nullptr;
   wkset_.res.local_res = local_res;
-  useGeneralKernel(false);
   timedBegin();
-  physics_->volumeResidual();
+  if (physics_id_ != MHA_PHYSICS_THERMAL) {
+    launchPointEngine(compute_jacobian, wkset_.res, 0, nelem_);
+  } else {
+    useGeneralKernel(false);
+    physics_->volumeResidual();
+  }
   timedEnd();
 }
 

@@ -25,6 +25,7 @@ class AssemblyManager {
   void setStream(hipStream_t s) { stream_ = s; wkset_.stream = s; }
   void setMesh(int nelem, const double *nodes, const int32_t *lids, const int32_t *offsets, int nrows,
                const uint8_t *fixed);
+  void setOrientation(const int8_t *signs);
   void setGraph(const int32_t *rowptr, const int32_t *colind);
   void selectPhysics(int physics_id);
   void setFunction(const std::string &name, int kind, double amp, const double *freq3, const double *ip_dev);
@@ -72,7 +73,18 @@ class AssemblyManager {
   void timedBegin();
   void timedEnd();
 
-  int dim_ = 0, order_ = 0, qdeg_ = 0, n_ = 0, nq_ = 0, nnodes_ = 0;
+  int dim_ = 0, order_ = 0, qdeg_ = 0, n_ = 0, nq_ = 0, nnodes_ = 0;  // n_ = dofs per element over all variables
+  // variables of the block (GroupMetaData::basis_types / basis orders; wkset->usebasis) and the point engine's tables
+  struct VarInfo { int type, order, card; };
+  std::vector<VarInfo> vars_;
+  bool single_hgrad_ = true;  // the thermal kernels of thermal_*.hip need one HGRAD variable
+  int physics_id_ = 0;
+  VarLayoutDev layout_;
+  DeviceBuffer<double> d_slot_tables_;
+  DeviceBuffer<int8_t> d_orient_;
+  bool has_orient_ = false;
+  void buildVarLayout();
+  void launchPointEngine(int compute_jacobian, const ElemOut &out, int e_begin, int e_count);
   int nelem_ = 0, nrows_ = 0, workset_size_ = 0;
   bool has_mesh_ = false, has_graph_ = false;
   int last_path_ = 0;

@@ -72,6 +72,10 @@ int mha_set_mesh(mha_context *ctx, int num_elems, const double *nodes, const int
   return guarded([&] { mgr(ctx).setMesh(num_elems, nodes, lids, offsets, num_rows, is_fixed); });
 }
 
+int mha_set_orientation(mha_context *ctx, const int8_t *signs_host) {
+  return guarded([&] { mgr(ctx).setOrientation(signs_host); });
+}
+
 int mha_set_graph(mha_context *ctx, const int32_t *rowptr, const int32_t *colind) {
   return guarded([&] { mgr(ctx).setGraph(rowptr, colind); });
 }

@@ -40,7 +40,7 @@ struct BlockDev {
 // (reference: src/tools/workset.cpp:589-623).
 struct TimeDev {
   int transient = 0, nsteps = 0, nstages = 0, stage = 0;
-  double alpha_u = 1.0, alpha_t = 0.0, timewt = 0.0;
+  double alpha_u = 1.0, alpha_t = 0.0, timewt = 0.0, dt = 1.0;
   double stage_ratio[kMaxStages] = {0};  // A(stage,s)/b(s), s < stage
   double bdf[kMaxSteps + 1] = {0};
   const double *u = nullptr;        // [nrows] current (stage) solution
@@ -118,6 +118,28 @@ struct BoundaryViewsDev {
   double *xyz[3] = {nullptr, nullptr, nullptr};   // [num][nqs]
   double *nrm[3] = {nullptr, nullptr, nullptr};   // [num][nqs] unit outward normals
   double *basis = nullptr, *basis_grad = nullptr; // [num][n][nqs], [num][n][nqs][dim]
+};
+
+// ---- multi-variable blocks (kernels/point_engine.hip) -------------------------------------------------------------
+constexpr int kMaxVars = 8, kMaxSlots = 24, kMaxFuncs = 8;
+
+// Variables of a block and their "slots": the quantities of a basis function that enter a weak form --
+// HGRAD: value, d/dx, d/dy(, d/dz); HVOL: value; HDIV: the vector components, then the divergence.
+struct VarLayoutDev {
+  int nvars = 0, n_tot = 0, ns_tot = 0, nq = 0;
+  int type[kMaxVars] = {0}, card[kMaxVars] = {0}, nslot[kMaxVars] = {0};
+  int varptr[kMaxVars + 1] = {0}, slotptr[kMaxVars + 1] = {0};
+  int table_off[kMaxVars] = {0};        // offset (doubles) of the variable's slot table inside `tables`
+  int tables_size = 0;                  // doubles; variables with the same (type, order) share one table
+  const double *tables = nullptr;       // per distinct basis: [card][nq][nslot] reference slot values
+  const int8_t *orient = nullptr;       // [E][n_tot] basis signs (modifyBasisByOrientation, lowest order) or null
+};
+
+// What a physics module's point function reads besides the fields: its named functions and scalar settings.
+struct PhysParamsDev {
+  int physics = 0;
+  FuncDesc f[kMaxFuncs];
+  double p[8] = {0};
 };
 
 // Destination of the row-owner kernels.

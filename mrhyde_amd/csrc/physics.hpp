@@ -73,6 +73,27 @@ class thermal : public PhysicsBase {
   double formparam = 1.0;  // settings "form_param" (reference: thermal.cpp:35)
 };
 
+// porousMixed: mixed Darcy, (K mobility)^-1 u + grad p = 0, div u = source
+// (reference: src/physics/porousMixed.hpp, src/physics/porousMixed.cpp:24-432); myvars {p (HVOL), u (HDIV)}
+class porousMixed : public PhysicsBase {
+ public:
+  porousMixed();
+  void defineFunctions(FunctionManager &fm) override;
+  void volumeResidual() override;
+};
+
+// navierstokes: incompressible Navier-Stokes with optional SUPG / PSPG
+// (reference: src/physics/navierstokes.hpp, src/physics/navierstokes.cpp:20-849, 1054-1079); myvars {ux, pr, uy[, uz]}
+class navierstokes : public PhysicsBase {
+ public:
+  navierstokes();
+  void defineFunctions(FunctionManager &fm) override;
+  void volumeResidual() override;
+  void setParameter(const std::string &name, double value) override;
+  bool useSUPG = false, usePSPG = false;  // navierstokes.cpp:45-46
+  bool fix_uz_offsets = false;            // false reproduces navierstokes.cpp:688
+};
+
 // PhysicsImporter::import equivalent (reference: src/physics/physicsImporter.cpp:48-204)
 std::unique_ptr<PhysicsBase> import_physics(int physics_id);
 

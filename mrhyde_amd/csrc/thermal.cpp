@@ -42,7 +42,15 @@ void thermal::volumeResidual() {
   BlockDev b = w.dev;
   b.e_begin = w.first_elem;
   b.e_count = w.numElem;
-  if (w.use_general)
+  if (w.use_point_engine) {
+    PhysParamsDev pp;
+    pp.physics = MHA_PHYSICS_THERMAL;
+    pp.f[0] = functionManager->evaluate("thermal source");
+    pp.f[1] = functionManager->evaluate("thermal diffusion");
+    pp.f[2] = functionManager->evaluate("specific heat");
+    pp.f[3] = functionManager->evaluate("density");
+    launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.stream);
+  } else if (w.use_general)
     launch_thermal_general(w.dimension, w.order, w.nq1, b, device_params(), w.tables, w.elem_slot, w.elem_slot_bytes,
                            w.res, w.stream);
   else
@@ -71,8 +79,81 @@ void thermal::boundaryResidual() {
   launch_thermal_boundary(w.dev, w.side_tables, bd, w.time_dev, w.res, w.stream);
 }
 
+// ---- porousMixed -------------------------------------------------------------------------------------------------
+porousMixed::porousMixed() {
+  label = "porousMixed";
+  myvars = {"p", "u"};               // reference: porousMixed.cpp:33-43
+  mybasistypes = {"HVOL", "HDIV"};
+}
+
+// reference: porousMixed::defineFunctions (porousMixed.cpp:134-152): source 0, Kinv_* 1, total_mobility 1
+void porousMixed::defineFunctions(FunctionManager &fm) {
+  functionManager = &fm;
+  auto constant = [](double v) { FuncDesc f; f.kind = MHA_FUNC_CONSTANT; f.amp = v; return f; };
+  if (!fm.has("source")) fm.addFunction("source", constant(0.0));
+  for (const char *k : {"Kinv_xx", "Kinv_yy", "Kinv_zz", "total_mobility"})
+    if (!fm.has(k)) fm.addFunction(k, constant(1.0));
+}
+
+// reference: porousMixed::volumeResidual (porousMixed.cpp:158-338) as the point function porous_point
+void porousMixed::volumeResidual() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "porousMixed::volumeResidual called without a workset");
+  Workset &w = *wkset;
+  BlockDev b = w.dev;
+  b.e_begin = w.first_elem;
+  b.e_count = w.numElem;
+  PhysParamsDev pp;
+  pp.physics = MHA_PHYSICS_POROUS_MIXED;
+  const char *names[5] = {"source", "Kinv_xx", "Kinv_yy", "Kinv_zz", "total_mobility"};
+  for (int k = 0; k < 5; ++k) pp.f[k] = functionManager->evaluate(names[k]);
+  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.stream);
+}
+
+// ---- navierstokes ------------------------------------------------------------------------------------------------
+navierstokes::navierstokes() {
+  label = "navierstokes";
+  myvars = {"ux", "pr", "uy", "uz"};  // reference: navierstokes.cpp:27-34 (uz only in 3-D)
+  mybasistypes = {"HGRAD", "HGRAD", "HGRAD", "HGRAD"};
+}
+
+// reference: navierstokes::defineFunctions (navierstokes.cpp:62-76): sources 0, density 1, viscosity 1
+void navierstokes::defineFunctions(FunctionManager &fm) {
+  functionManager = &fm;
+  auto constant = [](double v) { FuncDesc f; f.kind = MHA_FUNC_CONSTANT; f.amp = v; return f; };
+  for (const char *k : {"source ux", "source pr", "source uy", "source uz"})
+    if (!fm.has(k)) fm.addFunction(k, constant(0.0));
+  for (const char *k : {"density", "viscosity"})
+    if (!fm.has(k)) fm.addFunction(k, constant(1.0));
+}
+
+void navierstokes::setParameter(const std::string &name, double value) {
+  if (name == "useSUPG") useSUPG = value != 0.0;
+  else if (name == "usePSPG") usePSPG = value != 0.0;
+  else if (name == "fix_uz_offsets") fix_uz_offsets = value != 0.0;
+  else PhysicsBase::setParameter(name, value);
+}
+
+// reference: navierstokes::volumeResidual (navierstokes.cpp:82-849) as the point function navierstokes_point
+void navierstokes::volumeResidual() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "navierstokes::volumeResidual called without a workset");
+  Workset &w = *wkset;
+  BlockDev b = w.dev;
+  b.e_begin = w.first_elem;
+  b.e_count = w.numElem;
+  PhysParamsDev pp;
+  pp.physics = MHA_PHYSICS_NAVIERSTOKES;
+  const char *names[6] = {"source ux", "source pr", "source uy", "source uz", "density", "viscosity"};
+  for (int k = 0; k < 6; ++k) pp.f[k] = functionManager->evaluate(names[k]);
+  pp.p[0] = useSUPG ? 1.0 : 0.0;
+  pp.p[1] = usePSPG ? 1.0 : 0.0;
+  pp.p[2] = fix_uz_offsets ? 1.0 : 0.0;
+  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.stream);
+}
+
 std::unique_ptr<PhysicsBase> import_physics(int physics_id) {
   if (physics_id == MHA_PHYSICS_THERMAL) return std::unique_ptr<PhysicsBase>(new thermal());
+  if (physics_id == MHA_PHYSICS_POROUS_MIXED) return std::unique_ptr<PhysicsBase>(new porousMixed());
+  if (physics_id == MHA_PHYSICS_NAVIERSTOKES) return std::unique_ptr<PhysicsBase>(new navierstokes());
   throw Error(MHA_ERR_INVALID, "unknown physics module id " + std::to_string(physics_id));
 }
 

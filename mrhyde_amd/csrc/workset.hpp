@@ -50,6 +50,9 @@ class Workset {
   const void *elem_slot = nullptr;
   int elem_slot_bytes = 1;
   bool use_general = false;
+  // multi-variable point engine (kernels/point_engine.hip): variable/slot layout, orientation signs
+  VarLayoutDev layout;
+  bool use_point_engine = false;
   hipStream_t stream = nullptr;
   int order = 0, nq1 = 0;
 
