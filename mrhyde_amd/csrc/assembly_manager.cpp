@@ -518,6 +518,7 @@ void AssemblyManager::worksetUpdate(int index) {
 void AssemblyManager::prepareSideTables() {
   if (has_side_tables_) return;
   side_ref_ = make_side_tables(ref_);
+  d_side_ip_.upload(side_ref_.ip);
   d_side_wts_.upload(side_ref_.wts);
   d_side_tanU_.upload(side_ref_.tanU);
   d_side_tanV_.upload(side_ref_.tanV);
@@ -532,6 +533,7 @@ SideTablesDev AssemblyManager::sideTablesDev() const {
   SideTablesDev t;
   t.nsides = side_ref_.nsides;
   t.nqs = side_ref_.nqs;
+  t.ip = d_side_ip_.data();
   t.wts = d_side_wts_.data();
   t.tanU = d_side_tanU_.data();
   t.tanV = d_side_tanV_.data();
@@ -597,6 +599,8 @@ void AssemblyManager::assembleBoundary(int flags, const double *u, const double 
     wkset_.current_bc = g->bc_type;
     wkset_.bnd = boundaryDev(*g);
     wkset_.side_tables = sideTablesDev();
+    wkset_.layout = layout_;
+    wkset_.layout.orient = has_orient_ ? d_orient_.data() : nullptr;
     wkset_.res = ElemOut();
     wkset_.res.compute_jacobian = compute_jacobian;
     wkset_.res.res = res;
@@ -614,8 +618,11 @@ void AssemblyManager::boundaryUpdate(int group) {
   const size_t nqs = side_ref_.nqs, num = g.num;
   g.wts.resize(num * nqs);
   for (int d = 0; d < dim_; ++d) { g.xyz[d].resize(num * nqs); g.nrm[d].resize(num * nqs); }
-  g.basis.resize(num * n_ * nqs);
-  g.basis_grad.resize(num * n_ * nqs * dim_);
+  // basis views are those of the block's single HGRAD variable; multi-variable blocks expose the geometry views only
+  if (single_hgrad_) {
+    g.basis.resize(num * n_ * nqs);
+    g.basis_grad.resize(num * n_ * nqs * dim_);
+  }
   BoundaryViewsDev v;
   v.wts = g.wts.data();
   for (int d = 0; d < dim_; ++d) { v.xyz[d] = g.xyz[d].data(); v.nrm[d] = g.nrm[d].data(); }
@@ -642,6 +649,8 @@ View AssemblyManager::boundaryView(int group, const std::string &name) const {
     v.ptr = g.xyz[comp(name[0])].data(); v.rank = 2; v.extent[0] = num; v.extent[1] = nqs;
   } else if (name == "n[x]" || name == "n[y]" || name == "n[z]") {
     v.ptr = g.nrm[comp(name[2])].data(); v.rank = 2; v.extent[0] = num; v.extent[1] = nqs;
+  } else if ((name == "basis side" || name == "basis_grad side") && !single_hgrad_) {
+    throw Error(MHA_ERR_UNKNOWN_FIELD, "'" + name + "' is available for single-variable HGRAD blocks");
   } else if (name == "basis side") {
     v.ptr = g.basis.data(); v.rank = 4; v.extent[0] = num; v.extent[1] = n_; v.extent[2] = nqs; v.extent[3] = 1;
   } else if (name == "basis_grad side") {

@@ -134,7 +134,7 @@ class AssemblyManager {
   };
   std::vector<std::unique_ptr<BoundaryGroupData>> boundary_groups_;
   SideTables side_ref_;
-  DeviceBuffer<double> d_side_wts_, d_side_tanU_, d_side_tanV_, d_side_basis_, d_side_grad_, d_side_nodeval_,
+  DeviceBuffer<double> d_side_ip_, d_side_wts_, d_side_tanU_, d_side_tanV_, d_side_basis_, d_side_grad_, d_side_nodeval_,
       d_side_nodegrad_;
   bool has_side_tables_ = false;
   void prepareSideTables();

@@ -98,6 +98,7 @@ struct AffineDev {
 struct SideTablesDev {
   int nsides = 0, nqs = 0;
   const double *wts = nullptr, *tanU = nullptr, *tanV = nullptr;
+  const double *ip = nullptr;  // [ns][nqs][dim] side points in cell reference coordinates
   const double *basis = nullptr, *grad = nullptr, *nodeval = nullptr, *nodegrad = nullptr;
 };
 

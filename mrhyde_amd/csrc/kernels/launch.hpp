@@ -55,6 +55,10 @@ void launch_boundary_views(const BlockDev &b, const SideTablesDev &st, const Bou
 void launch_thermal_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const TimeDev &tm,
                              const ElemOut &out, hipStream_t stream);
 
+// porous_boundary.hip: porousMixed::boundaryResidual (weak Dirichlet on p)
+void launch_porous_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const VarLayoutDev &vl,
+                            const ElemOut &out, hipStream_t stream);
+
 // point_engine.hip: multi-variable blocks, any physics module stated as a point function
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
                          const ElemOut &out, hipStream_t stream);

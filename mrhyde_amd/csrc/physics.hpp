@@ -80,6 +80,7 @@ class porousMixed : public PhysicsBase {
   porousMixed();
   void defineFunctions(FunctionManager &fm) override;
   void volumeResidual() override;
+  void boundaryResidual() override;
 };
 
 // navierstokes: incompressible Navier-Stokes with optional SUPG / PSPG

@@ -109,6 +109,18 @@ void porousMixed::volumeResidual() {
   launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.stream);
 }
 
+// reference: porousMixed::boundaryResidual (porousMixed.cpp:345-432): bcs(pnum, side) == "Dirichlet" adds
+// "Dirichlet p <side>" * wts * (v . n) to the u rows
+void porousMixed::boundaryResidual() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "porousMixed::boundaryResidual called without a workset");
+  Workset &w = *wkset;
+  if (w.current_bc != MHA_BC_WEAK_DIRICHLET) return;  // other types contribute nothing (porousMixed.cpp:400, 420)
+  BoundaryDev bd = w.bnd;
+  bd.bc_type = w.current_bc;
+  bd.data = functionManager->evaluate("Dirichlet p " + w.sidename);
+  launch_porous_boundary(w.dev, w.side_tables, bd, w.layout, w.res, w.stream);
+}
+
 // ---- navierstokes ------------------------------------------------------------------------------------------------
 navierstokes::navierstokes() {
   label = "navierstokes";

@@ -1,0 +1,47 @@
+"""Timing of the multi-variable point engine at the sizes of BASELINE.json configs 2-4 (not a bench.py line: those
+configs are parity cases; this script records where the first implementation stands).  Usage:
+  python profiles/engine_bench.py [thermal|porous|ns] [ncell]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "tests")
+import mrhyde_amd  # noqa: E402
+import oracle_lib as orc  # noqa: E402  (mesh generator only: test infrastructure building the input)
+
+
+def run(kind, nc):
+    dim = 3
+    if kind == "thermal":
+        types, orders, phys, qdeg, B = [orc.HGRAD], [2], "thermal", 4, 6564
+    elif kind == "porous":
+        types, orders, phys, qdeg, B = [orc.HVOL, orc.HDIV], [0, 1], "porousMixed", 2, 724
+    else:
+        types, orders, phys, qdeg, B = [orc.HGRAD] * 4, [2, 1, 2, 2], "navierstokes", 4, 65340
+    t0 = time.time()
+    m = orc.mesh_multi(dim, (nc,) * 3, types, orders)
+    blk = mrhyde_amd.Block(dim, quadrature=qdeg, physics=phys, variables=list(zip(types, orders)))
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+    blk.set_orientation(m["orient"])
+    blk.set_graph()
+    rowptr, colind = blk.get_graph()
+    print("setup %.1fs  elements %d  dofs %d  nnz %d" % (time.time() - t0, m["nelem"], m["ndof"], len(colind)), flush=True)
+    rng = np.random.default_rng(5)
+    u = torch.tensor(rng.uniform(-1, 1, m["ndof"]), device="cuda")
+    res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(colind), dtype=torch.float64, device="cuda")
+    if kind == "ns":
+        blk.set_function("viscosity", 1.0)
+    blk.set_timing(True)
+    for it in range(3):
+        blk.assemble_jacres(u, res, vals, overwrite=True, path=mrhyde_amd.PATH_POINT_ENGINE)
+        torch.cuda.synchronize()
+        ms = blk.last_kernel_ms()
+        print("%s %d^3: %.3f ms  %.3e elements/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" %
+              (kind, nc, ms, m["nelem"] / ms * 1e3, m["nelem"] * B / ms / 1e6, m["nelem"] * B / ms / 1e6 / 80.0), flush=True)
+
+
+if __name__ == "__main__":
+    run(sys.argv[1] if len(sys.argv) > 1 else "porous", int(sys.argv[2]) if len(sys.argv) > 2 else 32)

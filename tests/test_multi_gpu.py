@@ -206,3 +206,73 @@ def test_navierstokes_channel_gold_end_to_end(oracle):
     g = gold_errors("navierstokes_channel.gold")
     for k in ("ux", "pr", "uy"):
         assert fmt(errs[k]) == fmt(g[k]), (k, errs[k], g[k])
+
+
+@pytest.mark.parametrize("dim,ncell", [(2, (5, 4)), (3, (3, 2, 3))])
+def test_porous_boundary_matches_oracle(oracle, dim, ncell):
+    """porousMixed::boundaryResidual (weak Dirichlet p) on curved sides, closed-form and per-ip data."""
+    torch = _torch()
+    import mrhyde_amd
+    rng = np.random.default_rng(34)
+    m = warp(oracle.mesh_multi(dim, ncell, [oracle.HVOL, oracle.HDIV], [0, 1]))
+    u = rng.uniform(-1, 1, m["ndof"])
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    nqs = oracle.side_sizes(dim, 2)[1]
+    names = ["left", "right", "bottom", "top"] + (["back", "front"] if dim == 3 else [])
+    blk = make_block(m, "porousMixed", 2, graph=(rowptr, colind))
+    res_ref, vals_ref = np.zeros(m["ndof"]), np.zeros(rowptr[-1])
+    keep = []
+    for i, name in enumerate(names):
+        be, bs = oracle.boundary_sides(dim, ncell, name)
+        data = ("array", rng.uniform(-2, 2, (len(be), nqs))) if i % 2 else ("sinprod", 1.7, [1.0, 2.0, 0.5][:dim])
+        oracle.assemble_block_boundary(m, oracle.PHYS_POROUS_MIXED, 2, u, be, bs, 1, data, rowptr=rowptr, colind=colind,
+                                       crs_vals=vals_ref, res=res_ref)
+        blk.add_boundary_group(name, mrhyde_amd.BC_WEAK_DIRICHLET, be, bs)
+        if data[0] == "array":
+            t = torch.tensor(data[1], device="cuda")
+            keep.append(t)
+            blk.set_function("Dirichlet p " + name, t)
+        else:
+            blk.set_function("Dirichlet p " + name, data)
+    res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(colind), dtype=torch.float64, device="cuda")
+    blk.assemble_boundary(torch.tensor(u, device="cuda"), res, vals)
+    torch.cuda.synchronize()
+    assert np.abs(res_ref).max() > 0 and np.all(vals_ref == 0.0)
+    assert rel_err(res.cpu().numpy(), res_ref) < RTOL
+    assert np.all(vals.cpu().numpy() == 0.0)
+
+
+def test_porous_mixed_2d_gold_end_to_end(oracle):
+    """regression/porous/Mixed: p = 1 on all four sides through the boundary-group path, GPU assembly."""
+    torch = _torch()
+    import mrhyde_amd
+    import scipy.sparse.linalg as spla
+    from test_oracle_multi import fmt, gold_errors
+    dim, ncell, qdeg = 2, (8, 8), 2
+    m = oracle.mesh_multi(dim, ncell, [oracle.HVOL, oracle.HDIV], [0, 1])
+    blk = make_block(m, "porousMixed", qdeg)
+    blk.set_function("source", ("sinprod", 8 * np.pi ** 2, [2 * np.pi] * 2))
+    for name in ("left", "right", "bottom", "top"):
+        be, bs = oracle.boundary_sides(dim, ncell, name)
+        blk.add_boundary_group(name, mrhyde_amd.BC_WEAK_DIRICHLET, be, bs)
+        blk.set_function("Dirichlet p " + name, 1.0)
+    rowptr, colind = blk.get_graph()
+    ud = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    res = torch.empty(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.empty(len(colind), dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(ud, res, vals, overwrite=True)
+    blk.assemble_boundary(ud, res, vals)
+    torch.cuda.synchronize()
+    J = sp.csr_matrix((vals.cpu().numpy(), colind, rowptr), shape=(m["ndof"],) * 2)
+    u = spla.spsolve(J.tocsc(), res.cpu().numpy())
+    pb = oracle.physical_basis_var(dim, oracle.HVOL, 0, qdeg, m["nodes"])
+    ub = oracle.physical_basis_var(dim, oracle.HDIV, 1, qdeg, m["nodes"], m["orient"][:, m["varptr"][1]:])
+    x, w = pb["ip"], pb["wts"]
+    s, c = np.sin(2 * np.pi * x), np.cos(2 * np.pi * x)
+    ep = np.sqrt(np.sum((u[m["lids"][:, m["offsets"][0]]][:, None] - 1.0 - np.prod(s, axis=-1)) ** 2 * w))
+    uh = np.einsum("ef,efqd->eqd", u[m["lids"][:, m["offsets"][m["varptr"][1]:]]], ub["basis"])
+    eu = np.sum((uh[..., 0] + 2 * np.pi * c[..., 0] * s[..., 1]) ** 2 * w) + \
+        np.sum((uh[..., 1] + 2 * np.pi * s[..., 0] * c[..., 1]) ** 2 * w)
+    g = gold_errors("porous_Mixed.gold")
+    assert fmt(ep) == fmt(g["p"]) and fmt(np.sqrt(eu)) == fmt(g["u"])
