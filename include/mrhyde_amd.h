@@ -148,6 +148,10 @@ int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int
 #define MHA_PATH_POINT_ENGINE 4   /* multi-variable kernel: point-level forward AD + B^T C B
                                      contraction, atomic scatter; the path of porousMixed and
                                      navierstokes, available to thermal as a cross-check    */
+#define MHA_PATH_ROW_GATHER 5     /* element kernel -> dense element matrices (device scratch,
+                                     E*n*n doubles) -> every CRS row summed by one wavefront from
+                                     its incident elements: no global atomics; AUTO for
+                                     porousMixed / navierstokes                                */
 int mha_assemble_jacres(mha_context *ctx, int flags, int path, const double *u_dev,
                         const double *u_prev_dev, const double *u_stage_dev, double *res_dev,
                         double *crs_vals_dev);

@@ -28,6 +28,7 @@ EXPORTS = [
 BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
 PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3}
 PATH_POINT_ENGINE = 4
+PATH_ROW_GATHER = 5
 BC_NEUMANN, BC_WEAK_DIRICHLET = 1, 2
 
 

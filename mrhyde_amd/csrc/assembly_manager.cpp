@@ -117,7 +117,7 @@ void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lid
   wkset_.maxElem = ws;
 }
 
-// slot tables of the point engine: per distinct (type, order) the reference values [card][nq][nslot] of
+// slot tables of the point engine: per distinct (type, order) the reference values [nq][nslot][card padded to 4] of
 // value / gradient components (HGRAD), value (HVOL), vector components + divergence (HDIV, raw In_FEM functions:
 // dof 2c = (1-x_c)/2 e_c, dof 2c+1 = (1+x_c)/2 e_c)
 void AssemblyManager::buildVarLayout() {
@@ -132,6 +132,7 @@ void AssemblyManager::buildVarLayout() {
     L.type[v] = vi.type;
     L.card[v] = vi.card;
     L.nslot[v] = vi.type == MHA_BASIS_HVOL ? 1 : 1 + dim_;
+    L.cardpad[v] = (vi.card + 3) & ~3;
     L.varptr[v + 1] = L.varptr[v] + vi.card;
     L.slotptr[v + 1] = L.slotptr[v] + L.nslot[v];
     int off = -1;
@@ -140,26 +141,25 @@ void AssemblyManager::buildVarLayout() {
     if (off < 0) {
       off = static_cast<int>(tables.size());
       built.push_back({{vi.type, vi.order}, off});
-      const int ns = L.nslot[v];
-      tables.resize(tables.size() + static_cast<size_t>(vi.card) * nq_ * ns, 0.0);
-      double *T = tables.data() + off;
+      const int ns = L.nslot[v], cp = L.cardpad[v];
+      tables.resize(tables.size() + static_cast<size_t>(nq_) * ns * cp, 0.0);
+      double *T = tables.data() + off;  // [q][slot][dof], rows padded with zeros
       if (vi.type == MHA_BASIS_HGRAD) {
         const RefTables rt = (vi.order == order_) ? ref_ : make_ref_tables(dim_, vi.order, qdeg_);
         for (int f = 0; f < vi.card; ++f)
           for (int q = 0; q < nq_; ++q) {
-            T[(f * nq_ + q) * ns] = rt.basis[f * nq_ + q];
-            for (int d = 0; d < dim_; ++d) T[(f * nq_ + q) * ns + 1 + d] = rt.grad[(f * nq_ + q) * dim_ + d];
+            T[(q * ns) * cp + f] = rt.basis[f * nq_ + q];
+            for (int d = 0; d < dim_; ++d) T[(q * ns + 1 + d) * cp + f] = rt.grad[(f * nq_ + q) * dim_ + d];
           }
       } else if (vi.type == MHA_BASIS_HVOL) {
-        for (int q = 0; q < nq_; ++q) T[q] = 1.0;
+        for (int q = 0; q < nq_; ++q) T[q * cp] = 1.0;
       } else {
         for (int c = 0; c < dim_; ++c)
           for (int sd = 0; sd < 2; ++sd)
             for (int q = 0; q < nq_; ++q) {
               const double x = ref_.ip[q * dim_ + c];
-              double *t = T + ((2 * c + sd) * nq_ + q) * ns;
-              t[c] = sd ? 0.5 * (1.0 + x) : 0.5 * (1.0 - x);
-              t[dim_] = sd ? 0.5 : -0.5;
+              T[(q * ns + c) * cp + 2 * c + sd] = sd ? 0.5 * (1.0 + x) : 0.5 * (1.0 - x);
+              T[(q * ns + dim_) * cp + 2 * c + sd] = sd ? 0.5 : -0.5;
             }
       }
     }
@@ -183,8 +183,31 @@ void AssemblyManager::setOrientation(const int8_t *signs) {
   d_orient_.upload(signs, cnt);
 }
 
+void AssemblyManager::prepareRowGather(bool need_jacobian) {
+  if (!has_incidence_) {
+    std::vector<int32_t> ptr, elem, lpos;
+    build_row_incidence(nrows_, nelem_, n_, h_lids_.data(), ptr, elem, lpos);
+    d_inc_ptr_.upload(ptr);
+    d_inc_elem_.upload(elem);
+    d_inc_pos_.upload(lpos);
+    max_row_ = 0;
+    for (int r = 0; r < nrows_; ++r) max_row_ = std::max(max_row_, h_rowptr_[r + 1] - h_rowptr_[r]);
+    has_incidence_ = true;
+  }
+  prepareElemSlots();
+  if (need_jacobian) d_gather_J_.resize(static_cast<size_t>(nelem_) * n_ * n_);
+  d_gather_res_.resize(static_cast<size_t>(nelem_) * n_);
+}
+
 void AssemblyManager::launchPointEngine(int compute_jacobian, const ElemOut &out, int e_begin, int e_count) {
-  (void)compute_jacobian;
+  // CRS scatter through the element-major slot map (built once per graph) instead of a column search per entry
+  if (compute_jacobian && out.crs_vals) {
+    prepareElemSlots();
+    wkset_.elem_slot = d_elem_slot_.data();
+    wkset_.elem_slot_bytes = elem_slot_bytes_;
+  } else {
+    wkset_.elem_slot = nullptr;
+  }
   wkset_.layout = layout_;
   wkset_.layout.orient = has_orient_ ? d_orient_.data() : nullptr;
   wkset_.use_point_engine = true;
@@ -215,6 +238,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   has_graph_ = true;
   ro_ = RowOwnerData();
   has_elem_slot_ = false;
+  has_incidence_ = false;
 }
 
 void AssemblyManager::selectPhysics(int physics_id) {
@@ -374,8 +398,10 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
   bindState(u, u_prev, u_stage);
   if (physics_id_ != MHA_PHYSICS_THERMAL) {
     // multi-variable modules run on the point engine
-    if (path == MHA_PATH_AUTO || path == MHA_PATH_ELEMENT_ATOMIC) path = MHA_PATH_POINT_ENGINE;
-    MHA_REQUIRE(path == MHA_PATH_POINT_ENGINE || path == MHA_PATH_LOCAL_THEN_SCATTER, MHA_ERR_INVALID,
+    if (path == MHA_PATH_AUTO) path = MHA_PATH_ROW_GATHER;
+    if (path == MHA_PATH_ELEMENT_ATOMIC) path = MHA_PATH_POINT_ENGINE;
+    MHA_REQUIRE(path == MHA_PATH_POINT_ENGINE || path == MHA_PATH_LOCAL_THEN_SCATTER || path == MHA_PATH_ROW_GATHER,
+                MHA_ERR_INVALID,
                 "assembly path " << path << " is not available for this physics module");
   }
   if (path == MHA_PATH_AUTO) {
@@ -387,8 +413,9 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
     std::string why;
     MHA_REQUIRE(rowOwnerUsable(&why), MHA_ERR_INVALID, "row-owner path not available: " << why);
   }
+  if (path == MHA_PATH_ROW_GATHER) prepareRowGather(compute_jacobian != 0);
   timedBegin();
-  if (overwrite && !(path == MHA_PATH_ROW_OWNER && ro_.all_rows_covered)) {
+  if (overwrite && path != MHA_PATH_ROW_GATHER && !(path == MHA_PATH_ROW_OWNER && ro_.all_rows_covered)) {
     // the accumulate-only kernels get the fused zeroing as an explicit memset on the same stream
     MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
     if (compute_jacobian) MHA_HIP(hipMemsetAsync(crs_vals, 0, sizeof(double) * h_rowptr_[nrows_], stream_));
@@ -408,6 +435,25 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
       wkset_.res.crs_vals = compute_jacobian ? crs_vals : nullptr;
       useGeneralKernel(compute_jacobian != 0);
       physics_->volumeResidual();
+      break;
+    }
+    case MHA_PATH_ROW_GATHER: {
+      // dense element matrices from the element kernel (stored, not accumulated), then one wavefront per CRS row
+      ElemOut o;
+      o.compute_jacobian = compute_jacobian ? 1 : 0;
+      o.local_store = 1;
+      o.local_J = compute_jacobian ? d_gather_J_.data() : nullptr;
+      o.local_res = d_gather_res_.data();
+      launchPointEngine(compute_jacobian, o, 0, nelem_);
+      RowGatherDev g;
+      g.inc_ptr = d_inc_ptr_.data();
+      g.inc_elem = d_inc_elem_.data();
+      g.inc_pos = d_inc_pos_.data();
+      g.slot = d_elem_slot_.data();
+      g.slot_bytes = elem_slot_bytes_;
+      g.max_row = max_row_;
+      launch_row_gather(blockDev(), g, o.local_J, o.local_res, res, compute_jacobian ? crs_vals : nullptr,
+                        overwrite ? 1 : 0, stream_);
       break;
     }
     case MHA_PATH_POINT_ENGINE: {

@@ -84,6 +84,12 @@ class AssemblyManager {
   DeviceBuffer<int8_t> d_orient_;
   bool has_orient_ = false;
   void buildVarLayout();
+  // row-gather path: row -> (element, position) incidences on the device, full-block dense scratch
+  DeviceBuffer<int32_t> d_inc_ptr_, d_inc_elem_, d_inc_pos_;
+  DeviceBuffer<double> d_gather_J_, d_gather_res_;
+  bool has_incidence_ = false;
+  int max_row_ = 0;
+  void prepareRowGather(bool need_jacobian);
   void launchPointEngine(int compute_jacobian, const ElemOut &out, int e_begin, int e_count);
   int nelem_ = 0, nrows_ = 0, workset_size_ = 0;
   bool has_mesh_ = false, has_graph_ = false;

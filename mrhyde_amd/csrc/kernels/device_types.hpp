@@ -56,6 +56,7 @@ struct ThermalDev {
 // Where an element kernel puts its results.
 struct ElemOut {
   int compute_jacobian = 1;
+  int local_store = 0;          // 1: local_J / local_res are stored (scratch of the row-gather path), 0: accumulated
   int local_base = 0;           // element id stored at local_J[0] / local_res[0]
   double *local_J = nullptr;    // [E][n][n]   (updateJac convention, +=)
   double *local_res = nullptr;  // [E][n]      (updateRes convention, -=)
@@ -129,10 +130,11 @@ constexpr int kMaxVars = 8, kMaxSlots = 24, kMaxFuncs = 8;
 struct VarLayoutDev {
   int nvars = 0, n_tot = 0, ns_tot = 0, nq = 0;
   int type[kMaxVars] = {0}, card[kMaxVars] = {0}, nslot[kMaxVars] = {0};
+  int cardpad[kMaxVars] = {0};          // card rounded up to a multiple of 4 (table row length)
   int varptr[kMaxVars + 1] = {0}, slotptr[kMaxVars + 1] = {0};
   int table_off[kMaxVars] = {0};        // offset (doubles) of the variable's slot table inside `tables`
   int tables_size = 0;                  // doubles; variables with the same (type, order) share one table
-  const double *tables = nullptr;       // per distinct basis: [card][nq][nslot] reference slot values
+  const double *tables = nullptr;       // per distinct basis: [nq][nslot][cardpad] reference slot values, dof fastest
   const int8_t *orient = nullptr;       // [E][n_tot] basis signs (modifyBasisByOrientation, lowest order) or null
 };
 
@@ -141,6 +143,13 @@ struct PhysParamsDev {
   int physics = 0;
   FuncDesc f[kMaxFuncs];
   double p[8] = {0};
+};
+
+// Row -> (element, LID position) incidences + the element-major slot map (kernels/row_gather.hip).
+struct RowGatherDev {
+  const int32_t *inc_ptr = nullptr, *inc_elem = nullptr, *inc_pos = nullptr;
+  const void *slot = nullptr;
+  int slot_bytes = 1, max_row = 0;
 };
 
 // Destination of the row-owner kernels.

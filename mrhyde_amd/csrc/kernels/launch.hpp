@@ -59,8 +59,13 @@ void launch_thermal_boundary(const BlockDev &b, const SideTablesDev &st, const B
 void launch_porous_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const VarLayoutDev &vl,
                             const ElemOut &out, hipStream_t stream);
 
+// row_gather.hip: CRS rows summed from dense element matrices, no global atomics
+void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *local_J, const double *local_res,
+                       double *res, double *vals, int overwrite, hipStream_t stream);
+
 // point_engine.hip: multi-variable blocks, any physics module stated as a point function
+// slot: element-major CRS slot map (launch_build_elem_slot_map) or null for the column search
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
-                         const ElemOut &out, hipStream_t stream);
+                         const ElemOut &out, const void *slot, int slot_bytes, hipStream_t stream);
 
 }  // namespace mha

@@ -12,12 +12,15 @@
 // Physical slots are reference slots times a per-point geometric block G (HGRAD: diag(1, J^-T); HDIV: J/detJ and
 // 1/detJ), so the contraction runs on element-independent reference tables T^ kept in LDS:
 //   res_i = sum_q T^(i,q) . F^(q),  J_ij = sum_q T^(i,q)^T C^(q) T^(j,q),  F^ = w G^T F,  C^ = w G^T (dF/dU) G.
-// One 256-thread workgroup per element, persistent over elements:
+// 64 threads (small elements, four per workgroup) or 256 threads (large ones) per element, persistent over elements:
 //   1 gather + seeding values (x orientation sign), geometry per point
 //   2 reference-slot fields U^(q) = sum_j u_j T^(j,q)
 //   3 one thread per (point, direction): the module's point function on Dual numbers -> one column of C^(q)
-//   4 residual rows;  5 Jacobian rows, one row per wave at a time: P = T^(i,.) C^ then P . T^(j,.) across lanes.
-// Scatter: atomics into res / CRS (column search) or dense local_J / local_res (updateJac / updateRes convention).
+//   4 residual rows
+//   5 Jacobian in panels of 16 rows: P = T^(i,.) C^ for the panel, then 2x4 register tiles (row pair x 4 dofs of one
+//     column variable) contract P with T^ -- the dense B^T C B product, operands read as 16-byte LDS vectors.
+// Output: dense local_J / local_res (updateJac / updateRes convention; the row-gather kernel turns them into CRS rows
+// without global atomics) or atomics into res / CRS through the element-major slot map.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -117,73 +120,94 @@ __device__ __forceinline__ void to_ref_T(int type, const double *phys, const dou
   }
 }
 
-constexpr int kEngineThreads = 256, kEngineWaves = kEngineThreads / 64;
+constexpr int kEngineThreads = 256, kPanelRows = 16;
+
+// orders a wave's LDS writes before its later LDS reads (data private to the wave: no workgroup barrier needed)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int DIM>
 constexpr int geo_size() { return 2 * DIM * DIM + 2 + DIM; }  // J, Ji, det, w, x
 
-__host__ __device__ inline size_t engine_lds_doubles(const VarLayoutDev &vl, int geo) {
+// per-element LDS (doubles): u, udot, sign | geometry | U^, Udot^, F^ | C^ | P panel | row, pos (ints)
+__host__ __device__ inline size_t engine_group_doubles(const VarLayoutDev &vl, int geo) {
   const size_t n = vl.n_tot, NS = vl.ns_tot, NQ = vl.nq;
-  return vl.tables_size + 3 * n + NQ * geo + 3 * NQ * NS + NQ * NS * NS + kEngineWaves * NQ * NS + n /*row,pos as int pairs*/;
+  return (3 * n + NQ * geo + 3 * NQ * NS + NQ * NS * NS + NQ * NS * kPanelRows + n + 1) & ~size_t(1);  // even: 16-B aligned groups
 }
 
-template <int DIM, int PHYS>
+// TPE threads work on one element; a workgroup holds 256/TPE elements at a time (TPE = 64: one wave per element and
+// only wave-level synchronisation inside the element loop; TPE = 256: the whole workgroup, block barriers).
+template <int DIM, int PHYS, int TPE>
 __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
-                                                                      TimeDev tm, ElemOut out) {
+                                                                      TimeDev tm, ElemOut out,
+                                                                      const uint8_t *slot8, const uint16_t *slot16) {
   using L = Layout<PHYS, DIM>;
-  constexpr int NS = L::NS, NN = 1 << DIM, GEO = geo_size<DIM>();
+  constexpr int NS = L::NS, NN = 1 << DIM, GEO = geo_size<DIM>(), NG = kEngineThreads / TPE;
   extern __shared__ double smem[];
-  const int n = vl.n_tot, NQ = vl.nq, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = vl.n_tot, NQ = vl.nq, tid = threadIdx.x, group = tid / TPE, gt = tid % TPE;
+  auto sync = [&]() {
+    if constexpr (TPE == 64) wave_lds_sync();
+    else __syncthreads();
+  };
   double *tab = smem;
-  double *s_u = tab + vl.tables_size, *s_ud = s_u + n, *s_sgn = s_ud + n;
-  double *s_geo = s_sgn + n;
-  double *s_Uh = s_geo + NQ * GEO, *s_Udh = s_Uh + NQ * NS, *s_Fh = s_Udh + NQ * NS;
-  double *s_Ch = s_Fh + NQ * NS;
-  double *s_P = s_Ch + NQ * NS * NS;
-  int *s_row = reinterpret_cast<int *>(s_P + kEngineWaves * NQ * NS), *s_pos = s_row + n;
+  double *gbase = tab + vl.tables_size + (size_t)group * engine_group_doubles(vl, GEO);
+  double *s_P = gbase;  // first: read as 16-byte vectors
+  double *s_Ch = s_P + NQ * NS * kPanelRows;
+  double *s_Uh = s_Ch + NQ * NS * NS, *s_Udh = s_Uh + NQ * NS, *s_Fh = s_Udh + NQ * NS;
+  double *s_geo = s_Fh + NQ * NS;
+  double *s_u = s_geo + NQ * GEO, *s_ud = s_u + n, *s_sgn = s_ud + n;
+  int *s_row = reinterpret_cast<int *>(s_sgn + n), *s_pos = s_row + n;
 
   for (int k = tid; k < vl.tables_size; k += kEngineThreads) tab[k] = vl.tables[k];
+  __syncthreads();
 
-  for (int el = blockIdx.x; el < b.e_count; el += gridDim.x) {
+  // blocked element ranges per group: groups running at the same time work far apart in the mesh
+  const int ngroups = gridDim.x * NG, gid = blockIdx.x * NG + group;
+  const int chunk = (b.e_count + ngroups - 1) / ngroups;
+  const int el_begin = gid * chunk, el_end = min(b.e_count, el_begin + chunk);
+  // TPE == 256: all threads of the block share el_begin/el_end, so the block barriers below are uniform
+  for (int el = el_begin; el < el_end; ++el) {
     const int e = b.e_begin + el;
-    __syncthreads();  // tables loaded / previous element done with LDS
+    sync();  // previous element done with the group's LDS
     // ---- 1. gather + seeding values, geometry ----
-    if (tid < n) {
-      const int pos = b.offsets[tid], row = b.lids[(size_t)e * n + pos];
-      const double sg = vl.orient ? (double)vl.orient[(size_t)e * n + tid] : 1.0;
+    for (int f = gt; f < n; f += TPE) {
+      const int pos = b.offsets[f], row = b.lids[(size_t)e * n + pos];
+      const double sg = vl.orient ? (double)vl.orient[(size_t)e * n + f] : 1.0;
       const double cu = tm.u[row];
       double ue = cu, ud = 0.0;
       if (tm.transient) {  // Workset::computeSolnTransientSeeded (workset.cpp:589-623)
         const double *cp = tm.u_prev + (size_t)row * tm.nsteps, *cs = tm.u_stage + (size_t)row * tm.nstages;
         double beta_u = (1.0 - tm.alpha_u) * cp[0];
-        for (int s = 0; s < tm.stage; ++s) beta_u += tm.stage_ratio[s] * (cs[s] - cp[0]);
+        for (int st = 0; st < tm.stage; ++st) beta_u += tm.stage_ratio[st] * (cs[st] - cp[0]);
         double beta_t = 0.0;
-        for (int s = 1; s < tm.nsteps + 1; ++s) beta_t += tm.bdf[s] * cp[s - 1];
+        for (int st = 1; st < tm.nsteps + 1; ++st) beta_t += tm.bdf[st] * cp[st - 1];
         beta_t *= tm.timewt;
         ue = tm.alpha_u * cu + beta_u;
         ud = tm.alpha_t * cu + beta_t;
       }
-      s_u[tid] = ue * sg;
-      s_ud[tid] = ud * sg;
-      s_sgn[tid] = sg;
-      s_row[tid] = row;
-      s_pos[tid] = pos;
+      s_u[f] = ue * sg;
+      s_ud[f] = ud * sg;
+      s_sgn[f] = sg;
+      s_row[f] = row;
+      s_pos[f] = pos;
     }
-    if (tid >= 64 && tid < 64 + NQ) {
-      const int q = tid - 64;
+    for (int q = gt; q < NQ; q += TPE) {
       const double *xn = b.nodes + (size_t)e * NN * DIM;
       double J[DIM * DIM], Ji[DIM * DIM], det, x[DIM];
 #pragma unroll
       for (int r = 0; r < DIM; ++r) {
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-          double s = 0.0;
-          for (int k = 0; k < NN; ++k) s += xn[k * DIM + r] * b.nodegrad[(k * NQ + q) * DIM + c];
-          J[r * DIM + c] = s;
+          double sum = 0.0;
+          for (int k = 0; k < NN; ++k) sum += xn[k * DIM + r] * b.nodegrad[(k * NQ + q) * DIM + c];
+          J[r * DIM + c] = sum;
         }
-        double s = 0.0;
-        for (int k = 0; k < NN; ++k) s += xn[k * DIM + r] * b.nodeval[k * NQ + q];
-        x[r] = s;
+        double sum = 0.0;
+        for (int k = 0; k < NN; ++k) sum += xn[k * DIM + r] * b.nodeval[k * NQ + q];
+        x[r] = sum;
       }
       invert<DIM>(J, Ji, det);
       double *g = s_geo + q * GEO;
@@ -194,30 +218,29 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
 #pragma unroll
       for (int d = 0; d < DIM; ++d) g[2 * DIM * DIM + 2 + d] = x[d];
     }
-    __syncthreads();
-    // ---- 2. reference-slot fields ----
-    for (int idx = tid; idx < NQ * NS; idx += kEngineThreads) {
+    sync();
+    // ---- 2. reference-slot fields: U^(q,m) = sum_dof u_dof T^[q][slot][dof] ----
+    for (int idx = gt; idx < NQ * NS; idx += TPE) {
       const int q = idx / NS, m = idx - q * NS;
       int v = 0;
       while (m >= vl.slotptr[v + 1]) ++v;
-      const int s = m - vl.slotptr[v], ns = vl.nslot[v], card = vl.card[v];
-      const double *T = tab + vl.table_off[v] + (size_t)q * ns + s;
+      const int sl = m - vl.slotptr[v], card = vl.card[v];
+      const double *T = tab + vl.table_off[v] + ((size_t)q * vl.nslot[v] + sl) * vl.cardpad[v];
       const double *uu = s_u + vl.varptr[v], *ud = s_ud + vl.varptr[v];
       double a = 0.0, ad = 0.0;
       for (int dof = 0; dof < card; ++dof) {
-        const double t = T[(size_t)dof * NQ * ns];
-        a += uu[dof] * t;
-        ad += ud[dof] * t;
+        a += uu[dof] * T[dof];
+        ad += ud[dof] * T[dof];
       }
       s_Uh[idx] = a;
       s_Udh[idx] = ad;
     }
-    __syncthreads();
+    sync();
     // ---- 3. point function, one (point, direction) per thread ----
     double vol = 0.0;
     for (int q = 0; q < NQ; ++q) vol += s_geo[q * GEO + 2 * DIM * DIM + 1];
     const double h = (DIM == 2) ? sqrt(vol) : cbrt(vol);  // Workset::getElementSize (workset.cpp:2666-2679)
-    for (int idx = tid; idx < NQ * (NS + 1); idx += kEngineThreads) {
+    for (int idx = gt; idx < NQ * (NS + 1); idx += TPE) {
       const int q = idx / (NS + 1), m = idx - q * (NS + 1);
       const double *g = s_geo + q * GEO;
       const double *J = g, *Ji = g + DIM * DIM;
@@ -225,23 +248,21 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       Dual U[NS], Ud[NS], F[NS];
 #pragma unroll
       for (int v = 0; v < L::nvars; ++v) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int type = L::type(v), sp = slotptr_of<L, DIM>(v), ns = slots_of(type, DIM);
         double ref[1 + DIM], phys[1 + DIM], refd[1 + DIM], physd[1 + DIM], dir[1 + DIM], pdir[1 + DIM];
 #pragma unroll
-        for (int s = 0; s < ns; ++s) {
-          ref[s] = s_Uh[q * NS + sp + s];
-          refd[s] = s_Udh[q * NS + sp + s];
-          dir[s] = (m == sp + s) ? 1.0 : 0.0;
+        for (int sl = 0; sl < ns; ++sl) {
+          ref[sl] = s_Uh[q * NS + sp + sl];
+          refd[sl] = s_Udh[q * NS + sp + sl];
+          dir[sl] = (m == sp + sl) ? 1.0 : 0.0;
         }
         to_phys<DIM>(type, ref, J, Ji, det, phys);
         to_phys<DIM>(type, refd, J, Ji, det, physd);
         to_phys<DIM>(type, dir, J, Ji, det, pdir);
 #pragma unroll
-        for (int s = 0; s < ns; ++s) {
-          U[sp + s] = mk(phys[s], tm.alpha_u * pdir[s]);
-          Ud[sp + s] = value_like(type, s, DIM) ? mk(physd[s], tm.alpha_t * pdir[s]) : mk(0.0);
+        for (int sl = 0; sl < ns; ++sl) {
+          U[sp + sl] = mk(phys[sl], tm.alpha_u * pdir[sl]);
+          Ud[sp + sl] = value_like(type, sl, DIM) ? mk(physd[sl], tm.alpha_t * pdir[sl]) : mk(0.0);
         }
       }
       PointArgs<DIM> pa;
@@ -255,70 +276,100 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
         const int type = L::type(v), sp = slotptr_of<L, DIM>(v), ns = slots_of(type, DIM);
         double phys[1 + DIM], ref[1 + DIM];
 #pragma unroll
-        for (int s = 0; s < ns; ++s) phys[s] = (m == NS) ? F[sp + s].v : F[sp + s].d;
+        for (int sl = 0; sl < ns; ++sl) phys[sl] = (m == NS) ? F[sp + sl].v : F[sp + sl].d;
         to_ref_T<DIM>(type, phys, J, Ji, det, ref);
 #pragma unroll
-        for (int s = 0; s < ns; ++s) {
-          if (m == NS) s_Fh[q * NS + sp + s] = w * ref[s];
-          else s_Ch[(q * NS + sp + s) * NS + m] = w * ref[s];
+        for (int sl = 0; sl < ns; ++sl) {
+          if (m == NS) s_Fh[q * NS + sp + sl] = w * ref[sl];
+          else s_Ch[(q * NS + sp + sl) * NS + m] = w * ref[sl];
         }
       }
     }
-    __syncthreads();
+    sync();
     // ---- 4. residual rows ----
-    if (tid < n) {
+    for (int f = gt; f < n; f += TPE) {
       int v = 0;
-      while (tid >= vl.varptr[v + 1]) ++v;
-      const int dof = tid - vl.varptr[v], ns = vl.nslot[v], sp = vl.slotptr[v];
-      const double *T = tab + vl.table_off[v] + (size_t)dof * NQ * ns;
+      while (f >= vl.varptr[v + 1]) ++v;
+      const int ns = vl.nslot[v], sp = vl.slotptr[v], cp = vl.cardpad[v];
+      const double *T = tab + vl.table_off[v] + (f - vl.varptr[v]);
       double r = 0.0;
       for (int q = 0; q < NQ; ++q)
-        for (int s = 0; s < ns; ++s) r += T[q * ns + s] * s_Fh[q * NS + sp + s];
-      r *= s_sgn[tid];
-      const int row = s_row[tid];
-      if (out.local_res) out.local_res[(size_t)(e - out.local_base) * n + s_pos[tid]] -= r;
+        for (int sl = 0; sl < ns; ++sl) r += T[((size_t)q * ns + sl) * cp] * s_Fh[q * NS + sp + sl];
+      r *= s_sgn[f];
+      const int row = s_row[f];
+      if (out.local_res) {
+        double *lr = out.local_res + (size_t)(e - out.local_base) * n + s_pos[f];
+        *lr = out.local_store ? -r : *lr - r;
+      }
       if (out.res && !(b.fixed && b.fixed[row])) unsafeAtomicAdd(out.res + row, -r);
     }
-    // ---- 5. Jacobian rows: wave `wave` takes rows wave, wave+4, ... ----
+    // ---- 5. Jacobian: panels of 16 rows; P[(q,m)][r] = T^(i_r,q) . C^(q)[:,m]; then 2x4 register tiles over
+    //         (row pair, 4 dofs of one column variable): J[i][j] = sum_(q,s) P[(q, sp_j+s)][i] T^[q][s][j] ----
     if (out.compute_jacobian) {
-      double *P = s_P + wave * NQ * NS;
-      for (int i0 = 0; i0 < n; i0 += kEngineWaves) {
-        const int i = i0 + wave;
-        const bool active = i < n;
-        int vi = 0;
-        if (active) while (i >= vl.varptr[vi + 1]) ++vi;
-        if (active) {
-          const int dof = i - vl.varptr[vi], ns = vl.nslot[vi], sp = vl.slotptr[vi];
-          const double *T = tab + vl.table_off[vi] + (size_t)dof * NQ * ns;
-          for (int idx = lane; idx < NQ * NS; idx += 64) {
-            const int q = idx / NS, m = idx - q * NS;
-            double a = 0.0;
-            for (int s = 0; s < ns; ++s) a += T[q * ns + s] * s_Ch[(q * NS + sp + s) * NS + m];
-            P[idx] = a;
+      int ntile_cols = 0;  // column quads, enumerated variable by variable
+      for (int v = 0; v < vl.nvars; ++v) ntile_cols += vl.cardpad[v] >> 2;
+      for (int i0 = 0; i0 < n; i0 += kPanelRows) {
+        for (int idx = gt; idx < NQ * NS * kPanelRows; idx += TPE) {
+          const int r = idx % kPanelRows, qm = idx / kPanelRows;
+          const int q = qm / NS, m = qm - q * NS, i = i0 + r;
+          double a = 0.0;
+          if (i < n) {
+            int vi = 0;
+            while (i >= vl.varptr[vi + 1]) ++vi;
+            const int ns = vl.nslot[vi], sp = vl.slotptr[vi], cp = vl.cardpad[vi];
+            const double *T = tab + vl.table_off[vi] + (size_t)q * ns * cp + (i - vl.varptr[vi]);
+            for (int sl = 0; sl < ns; ++sl) a += T[sl * cp] * s_Ch[(q * NS + sp + sl) * NS + m];
           }
+          s_P[idx] = a;
         }
-        __syncthreads();
-        if (active) {
-          const int row_i = s_row[i];
-          const bool skip = out.crs_vals == nullptr || (b.fixed && b.fixed[row_i]);
-          const double sgi = s_sgn[i];
-          for (int j = lane; j < n; j += 64) {
-            int vj = 0;
-            while (j >= vl.varptr[vj + 1]) ++vj;
-            const int dofj = j - vl.varptr[vj], nsj = vl.nslot[vj], spj = vl.slotptr[vj];
-            const double *T = tab + vl.table_off[vj] + (size_t)dofj * NQ * nsj;
-            double a = 0.0;
-            for (int q = 0; q < NQ; ++q)
-              for (int s = 0; s < nsj; ++s) a += P[q * NS + spj + s] * T[q * nsj + s];
-            a *= sgi * s_sgn[j];
-            if (out.local_J) out.local_J[((size_t)(e - out.local_base) * n + s_pos[i]) * n + s_pos[j]] += a;
-            if (!skip) {
-              const int p = find_col(b.colind, b.rowptr[row_i], b.rowptr[row_i + 1], s_row[j]);
-              if (p >= 0) unsafeAtomicAdd(out.crs_vals + p, a);
+        sync();
+        for (int t = gt; t < (kPanelRows / 2) * ntile_cols; t += TPE) {
+          const int rp = t % (kPanelRows / 2);
+          int cq = t / (kPanelRows / 2), vj = 0;
+          while (cq >= (vl.cardpad[vj] >> 2)) { cq -= vl.cardpad[vj] >> 2; ++vj; }
+          const int nsj = vl.nslot[vj], spj = vl.slotptr[vj], cpj = vl.cardpad[vj];
+          const double *T = tab + vl.table_off[vj] + 4 * cq;
+          const double *Pp = s_P + (size_t)spj * kPanelRows + 2 * rp;
+          double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+          for (int q = 0; q < NQ; ++q) {
+            const double *Tq = T + (size_t)q * nsj * cpj;
+            const double *Pq = Pp + (size_t)q * NS * kPanelRows;
+            for (int sl = 0; sl < nsj; ++sl) {
+              const double2 a = *reinterpret_cast<const double2 *>(Pq + sl * kPanelRows);
+              const double2 b0 = *reinterpret_cast<const double2 *>(Tq + sl * cpj);
+              const double2 b1 = *reinterpret_cast<const double2 *>(Tq + sl * cpj + 2);
+              acc[0][0] += a.x * b0.x; acc[0][1] += a.x * b0.y; acc[0][2] += a.x * b1.x; acc[0][3] += a.x * b1.y;
+              acc[1][0] += a.y * b0.x; acc[1][1] += a.y * b0.y; acc[1][2] += a.y * b1.x; acc[1][3] += a.y * b1.y;
+            }
+          }
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            const int i = i0 + 2 * rp + x;
+            if (i >= n) continue;
+            const int pos_i = s_pos[i], row_i = s_row[i];
+            const bool to_crs = out.crs_vals && !(b.fixed && b.fixed[row_i]);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+              const int dofj = 4 * cq + y;
+              if (dofj >= vl.card[vj]) continue;
+              const int j = vl.varptr[vj] + dofj, pos_j = s_pos[j];
+              const double a = acc[x][y] * s_sgn[i] * s_sgn[j];
+              if (out.local_J) {
+                double *lj = out.local_J + ((size_t)(e - out.local_base) * n + pos_i) * n + pos_j;
+                *lj = out.local_store ? a : *lj + a;
+              }
+              if (to_crs) {
+                const size_t so = ((size_t)e * n + pos_i) * n + pos_j;
+                int p;
+                if (slot8) p = b.rowptr[row_i] + slot8[so];
+                else if (slot16) p = b.rowptr[row_i] + slot16[so];
+                else p = find_col(b.colind, b.rowptr[row_i], b.rowptr[row_i + 1], s_row[j]);
+                if (p >= 0) unsafeAtomicAdd(out.crs_vals + p, a);
+              }
             }
           }
         }
-        __syncthreads();
+        sync();
       }
     }
   }
@@ -326,50 +377,53 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
 
 template <int DIM, int PHYS>
 void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
-                  const ElemOut &out, hipStream_t stream) {
+                  const ElemOut &out, const void *slot, int slot_bytes, hipStream_t stream) {
   using L = Layout<PHYS, DIM>;
   MHA_REQUIRE(vl.nvars == L::nvars && vl.ns_tot == L::NS, MHA_ERR_INVALID,
               "variable layout does not match the physics module (" << vl.nvars << " variables, " << vl.ns_tot
                                                                     << " slots)");
   for (int v = 0; v < L::nvars; ++v)
     MHA_REQUIRE(vl.type[v] == L::type(v), MHA_ERR_INVALID, "basis type of variable " << v << " does not match the module");
-  MHA_REQUIRE(vl.n_tot <= kEngineThreads && vl.nq <= kEngineThreads - 64, MHA_ERR_INVALID,
-              "point engine supports at most " << kEngineThreads << " dofs and " << kEngineThreads - 64
-                                               << " integration points per element");
-  const size_t lds = engine_lds_doubles(vl, geo_size<DIM>()) * sizeof(double);
+  const size_t per_group = engine_group_doubles(vl, geo_size<DIM>()) * sizeof(double);
+  const size_t tables = vl.tables_size * sizeof(double);
+  // small elements: one wave per element, four elements per workgroup; large ones: the whole workgroup per element
+  const bool small = vl.n_tot <= 48 && tables + 4 * per_group <= 160 * 1024;
+  const size_t lds = tables + (small ? 4 : 1) * per_group;
   MHA_REQUIRE(lds <= 160 * 1024, MHA_ERR_INVALID, "element needs " << lds << " B of LDS (limit 160 KB)");
-  auto kern = point_engine_kernel<DIM, PHYS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    attr_set = true;
-  }
   static int num_cu = 0;
   if (!num_cu) {
     int dev = 0;
     MHA_HIP(hipGetDevice(&dev));
     MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds)));
-  const int grid = std::min(b.e_count, num_cu * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kEngineThreads), lds, stream, b, vl, pp, tm, out);
-  MHA_HIP(hipGetLastError());
+  const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds)));
+  const int groups = small ? 4 : 1;
+  const int grid = std::max(1, std::min((b.e_count + groups - 1) / groups, num_cu * per_cu));
+  const uint8_t *s8 = (slot && slot_bytes == 1) ? static_cast<const uint8_t *>(slot) : nullptr;
+  const uint16_t *s16 = (slot && slot_bytes == 2) ? static_cast<const uint16_t *>(slot) : nullptr;
+  auto go = [&](auto kern) {
+    MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEngineThreads), lds, stream, b, vl, pp, tm, out, s8, s16);
+    MHA_HIP(hipGetLastError());
+  };
+  if (small) go(point_engine_kernel<DIM, PHYS, 64>);
+  else go(point_engine_kernel<DIM, PHYS, 256>);
 }
 
 }  // namespace
 
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
-                         const ElemOut &out, hipStream_t stream) {
+                         const ElemOut &out, const void *slot, int slot_bytes, hipStream_t stream) {
   if (b.e_count <= 0) return;
   const int key = b.dim * 10 + pp.physics;
   switch (key) {
-    case 20 + MHA_PHYSICS_THERMAL: launch_typed<2, MHA_PHYSICS_THERMAL>(b, vl, pp, tm, out, stream); break;
-    case 30 + MHA_PHYSICS_THERMAL: launch_typed<3, MHA_PHYSICS_THERMAL>(b, vl, pp, tm, out, stream); break;
-    case 20 + MHA_PHYSICS_POROUS_MIXED: launch_typed<2, MHA_PHYSICS_POROUS_MIXED>(b, vl, pp, tm, out, stream); break;
-    case 30 + MHA_PHYSICS_POROUS_MIXED: launch_typed<3, MHA_PHYSICS_POROUS_MIXED>(b, vl, pp, tm, out, stream); break;
-    case 20 + MHA_PHYSICS_NAVIERSTOKES: launch_typed<2, MHA_PHYSICS_NAVIERSTOKES>(b, vl, pp, tm, out, stream); break;
-    case 30 + MHA_PHYSICS_NAVIERSTOKES: launch_typed<3, MHA_PHYSICS_NAVIERSTOKES>(b, vl, pp, tm, out, stream); break;
+    case 20 + MHA_PHYSICS_THERMAL: launch_typed<2, MHA_PHYSICS_THERMAL>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
+    case 30 + MHA_PHYSICS_THERMAL: launch_typed<3, MHA_PHYSICS_THERMAL>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
+    case 20 + MHA_PHYSICS_POROUS_MIXED: launch_typed<2, MHA_PHYSICS_POROUS_MIXED>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
+    case 30 + MHA_PHYSICS_POROUS_MIXED: launch_typed<3, MHA_PHYSICS_POROUS_MIXED>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
+    case 20 + MHA_PHYSICS_NAVIERSTOKES: launch_typed<2, MHA_PHYSICS_NAVIERSTOKES>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
+    case 30 + MHA_PHYSICS_NAVIERSTOKES: launch_typed<3, MHA_PHYSICS_NAVIERSTOKES>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
     default: MHA_REQUIRE(false, MHA_ERR_INVALID, "no point-engine kernel for physics " << pp.physics << " in " << b.dim << "-D");
   }
 }

@@ -1,0 +1,92 @@
+// row_gather.hip -- scatter without global atomics: every CRS row is summed by one wavefront from the dense element
+// matrices of the elements incident to it.
+//
+// Replaces scatterJac / scatterRes (reference: src/managers/assemblyManager.cpp:3882-3935, 3943-3978) -- and, with the
+// element kernels writing local_J/local_res first, the fused scatter (:4031-4145) -- for any physics module and any
+// LID map.  The reference adds element by element into the CRS with a column search (and atomics on a parallel
+// device); here a row's owner walks its (element, LID position) incidences, reads row `position` of each element
+// matrix (n contiguous doubles, coalesced), adds the entries into an LDS image of the CRS row through the
+// element-major slot map (ds_add_f64: two elements of the row may hit the same column), then stores the row once,
+// coalesced.  No global atomics, results independent of scheduling up to the order of the LDS adds within one row.
+// HBM traffic: local_J once, the slot map once, the CRS values once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device_math.hpp"
+#include "launch.hpp"
+
+namespace mha {
+namespace {
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename SlotT>
+__global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDev g, const double *__restrict__ local_J,
+                                                         const double *__restrict__ local_res, double *res, double *vals,
+                                                         int overwrite) {
+  extern __shared__ double acc_all[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = b.n;
+  double *acc = acc_all + (size_t)wave * g.max_row;
+  const SlotT *slot = static_cast<const SlotT *>(g.slot);
+  const int nwaves = gridDim.x * 4;
+  for (int k = lane; k < g.max_row; k += 64) acc[k] = 0.0;
+  wave_lds_sync();
+  for (int row = blockIdx.x * 4 + wave; row < b.nrows; row += nwaves) {
+    const int lo = b.rowptr[row], len = b.rowptr[row + 1] - lo;
+    const bool fixed = b.fixed && b.fixed[row];  // isFixedDOF rows are skipped by the scatter (assemblyManager.cpp:4075,4120)
+    if (fixed) {
+      if (overwrite) {
+        if (vals) for (int k = lane; k < len; k += 64) vals[lo + k] = 0.0;
+        if (res && lane == 0) res[row] = 0.0;
+      }
+      continue;
+    }
+    const int i0 = g.inc_ptr[row], ni = g.inc_ptr[row + 1] - i0;
+    if (vals) {
+      const int total = ni * n;
+      for (int t = lane; t < total; t += 64) {
+        const int k = t / n, sj = t - k * n;
+        const size_t off = ((size_t)g.inc_elem[i0 + k] * n + g.inc_pos[i0 + k]) * n + sj;
+        unsafeAtomicAdd(acc + slot[off], local_J[off]);
+      }
+      wave_lds_sync();
+      for (int k = lane; k < len; k += 64) {
+        const double a = acc[k];
+        acc[k] = 0.0;
+        vals[lo + k] = overwrite ? a : vals[lo + k] + a;
+      }
+      wave_lds_sync();
+    }
+    if (res) {
+      double r = 0.0;
+      for (int k = lane; k < ni; k += 64) r += local_res[(size_t)g.inc_elem[i0 + k] * n + g.inc_pos[i0 + k]];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+      if (lane == 0) res[row] = overwrite ? r : res[row] + r;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *local_J, const double *local_res,
+                       double *res, double *vals, int overwrite, hipStream_t stream) {
+  if (b.nrows <= 0) return;
+  const size_t lds = sizeof(double) * 4 * (size_t)g.max_row;
+  MHA_REQUIRE(lds <= 64 * 1024, MHA_ERR_INVALID, "CRS rows of " << g.max_row << " entries do not fit the row-gather kernel");
+  const int grid = std::min((b.nrows + 3) / 4, 256 * 8);
+  if (g.slot_bytes == 1)
+    hipLaunchKernelGGL(row_gather_kernel<uint8_t>, dim3(grid), dim3(256), lds, stream, b, g, local_J, local_res, res, vals,
+                       overwrite);
+  else
+    hipLaunchKernelGGL(row_gather_kernel<uint16_t>, dim3(grid), dim3(256), lds, stream, b, g, local_J, local_res, res, vals,
+                       overwrite);
+  MHA_HIP(hipGetLastError());
+}
+
+}  // namespace mha

@@ -49,7 +49,7 @@ void thermal::volumeResidual() {
     pp.f[1] = functionManager->evaluate("thermal diffusion");
     pp.f[2] = functionManager->evaluate("specific heat");
     pp.f[3] = functionManager->evaluate("density");
-    launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.stream);
+    launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
   } else if (w.use_general)
     launch_thermal_general(w.dimension, w.order, w.nq1, b, device_params(), w.tables, w.elem_slot, w.elem_slot_bytes,
                            w.res, w.stream);
@@ -106,7 +106,7 @@ void porousMixed::volumeResidual() {
   pp.physics = MHA_PHYSICS_POROUS_MIXED;
   const char *names[5] = {"source", "Kinv_xx", "Kinv_yy", "Kinv_zz", "total_mobility"};
   for (int k = 0; k < 5; ++k) pp.f[k] = functionManager->evaluate(names[k]);
-  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.stream);
+  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
 }
 
 // reference: porousMixed::boundaryResidual (porousMixed.cpp:345-432): bcs(pnum, side) == "Dirichlet" adds
@@ -159,7 +159,7 @@ void navierstokes::volumeResidual() {
   pp.p[0] = useSUPG ? 1.0 : 0.0;
   pp.p[1] = usePSPG ? 1.0 : 0.0;
   pp.p[2] = fix_uz_offsets ? 1.0 : 0.0;
-  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.stream);
+  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
 }
 
 std::unique_ptr<PhysicsBase> import_physics(int physics_id) {

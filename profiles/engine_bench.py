@@ -7,7 +7,10 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mrhyde_amd  # noqa: E402
 import oracle_lib as orc  # noqa: E402  (mesh generator only: test infrastructure building the input)
 
@@ -35,11 +38,23 @@ def run(kind, nc):
     if kind == "ns":
         blk.set_function("viscosity", 1.0)
     blk.set_timing(True)
+    mode = sys.argv[3] if len(sys.argv) > 3 else "full"
+    if mode == "local":
+        E, n = m["lids"].shape
+        lJ = torch.zeros((E, n, n), dtype=torch.float64, device="cuda")
+        lr = torch.zeros((E, n), dtype=torch.float64, device="cuda")
     for it in range(3):
-        blk.assemble_jacres(u, res, vals, overwrite=True, path=mrhyde_amd.PATH_POINT_ENGINE)
+        if mode == "full":
+            blk.assemble_jacres(u, res, vals, overwrite=True, path=mrhyde_amd.PATH_POINT_ENGINE)
+        elif mode == "gather":
+            blk.assemble_jacres(u, res, vals, overwrite=True, path=mrhyde_amd.PATH_ROW_GATHER)
+        elif mode == "res":
+            blk.assemble_jacres(u, res, None, compute_jacobian=False, overwrite=True, path=mrhyde_amd.PATH_POINT_ENGINE)
+        else:
+            blk.compute_local_jacres(u, lJ, lr)
         torch.cuda.synchronize()
         ms = blk.last_kernel_ms()
-        print("%s %d^3: %.3f ms  %.3e elements/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" %
+        print(mode, "%s %d^3: %.3f ms  %.3e elements/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" %
               (kind, nc, ms, m["nelem"] / ms * 1e3, m["nelem"] * B / ms / 1e6, m["nelem"] * B / ms / 1e6 / 80.0), flush=True)
 
 

@@ -72,6 +72,16 @@ def run_gpu(blk, m, u, tr, nnz, local=False):
         res2, vals2 = torch.zeros_like(res), torch.zeros_like(vals)
         blk.assemble_jacres(ud, res2, vals2, path=mrhyde_amd.PATH_LOCAL_THEN_SCATTER, **kw)
         out["res2"], out["crs_vals2"] = res2.cpu().numpy(), vals2.cpu().numpy()
+        # row-gather path (no global atomics): overwrite semantics on garbage, then accumulate on top
+        res3, vals3 = torch.full_like(res, 7.0), torch.full_like(vals, -3.0)
+        blk.assemble_jacres(ud, res3, vals3, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True, **kw)
+        r3, v3 = res3.cpu().numpy().copy(), vals3.cpu().numpy().copy()
+        blk.assemble_jacres(ud, res3, vals3, path=mrhyde_amd.PATH_ROW_GATHER, **kw)
+        assert rel_err(res3.cpu().numpy(), 2 * r3) < 1e-14 and rel_err(vals3.cpu().numpy(), 2 * v3) < 1e-14
+        assert rel_err(r3, out["res"]) < RTOL and rel_err(v3, out["crs_vals"]) < RTOL
+        # residual-only pass leaves the matrix alone
+        blk.assemble_jacres(ud, res3, vals3, path=mrhyde_amd.PATH_ROW_GATHER, compute_jacobian=False, overwrite=True, **kw)
+        assert rel_err(res3.cpu().numpy(), r3) < 1e-14 and rel_err(vals3.cpu().numpy(), 2 * v3) < 1e-14
     torch.cuda.synchronize()
     return out
 
