@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -120,6 +121,9 @@ __device__ __forceinline__ void to_ref_T(int type, const double *phys, const dou
   }
 }
 
+#ifndef MHA_ENGINE_MINW
+#define MHA_ENGINE_MINW 2
+#endif
 constexpr int kEngineThreads = 256, kPanelRows = 16;
 
 // orders a wave's LDS writes before its later LDS reads (data private to the wave: no workgroup barrier needed)
@@ -141,7 +145,7 @@ __host__ __device__ inline size_t engine_group_doubles(const VarLayoutDev &vl, i
 // TPE threads work on one element; a workgroup holds 256/TPE elements at a time (TPE = 64: one wave per element and
 // only wave-level synchronisation inside the element loop; TPE = 256: the whole workgroup, block barriers).
 template <int DIM, int PHYS, int TPE>
-__global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
+__global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) void point_engine_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
                                                                       TimeDev tm, ElemOut out,
                                                                       const uint8_t *slot8, const uint16_t *slot16) {
   using L = Layout<PHYS, DIM>;
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
   double *s_u = s_geo + NQ * GEO, *s_ud = s_u + n, *s_sgn = s_ud + n;
   int *s_row = reinterpret_cast<int *>(s_sgn + n), *s_pos = s_row + n;
 
+  const int dbg_stop = (int)pp.p[7];  // profiling aid (MHA_ENGINE_STOP): leave the element after phase k
   for (int k = tid; k < vl.tables_size; k += kEngineThreads) tab[k] = vl.tables[k];
   __syncthreads();
 
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       for (int d = 0; d < DIM; ++d) g[2 * DIM * DIM + 2 + d] = x[d];
     }
     sync();
+    if (dbg_stop == 1) continue;
     // ---- 2. reference-slot fields: U^(q,m) = sum_dof u_dof T^[q][slot][dof] ----
     for (int idx = gt; idx < NQ * NS; idx += TPE) {
       const int q = idx / NS, m = idx - q * NS;
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       s_Udh[idx] = ad;
     }
     sync();
+    if (dbg_stop == 2) continue;
     // ---- 3. point function, one (point, direction) per thread ----
     double vol = 0.0;
     for (int q = 0; q < NQ; ++q) vol += s_geo[q * GEO + 2 * DIM * DIM + 1];
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       }
     }
     sync();
+    if (dbg_stop == 3) continue;
     // ---- 4. residual rows ----
     for (int f = gt; f < n; f += TPE) {
       int v = 0;
@@ -303,26 +311,37 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       }
       if (out.res && !(b.fixed && b.fixed[row])) unsafeAtomicAdd(out.res + row, -r);
     }
+    if (dbg_stop == 4) continue;
     // ---- 5. Jacobian: panels of 16 rows; P[(q,m)][r] = T^(i_r,q) . C^(q)[:,m]; then 2x4 register tiles over
     //         (row pair, 4 dofs of one column variable): J[i][j] = sum_(q,s) P[(q, sp_j+s)][i] T^[q][s][j] ----
     if (out.compute_jacobian) {
       int ntile_cols = 0;  // column quads, enumerated variable by variable
       for (int v = 0; v < vl.nvars; ++v) ntile_cols += vl.cardpad[v] >> 2;
       for (int i0 = 0; i0 < n; i0 += kPanelRows) {
-        for (int idx = gt; idx < NQ * NS * kPanelRows; idx += TPE) {
-          const int r = idx % kPanelRows, qm = idx / kPanelRows;
-          const int q = qm / NS, m = qm - q * NS, i = i0 + r;
-          double a = 0.0;
-          if (i < n) {
-            int vi = 0;
-            while (i >= vl.varptr[vi + 1]) ++vi;
-            const int ns = vl.nslot[vi], sp = vl.slotptr[vi], cp = vl.cardpad[vi];
-            const double *T = tab + vl.table_off[vi] + (size_t)q * ns * cp + (i - vl.varptr[vi]);
-            for (int sl = 0; sl < ns; ++sl) a += T[sl * cp] * s_Ch[(q * NS + sp + sl) * NS + m];
+        {  // P panel: thread = (row r, every (TPE/16)-th (q,m)); the row's table pointers are set up once
+          const int r = gt % kPanelRows, i = i0 + r;
+          int vi = 0;
+          if (i < n) while (i >= vl.varptr[vi + 1]) ++vi;
+          const int ns = vl.nslot[vi], sp = vl.slotptr[vi], cp = vl.cardpad[vi];
+          const double *Ti = tab + vl.table_off[vi] + (i < n ? i - vl.varptr[vi] : 0);
+          for (int qm = gt / kPanelRows; qm < NQ * NS; qm += TPE / kPanelRows) {
+            const int q = qm / NS, m = qm - q * NS;
+            double a = 0.0;
+            if (i < n) {
+              const double *T = Ti + (size_t)q * ns * cp;
+              const double *C = s_Ch + (q * NS + sp) * NS + m;
+              if (ns == 1) {
+                a = T[0] * C[0];
+              } else {
+#pragma unroll
+                for (int sl = 0; sl < 1 + DIM; ++sl) a += T[sl * cp] * C[sl * NS];
+              }
+            }
+            s_P[qm * kPanelRows + r] = a;
           }
-          s_P[idx] = a;
         }
         sync();
+        if (dbg_stop == 5) continue;
         for (int t = gt; t < (kPanelRows / 2) * ntile_cols; t += TPE) {
           const int rp = t % (kPanelRows / 2);
           int cq = t / (kPanelRows / 2), vj = 0;
@@ -331,15 +350,23 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
           const double *T = tab + vl.table_off[vj] + 4 * cq;
           const double *Pp = s_P + (size_t)spj * kPanelRows + 2 * rp;
           double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-          for (int q = 0; q < NQ; ++q) {
-            const double *Tq = T + (size_t)q * nsj * cpj;
-            const double *Pq = Pp + (size_t)q * NS * kPanelRows;
-            for (int sl = 0; sl < nsj; ++sl) {
-              const double2 a = *reinterpret_cast<const double2 *>(Pq + sl * kPanelRows);
-              const double2 b0 = *reinterpret_cast<const double2 *>(Tq + sl * cpj);
-              const double2 b1 = *reinterpret_cast<const double2 *>(Tq + sl * cpj + 2);
-              acc[0][0] += a.x * b0.x; acc[0][1] += a.x * b0.y; acc[0][2] += a.x * b1.x; acc[0][3] += a.x * b1.y;
-              acc[1][0] += a.y * b0.x; acc[1][1] += a.y * b0.y; acc[1][2] += a.y * b1.x; acc[1][3] += a.y * b1.y;
+          auto kstep = [&](const double *Pk, const double *Tk) {
+            const double2 a = *reinterpret_cast<const double2 *>(Pk);
+            const double2 b0 = *reinterpret_cast<const double2 *>(Tk);
+            const double2 b1 = *reinterpret_cast<const double2 *>(Tk + 2);
+            acc[0][0] += a.x * b0.x; acc[0][1] += a.x * b0.y; acc[0][2] += a.x * b1.x; acc[0][3] += a.x * b1.y;
+            acc[1][0] += a.y * b0.x; acc[1][1] += a.y * b0.y; acc[1][2] += a.y * b1.x; acc[1][3] += a.y * b1.y;
+          };
+          if (nsj == 1) {
+#pragma unroll 4
+            for (int q = 0; q < NQ; ++q) kstep(Pp + (size_t)q * NS * kPanelRows, T + (size_t)q * cpj);
+          } else {
+#pragma unroll 2
+            for (int q = 0; q < NQ; ++q) {
+              const double *Tq = T + (size_t)q * (1 + DIM) * cpj;
+              const double *Pq = Pp + (size_t)q * NS * kPanelRows;
+#pragma unroll
+              for (int sl = 0; sl < 1 + DIM; ++sl) kstep(Pq + sl * kPanelRows, Tq + sl * cpj);
             }
           }
 #pragma unroll
@@ -396,7 +423,9 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
     MHA_HIP(hipGetDevice(&dev));
     MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds)));
+  const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(small ? MHA_ENGINE_MINW : 1, (160 * 1024) / lds)));
+  PhysParamsDev ppd = pp;
+  if (const char *st = std::getenv("MHA_ENGINE_STOP")) ppd.p[7] = std::atof(st);
   const int groups = small ? 4 : 1;
   const int grid = std::max(1, std::min((b.e_count + groups - 1) / groups, num_cu * per_cu));
   const uint8_t *s8 = (slot && slot_bytes == 1) ? static_cast<const uint8_t *>(slot) : nullptr;
@@ -404,7 +433,7 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
   auto go = [&](auto kern) {
     MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEngineThreads), lds, stream, b, vl, pp, tm, out, s8, s16);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEngineThreads), lds, stream, b, vl, ppd, tm, out, s8, s16);
     MHA_HIP(hipGetLastError());
   };
   if (small) go(point_engine_kernel<DIM, PHYS, 64>);
