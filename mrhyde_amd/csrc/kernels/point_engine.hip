@@ -144,20 +144,23 @@ __host__ __device__ inline size_t engine_group_doubles(const VarLayoutDev &vl, i
 
 // TPE threads work on one element; a workgroup holds 256/TPE elements at a time (TPE = 64: one wave per element and
 // only wave-level synchronisation inside the element loop; TPE = 256: the whole workgroup, block barriers).
-template <int DIM, int PHYS, int TPE>
+// NQ1 = integration points per direction when it is 2 or 3 (the loops over points then have compile-time bounds and
+// the compiler batches their LDS loads), 0 = taken from the layout at run time.
+template <int DIM, int PHYS, int TPE, int NQ1>
 __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) void point_engine_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
                                                                       TimeDev tm, ElemOut out,
                                                                       const uint8_t *slot8, const uint16_t *slot16) {
   using L = Layout<PHYS, DIM>;
   constexpr int NS = L::NS, NN = 1 << DIM, GEO = geo_size<DIM>(), NG = kEngineThreads / TPE;
   extern __shared__ double smem[];
-  const int n = vl.n_tot, NQ = vl.nq, tid = threadIdx.x, group = tid / TPE, gt = tid % TPE;
+  const int NQ = NQ1 ? (DIM == 2 ? NQ1 * NQ1 : NQ1 * NQ1 * NQ1) : vl.nq;
+  const int n = vl.n_tot, tid = threadIdx.x, group = tid / TPE, gt = tid % TPE;
   auto sync = [&]() {
     if constexpr (TPE == 64) wave_lds_sync();
     else __syncthreads();
   };
   double *tab = smem;
-  double *gbase = tab + vl.tables_size + (size_t)group * engine_group_doubles(vl, GEO);
+  double *gbase = tab + vl.tables_size + group * (int)engine_group_doubles(vl, GEO);
   double *s_P = gbase;  // first: read as 16-byte vectors
   double *s_Ch = s_P + NQ * NS * kPanelRows;
   double *s_Uh = s_Ch + NQ * NS * NS, *s_Udh = s_Uh + NQ * NS, *s_Fh = s_Udh + NQ * NS;
@@ -231,9 +234,10 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
       int v = 0;
       while (m >= vl.slotptr[v + 1]) ++v;
       const int sl = m - vl.slotptr[v], card = vl.card[v];
-      const double *T = tab + vl.table_off[v] + ((size_t)q * vl.nslot[v] + sl) * vl.cardpad[v];
+      const double *T = tab + vl.table_off[v] + (q * vl.nslot[v] + sl) * vl.cardpad[v];
       const double *uu = s_u + vl.varptr[v], *ud = s_ud + vl.varptr[v];
       double a = 0.0, ad = 0.0;
+#pragma unroll 4
       for (int dof = 0; dof < card; ++dof) {
         a += uu[dof] * T[dof];
         ad += ud[dof] * T[dof];
@@ -301,8 +305,16 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
       const int ns = vl.nslot[v], sp = vl.slotptr[v], cp = vl.cardpad[v];
       const double *T = tab + vl.table_off[v] + (f - vl.varptr[v]);
       double r = 0.0;
-      for (int q = 0; q < NQ; ++q)
-        for (int sl = 0; sl < ns; ++sl) r += T[((size_t)q * ns + sl) * cp] * s_Fh[q * NS + sp + sl];
+      if (ns == 1) {
+#pragma unroll 4
+        for (int q = 0; q < NQ; ++q) r += T[q * cp] * s_Fh[q * NS + sp];
+      } else {
+#pragma unroll 3
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+          for (int sl = 0; sl < 1 + DIM; ++sl) r += T[(q * (1 + DIM) + sl) * cp] * s_Fh[q * NS + sp + sl];
+        }
+      }
       r *= s_sgn[f];
       const int row = s_row[f];
       if (out.local_res) {
@@ -315,6 +327,7 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
     // ---- 5. Jacobian: panels of 16 rows; P[(q,m)][r] = T^(i_r,q) . C^(q)[:,m]; then 2x4 register tiles over
     //         (row pair, 4 dofs of one column variable): J[i][j] = sum_(q,s) P[(q, sp_j+s)][i] T^[q][s][j] ----
     if (out.compute_jacobian) {
+      double *lj_e = out.local_J ? out.local_J + (size_t)(e - out.local_base) * n * n : nullptr;
       int ntile_cols = 0;  // column quads, enumerated variable by variable
       for (int v = 0; v < vl.nvars; ++v) ntile_cols += vl.cardpad[v] >> 2;
       for (int i0 = 0; i0 < n; i0 += kPanelRows) {
@@ -324,11 +337,12 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
           if (i < n) while (i >= vl.varptr[vi + 1]) ++vi;
           const int ns = vl.nslot[vi], sp = vl.slotptr[vi], cp = vl.cardpad[vi];
           const double *Ti = tab + vl.table_off[vi] + (i < n ? i - vl.varptr[vi] : 0);
+#pragma unroll 4
           for (int qm = gt / kPanelRows; qm < NQ * NS; qm += TPE / kPanelRows) {
             const int q = qm / NS, m = qm - q * NS;
             double a = 0.0;
             if (i < n) {
-              const double *T = Ti + (size_t)q * ns * cp;
+              const double *T = Ti + q * ns * cp;
               const double *C = s_Ch + (q * NS + sp) * NS + m;
               if (ns == 1) {
                 a = T[0] * C[0];
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
           while (cq >= (vl.cardpad[vj] >> 2)) { cq -= vl.cardpad[vj] >> 2; ++vj; }
           const int nsj = vl.nslot[vj], spj = vl.slotptr[vj], cpj = vl.cardpad[vj];
           const double *T = tab + vl.table_off[vj] + 4 * cq;
-          const double *Pp = s_P + (size_t)spj * kPanelRows + 2 * rp;
+          const double *Pp = s_P + spj * kPanelRows + 2 * rp;
           double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
           auto kstep = [&](const double *Pk, const double *Tk) {
             const double2 a = *reinterpret_cast<const double2 *>(Pk);
@@ -359,12 +373,12 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
           };
           if (nsj == 1) {
 #pragma unroll 4
-            for (int q = 0; q < NQ; ++q) kstep(Pp + (size_t)q * NS * kPanelRows, T + (size_t)q * cpj);
+            for (int q = 0; q < NQ; ++q) kstep(Pp + q * NS * kPanelRows, T + q * cpj);
           } else {
-#pragma unroll 2
+#pragma unroll 3
             for (int q = 0; q < NQ; ++q) {
-              const double *Tq = T + (size_t)q * (1 + DIM) * cpj;
-              const double *Pq = Pp + (size_t)q * NS * kPanelRows;
+              const double *Tq = T + q * (1 + DIM) * cpj;
+              const double *Pq = Pp + q * NS * kPanelRows;
 #pragma unroll
               for (int sl = 0; sl < 1 + DIM; ++sl) kstep(Pq + sl * kPanelRows, Tq + sl * cpj);
             }
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
               const int j = vl.varptr[vj] + dofj, pos_j = s_pos[j];
               const double a = acc[x][y] * s_sgn[i] * s_sgn[j];
               if (out.local_J) {
-                double *lj = out.local_J + ((size_t)(e - out.local_base) * n + pos_i) * n + pos_j;
+                double *lj = lj_e + (pos_i * n + pos_j);
                 *lj = out.local_store ? a : *lj + a;
               }
               if (to_crs) {
@@ -436,8 +450,16 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kEngineThreads), lds, stream, b, vl, ppd, tm, out, s8, s16);
     MHA_HIP(hipGetLastError());
   };
-  if (small) go(point_engine_kernel<DIM, PHYS, 64>);
-  else go(point_engine_kernel<DIM, PHYS, 256>);
+  const int nq1 = (vl.nq == (DIM == 2 ? 4 : 8)) ? 2 : (vl.nq == (DIM == 2 ? 9 : 27)) ? 3 : 0;
+  if (small) {
+    if (nq1 == 2) go(point_engine_kernel<DIM, PHYS, 64, 2>);
+    else if (nq1 == 3) go(point_engine_kernel<DIM, PHYS, 64, 3>);
+    else go(point_engine_kernel<DIM, PHYS, 64, 0>);
+  } else {
+    if (nq1 == 2) go(point_engine_kernel<DIM, PHYS, 256, 2>);
+    else if (nq1 == 3) go(point_engine_kernel<DIM, PHYS, 256, 3>);
+    else go(point_engine_kernel<DIM, PHYS, 256, 0>);
+  }
 }
 
 }  // namespace

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT.$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python $GRAFT_REPO_ROOT/${PMC_PROG:-bench.py} ${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline} > $OUT.$name.log 2>&1 || echo "pass $name failed"
 }
 mkdir -p $OUT
 run inst SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES
