@@ -181,6 +181,7 @@ int orc_assemble_thermal_boundary(const orc_thermal_bnd_args *a);
 #define ORC_PHYS_THERMAL 1
 #define ORC_PHYS_POROUS_MIXED 2
 #define ORC_PHYS_NAVIERSTOKES 3
+#define ORC_PHYS_SHALLOWWATER_HYBRIDIZED 4
 #define ORC_MAX_VARS 8
 #define ORC_MAX_FUNCS 8
 int orc_basis_card(int dim, int type, int order);
@@ -250,6 +251,21 @@ int orc_assemble_block_boundary(const orc_block_args *a);
 /* HDIV side basis of boundary entries: basis[nb][n][nqs][dim] = J phi/detJ at the side points (with orientation) */
 int orc_physical_side_basis_hdiv(int dim, int qdeg, int nb, const double *nodes, const int *belem, const int *bside,
                                  const signed char *orient, int orient_stride, int orient_off, double *basis);
+
+/* ---- shallowwaterHybridized, point level (mrhyde_oracle_swhdg.c) ------------------------------------------------
+ * State order H, Hux[, Huy]; matrices row-major; dim = 1 or 2.  Each function cites the reference lines in its
+ * definition; all are pinned by unit_tests/physics/shallowwaterHybridized.cpp.  The volume residual of the module
+ * ((v, dS/dt) - (grad v, F(S)) - (v, source), :113-184) runs through orc_assemble_block with
+ * ORC_PHYS_SHALLOWWATER_HYBRIDIZED: variables H, Hux, Huy (HGRAD), functions {source H, source Hux, source Huy},
+ * params {g}.                                                                                                   */
+void orc_swh_matvec(int n, const double *A, const double *x, double *y);
+void orc_swh_eigendecomp(int dim, const double *Shat, const double *nrm, double g, double *L, double *lam, double *R);
+void orc_swh_flux_vector(int dim, const double *S, double g, double *F);
+void orc_swh_stab_term(int dim, const double *S, const double *Shat, const double *nrm, double g, int roe, double *out);
+void orc_swh_boundary_term(int dim, int type, const double *S, const double *Shat, const double *Sinf,
+                           const double *nrm, double g, double *out);
+void orc_swh_interface_flux(int dim, int side_type, int roe, const double *S, const double *Shat, const double *Sinf,
+                            const double *nrm, double g, double *out);
 
 #ifdef __cplusplus
 }

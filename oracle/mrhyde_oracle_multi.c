@@ -621,6 +621,42 @@ static void thermal_volume(const blk_ctx *c, size_t e, ad_t *res) {
   for (int d = 0; d < dim; ++d) free(dT[d]);
 }
 
+/* shallowwaterHybridized::volumeResidual (shallowwaterHybridized.cpp:113-184) with computeFluxVector(false) (:409-480):
+ * res += S_t v w - (F_x dv/dx + F_y dv/dy + source v) w, per equation; params[0] = g */
+static void swh_volume(const blk_ctx *c, size_t e, ad_t *res) {
+  const orc_block_args *a = c->a;
+  const int dim = a->dim, nq = c->nq, nv = dim + 1;
+  const double g = a->params[0];
+  ad_t *S[3], *St[3];
+  for (int i = 0; i < nv; ++i) {
+    S[i] = malloc(sizeof(ad_t) * nq); St[i] = malloc(sizeof(ad_t) * nq);
+    eval_field(c, i, F_VAL, 0, S[i]);
+    eval_field(c, i, F_DOT, 0, St[i]);
+  }
+  for (int pt = 0; pt < nq; ++pt) {
+    const double w = c->wts[pt], *x = c->ip + (size_t)pt * dim;
+    const ad_t *H = &S[0][pt], *Hux = &S[1][pt], *Huy = &S[2][pt];
+    ad_t F[3][2];
+    ad_t hh = ad_scale(ad_mul(H, H), 0.5 * g);
+    ad_t uu = ad_mul(Hux, Hux), uv = ad_mul(Hux, Huy), vv = ad_mul(Huy, Huy);
+    F[0][0] = *Hux; F[0][1] = *Huy;
+    F[1][0] = ad_add(ad_div(&uu, H), &hh); F[1][1] = ad_div(&uv, H);
+    F[2][0] = ad_div(&uv, H); F[2][1] = ad_add(ad_div(&vv, H), &hh);
+    for (int i = 0; i < nv; ++i) {
+      const double src = eval_func(&a->funcs[i], dim, e, pt, nq, x);
+      const int n = c->varptr[i + 1] - c->varptr[i];
+      for (int dof = 0; dof < n; ++dof) {
+        const int pos = a->offsets[c->varptr[i] + dof];
+        const size_t o = (size_t)dof * nq + pt;
+        res_add(res, pos, &St[i][pt], c->basis[i][o] * w);
+        for (int d = 0; d < dim; ++d) res_add(res, pos, &F[i][d], -c->grad[i][o * dim + d] * w);
+        res[pos].v[0] += -src * c->basis[i][o] * w;
+      }
+    }
+  }
+  for (int i = 0; i < nv; ++i) { free(S[i]); free(St[i]); }
+}
+
 static int ctx_init(blk_ctx *c, const orc_block_args *a) {
   int n1;
   memset(c, 0, sizeof(*c));
@@ -720,6 +756,7 @@ int orc_assemble_block(const orc_block_args *a) {
     if (a->physics == ORC_PHYS_POROUS_MIXED) porous_volume(&c, e, res);
     else if (a->physics == ORC_PHYS_NAVIERSTOKES) ns_volume(&c, e, res);
     else if (a->physics == ORC_PHYS_THERMAL) thermal_volume(&c, e, res);
+    else if (a->physics == ORC_PHYS_SHALLOWWATER_HYBRIDIZED && a->dim == 2) swh_volume(&c, e, res);
     else { free(res); ctx_free(&c); return -2; }
     scatter(&c, e, res);
   }

@@ -530,3 +530,70 @@ def physical_side_basis_hdiv(dim, qdeg, nodes, belem, bside, orient=None):
                                             _d(out))
     assert rc == 0, rc
     return out
+
+
+# ---- shallowwaterHybridized, point level ---------------------------------------------------------------------------
+PHYS_SHALLOWWATER_HYBRIDIZED = 4
+PHYS_FUNCS[PHYS_SHALLOWWATER_HYBRIDIZED] = ["source H", "source Hux", "source Huy"]
+PHYS_DEFAULTS[PHYS_SHALLOWWATER_HYBRIDIZED] = [0.0, 0.0, 0.0]
+
+
+def swh_eigendecomp(dim, Shat, nrm, g=9.81):
+    nv = dim + 1
+    L, lam, R = np.zeros((nv, nv)), np.zeros(nv), np.zeros((nv, nv))
+    Shat, nrm = np.ascontiguousarray(Shat, dtype=np.float64), np.ascontiguousarray(nrm, dtype=np.float64)
+    f = lib().orc_swh_eigendecomp
+    f.restype = None
+    f.argtypes = [C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp]
+    f(dim, _d(Shat), _d(nrm), g, _d(L), _d(lam), _d(R))
+    return L, lam, R
+
+
+def swh_flux_vector(dim, S, g=9.81):
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    F = np.zeros((dim + 1, dim))
+    f = lib().orc_swh_flux_vector
+    f.restype = None
+    f.argtypes = [C.c_int, _dp, C.c_double, _dp]
+    f(dim, _d(S), g, _d(F))
+    return F
+
+
+def swh_stab_term(dim, S, Shat, nrm, g=9.81, roe=True):
+    S, Shat, nrm = (np.ascontiguousarray(a, dtype=np.float64) for a in (S, Shat, nrm))
+    out = np.zeros(dim + 1)
+    f = lib().orc_swh_stab_term
+    f.restype = None
+    f.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, _dp]
+    f(dim, _d(S), _d(Shat), _d(nrm), g, int(roe), _d(out))
+    return out
+
+
+def swh_boundary_term(dim, btype, S, Shat, Sinf, nrm, g=9.81):
+    S, Shat, Sinf, nrm = (np.ascontiguousarray(a, dtype=np.float64) for a in (S, Shat, Sinf, nrm))
+    out = np.zeros(dim + 1)
+    f = lib().orc_swh_boundary_term
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, _dp]
+    f(dim, btype, _d(S), _d(Shat), _d(Sinf), _d(nrm), g, _d(out))
+    return out
+
+
+def swh_interface_flux(dim, side_type, roe, S, Shat, Sinf, nrm, g=9.81):
+    S, Shat, Sinf, nrm = (np.ascontiguousarray(a, dtype=np.float64) for a in (S, Shat, Sinf, nrm))
+    out = np.zeros(dim + 1)
+    f = lib().orc_swh_interface_flux
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, _dp]
+    f(dim, side_type, int(roe), _d(S), _d(Shat), _d(Sinf), _d(nrm), g, _d(out))
+    return out
+
+
+def swh_matvec(A, x):
+    A, x = np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(len(x))
+    f = lib().orc_swh_matvec
+    f.restype = None
+    f.argtypes = [C.c_int, _dp, _dp, _dp]
+    f(len(x), _d(A), _d(x), _d(y))
+    return y

@@ -1,0 +1,91 @@
+"""Oracle restatement of shallowwaterHybridized's point functions against the reference's own unit-test values
+(tests/golden/swhdg_unit_values.py) and consistency of the pieces (A = R Lambda L, flux Jacobian)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import swhdg_unit_values as V  # noqa: E402
+
+TOL = 1e-12  # relative; the golds carry 15-17 significant digits
+
+
+def close(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+
+
+def test_matvec(oracle):
+    assert np.array_equal(oracle.swh_matvec(V.MATVEC["A"], V.MATVEC["x"]), np.array(V.MATVEC["y"], dtype=float))
+
+
+def test_eigendecomposition_golds(oracle):
+    L, lam, R = oracle.swh_eigendecomp(1, V.EV1D["Shat"], [1.0], V.G)
+    assert close(lam, V.EV1D["lam"]) and close(L, V.EV1D["L"]) and close(R, V.EV1D["R"])
+    L, lam, R = oracle.swh_eigendecomp(2, V.EV2D["Shat"], V.EV2D["n"], V.G)
+    assert close(lam, V.EV2D["lam"]) and close(L, V.EV2D["L"]) and close(R, V.EV2D["R"])
+    # L R = I and R diag(lam) L = d(F.n)/dS (finite differences of the flux vector)
+    assert close(L @ R, np.eye(3))
+    A = R @ np.diag(lam) @ L
+    S0, n = np.array(V.EV2D["Shat"]), np.array(V.EV2D["n"])
+    fd = np.zeros((3, 3))
+    for j in range(3):
+        d = np.zeros(3)
+        d[j] = 1e-6 * max(1.0, abs(S0[j]))
+        fd[:, j] = ((oracle.swh_flux_vector(2, S0 + d, V.G) - oracle.swh_flux_vector(2, S0 - d, V.G)) @ n) / (2 * d[j])
+    assert np.abs(A - fd).max() < 1e-6 * np.abs(A).max()
+
+
+def test_flux_vector_golds(oracle):
+    F = oracle.swh_flux_vector(2, V.FLUX["S"], V.G)
+    assert close(F[:, 0], V.FLUX["Fx"]) and close(F[:, 1], V.FLUX["Fy"])
+    F = oracle.swh_flux_vector(2, V.FLUX["Shat"], V.G)
+    assert close(F[:, 0], V.FLUX["Fx_hat"]) and close(F[:, 1], V.FLUX["Fy_hat"])
+
+
+def test_stabilization_golds(oracle):
+    s = V.STAB
+    assert close(oracle.swh_stab_term(2, s["S"], s["Shat"], s["n"], V.G, roe=True), s["roe"])
+    assert close(oracle.swh_stab_term(2, s["S"], s["Shat"], s["n"], V.G, roe=False), s["maxEV"])
+
+
+def test_boundary_term_gold(oracle):
+    b = V.BOUND
+    assert close(oracle.swh_boundary_term(2, 1, b["S"], b["Shat"], b["Sinf"], b["n"], V.G), b["farfield"])
+    # slip (no reference value): depth jump, tangential velocity jump, zero normal velocity of the state part
+    out = oracle.swh_boundary_term(2, 2, b["S"], b["Shat"], b["Sinf"], b["n"], V.G)
+    S, Sh, n = np.array(b["S"]), np.array(b["Shat"]), np.array(b["n"])
+    u = S[1:] / S[0]
+    assert close(out[0], S[0] - Sh[0]) and close(out[1:], (u - (u @ n) * n) - Sh[1:] / Sh[0])
+    # interface flux = F(Shat).n + Stab (S - Shat)
+    f = oracle.swh_interface_flux(2, 0, True, b["S"], b["Shat"], b["Sinf"], b["n"], V.G)
+    ref = oracle.swh_flux_vector(2, b["Shat"], V.G) @ n + oracle.swh_stab_term(2, b["S"], b["Shat"], b["n"], V.G, True)
+    assert close(f, ref)
+
+
+def test_volume_residual_is_consistent(oracle):
+    """shallowwaterHybridized::volumeResidual through the AD-array restatement: Jacobian = derivative of the residual,
+    constant state with zero sources gives a residual that sums to zero per equation (sum_i grad N_i = 0)."""
+    import scipy.sparse as sp
+    H = oracle.HGRAD
+    m = oracle.mesh_multi(2, (4, 3), [H, H, H], [1, 1, 1])
+    rng = np.random.default_rng(2)
+    u = rng.uniform(-1, 1, m["ndof"])
+    u[m["dof_var"] == 0] = rng.uniform(1.0, 2.0, (m["dof_var"] == 0).sum())  # H > 0
+    tr = dict(u_prev=rng.uniform(-1, 1, (m["ndof"], 1)), u_stage=u[:, None].copy(), stage=0,
+              butcher_A=np.array([[1.0]]), butcher_b=np.array([1.0]), bdf=np.array([1.0, -1.0]), dt=0.1)
+    kw = dict(funcs={"source H": 0.2, "source Hux": ("sinprod", 1.0, [1.0, 2.0])}, params=[9.81], transient=tr)
+    a = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, u, **kw)
+    J = sp.csr_matrix((a["crs_vals"], a["colind"], a["rowptr"]), shape=(m["ndof"],) * 2)
+    du = 1e-6 * rng.uniform(-1, 1, m["ndof"])
+    b = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, u + du,
+                              **dict(kw, transient=dict(tr, u_stage=(u + du)[:, None].copy())))
+    lin = -(J @ du)
+    assert np.abs((b["res"] - a["res"]) - lin).max() < 1e-4 * np.abs(lin).max()
+    uc = np.zeros(m["ndof"])
+    for v, val in enumerate((1.7, 0.4, -0.3)):
+        uc[m["dof_var"] == v] = val
+    c = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, uc, params=[9.81])
+    for v in range(3):
+        assert abs(c["res"][m["dof_var"] == v].sum()) < 1e-12
