@@ -106,6 +106,8 @@ int mha_get_graph(mha_context *ctx, int32_t *rowptr_host, int32_t *colind_host);
 #define MHA_PHYSICS_THERMAL 1        /* src/physics/thermal.cpp: e (HGRAD)                                   */
 #define MHA_PHYSICS_POROUS_MIXED 2   /* src/physics/porousMixed.cpp: p (HVOL 0), u (HDIV 1)                   */
 #define MHA_PHYSICS_NAVIERSTOKES 3   /* src/physics/navierstokes.cpp: ux, pr, uy[, uz] (HGRAD)                */
+#define MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED 4 /* src/physics/shallowwaterHybridized.cpp: H, Hux, Huy (HGRAD, 2-D):
+                                                volumeResidual only; the side terms are mha_swhdg_side_terms */
 int mha_physics_select(mha_context *ctx, int physics_id);
 #define MHA_FUNC_CONSTANT 0
 #define MHA_FUNC_IP_ARRAY 1     /* dev pointer to [E][numip] f64                    */
@@ -113,7 +115,8 @@ int mha_physics_select(mha_context *ctx, int physics_id);
 /* thermal: "thermal source","thermal diffusion","specific heat","density" (thermal.cpp:52-63);
  * porousMixed: "source","Kinv_xx","Kinv_yy","Kinv_zz","total_mobility" (porousMixed.cpp:141-151);
  * navierstokes: "source ux","source pr","source uy","source uz","density","viscosity"
- * (navierstokes.cpp:68-74); or a boundary
+ * (navierstokes.cpp:68-74); shallowwaterHybridized: "source H","source Hux","source Huy"
+ * (shallowwaterHybridized.cpp:84-88); or a boundary
  * data function "Neumann e <sidename>" / "Dirichlet e <sidename>" (see boundary groups)    */
 int mha_set_function(mha_context *ctx, const char *name, int kind, double amp, const double *freq3,
                      const double *ip_array_dev);
@@ -215,8 +218,31 @@ int mha_boundary_view(mha_context *ctx, int group_id, const char *name, void **d
 /* scalar settings of the physics module; thermal: "form_param" (thermal.cpp:35, default 1:
  * symmetric Nitsche; -1 the non-symmetric variant); navierstokes: "useSUPG", "usePSPG"
  * (navierstokes.cpp:45-46) and "fix_uz_offsets": the reference scatters the 3-D uz momentum
- * block through uy's offsets (navierstokes.cpp:688); 0 (default) reproduces that, 1 uses uz's. */
+ * block through uy's offsets (navierstokes.cpp:688); 0 (default) reproduces that, 1 uses uz's;
+ * shallowwaterHybridized: "g" (shallowwaterHybridized.cpp:72, default 9.81).                     */
 int mha_set_physics_parameter(mha_context *ctx, const char *name, double value);
+
+/* ---- shallowwaterHybridized side terms ---------------------------------------------------
+ * replaces: computeFluxVector(on_side) :409-480, eigendecompFluxJacobian :765-823,
+ * computeStabilizationTerm :487-588, computeBoundaryTerm :595-758 and computeFlux :270-368 of
+ * src/physics/shallowwaterHybridized.cpp, evaluated at npts side integration points (2-D; state
+ * order H, Hux, Huy).  S = interior state ("H","Hux","Huy" side fields), Shat = trace state
+ * ("aux H", ...), normals[npts][2], Sinf[npts][3] = "Far-field <var> <side>" (Far-field only).
+ * Outputs (any may be NULL): fluxvec[npts][3][2] = fluxes_side; term[npts][3] = stab_bound_side
+ * (stabilisation term for MHA_SWH_INTERFACE, boundary term otherwise); iflux[npts][3] = what
+ * computeFlux stores in wkset->flux; d_iflux_dS / d_iflux_dShat [npts][3][3] = its derivatives
+ * (the SFad part of the reference's result), by forward AD on the device.  All pointers device.
+ * Stateless: no context; hip_stream may be NULL.                                              */
+#define MHA_SWH_INTERFACE 0
+#define MHA_SWH_FARFIELD 1
+#define MHA_SWH_SLIP 2
+int mha_swhdg_side_terms(int side_type, int roe_stabilization, double g, int64_t npts, const double *S_dev,
+                         const double *Shat_dev, const double *normals_dev, const double *Sinf_dev,
+                         double *fluxvec_dev, double *term_dev, double *iflux_dev, double *d_iflux_dS_dev,
+                         double *d_iflux_dShat_dev, void *hip_stream);
+/* L[npts][3][3], lam[npts][3], R[npts][3][3] (row-major) of the normal flux Jacobian at Shat */
+int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat_dev, const double *normals_dev,
+                          double *L_dev, double *lam_dev, double *R_dev, void *hip_stream);
 
 /* ---- structured mesh helper (input generation, not part of the hot path) ------
  * 2-D order 1 = SimpleMeshManager_Rectangle (src/tools/simplemeshmanager.hpp:639-675)

@@ -23,10 +23,11 @@ EXPORTS = [
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
-    "mha_set_orientation",
+    "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp",
 ]
+SWH_INTERFACE, SWH_FARFIELD, SWH_SLIP = 0, 1, 2
 BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
-PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3}
+PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3, "shallowwaterHybridized": 4}
 PATH_POINT_ENGINE = 4
 PATH_ROW_GATHER = 5
 BC_NEUMANN, BC_WEAK_DIRICHLET = 1, 2
@@ -95,6 +96,8 @@ def load_library():
         _lib.mha_boundary_view.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mha_set_physics_parameter.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         _lib.mha_set_orientation.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_swhdg_side_terms.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int64] + [C.c_void_p] * 10
+        _lib.mha_swhdg_eigendecomp.argtypes = [C.c_double, C.c_int64] + [C.c_void_p] * 6
     return _lib
 
 
@@ -121,6 +124,30 @@ def _ptr(t):
         return None
     assert t.is_cuda and t.is_contiguous(), "device arguments must be contiguous CUDA tensors"
     return C.c_void_p(t.data_ptr())
+
+
+def swhdg_side_terms(side_type, roe, g, S, Shat, normals, Sinf=None, want=("fluxvec", "term", "iflux", "d_dS", "d_dShat")):
+    """shallowwaterHybridized side terms at the points of CUDA tensors S, Shat [npts,3], normals [npts,2] (mha_swhdg_side_terms).
+    -> dict of CUDA tensors."""
+    import torch
+    npts = S.shape[0]
+    shapes = dict(fluxvec=(npts, 3, 2), term=(npts, 3), iflux=(npts, 3), d_dS=(npts, 3, 3), d_dShat=(npts, 3, 3))
+    out = {k: torch.zeros(shapes[k], dtype=torch.float64, device=S.device) for k in want}
+    _check(load_library().mha_swhdg_side_terms(side_type, int(roe), float(g), npts, _ptr(S), _ptr(Shat), _ptr(normals),
+                                               _ptr(Sinf), _ptr(out.get("fluxvec")), _ptr(out.get("term")),
+                                               _ptr(out.get("iflux")), _ptr(out.get("d_dS")), _ptr(out.get("d_dShat")),
+                                               None))
+    return out
+
+
+def swhdg_eigendecomp(g, Shat, normals):
+    import torch
+    npts = Shat.shape[0]
+    L = torch.zeros((npts, 3, 3), dtype=torch.float64, device=Shat.device)
+    lam = torch.zeros((npts, 3), dtype=torch.float64, device=Shat.device)
+    R = torch.zeros_like(L)
+    _check(load_library().mha_swhdg_eigendecomp(float(g), npts, _ptr(Shat), _ptr(normals), _ptr(L), _ptr(lam), _ptr(R), None))
+    return L, lam, R
 
 
 def mesh_structured(dim, order, ncell, lo=None, hi=None):

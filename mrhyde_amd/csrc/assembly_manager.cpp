@@ -258,6 +258,9 @@ void AssemblyManager::selectPhysics(int physics_id) {
     MHA_REQUIRE(dim_ == 2 ? expect({MHA_BASIS_HGRAD, MHA_BASIS_HGRAD, MHA_BASIS_HGRAD})
                           : expect({MHA_BASIS_HGRAD, MHA_BASIS_HGRAD, MHA_BASIS_HGRAD, MHA_BASIS_HGRAD}),
                 MHA_ERR_INVALID, "navierstokes needs the HGRAD variables ux, pr, uy[, uz], in that order");
+  else if (physics_id == MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED)
+    MHA_REQUIRE(dim_ == 2 && expect({MHA_BASIS_HGRAD, MHA_BASIS_HGRAD, MHA_BASIS_HGRAD}), MHA_ERR_INVALID,
+                "shallowwaterHybridized needs the HGRAD variables H, Hux, Huy in 2-D");
   physics_id_ = physics_id;
   physics_ = import_physics(physics_id);
   physics_->defineFunctions(functions_);

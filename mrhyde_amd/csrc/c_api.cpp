@@ -194,6 +194,35 @@ int mha_set_physics_parameter(mha_context *ctx, const char *name, double value) 
   });
 }
 
+int mha_swhdg_side_terms(int side_type, int roe_stabilization, double g, int64_t npts, const double *S, const double *Shat,
+                         const double *normals, const double *Sinf, double *fluxvec, double *term, double *iflux,
+                         double *d_iflux_dS, double *d_iflux_dShat, void *hip_stream) {
+  return guarded([&] {
+    MHA_REQUIRE(side_type == MHA_SWH_INTERFACE || side_type == MHA_SWH_FARFIELD || side_type == MHA_SWH_SLIP,
+                MHA_ERR_INVALID, "unknown side type " << side_type);
+    MHA_REQUIRE(npts >= 0 && (npts == 0 || (S && Shat && normals)), MHA_ERR_INVALID, "null state / normal arrays");
+    MHA_REQUIRE(side_type != MHA_SWH_FARFIELD || Sinf, MHA_ERR_INVALID, "Far-field sides need the far-field state");
+    MHA_REQUIRE(g > 0.0, MHA_ERR_INVALID, "g must be positive");
+    mha::SwhSideArgs a;
+    a.npts = npts; a.side_type = side_type; a.roe = roe_stabilization ? 1 : 0; a.g = g;
+    a.S = S; a.Shat = Shat; a.normals = normals; a.Sinf = Sinf;
+    a.fluxvec = fluxvec; a.term = term; a.iflux = iflux; a.d_dS = d_iflux_dS; a.d_dShat = d_iflux_dShat;
+    mha::launch_swhdg_side(a, static_cast<hipStream_t>(hip_stream));
+  });
+}
+
+int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat, const double *normals, double *L, double *lam,
+                          double *R, void *hip_stream) {
+  return guarded([&] {
+    MHA_REQUIRE(npts >= 0 && (npts == 0 || (Shat && normals && L && lam && R)), MHA_ERR_INVALID, "null argument");
+    MHA_REQUIRE(g > 0.0, MHA_ERR_INVALID, "g must be positive");
+    mha::SwhSideArgs a;
+    a.npts = npts; a.g = g; a.S = Shat; a.Shat = Shat; a.normals = normals;
+    a.L = L; a.lam = lam; a.R = R;
+    mha::launch_swhdg_side(a, static_cast<hipStream_t>(hip_stream));
+  });
+}
+
 int mha_mesh_sizes(int dim, int order, const int *ncell, int *nverts, int *nelem, int64_t *ndof) {
   return guarded([&] {
     MHA_REQUIRE(ncell && nverts && nelem && ndof, MHA_ERR_INVALID, "null argument");

@@ -152,6 +152,19 @@ struct RowGatherDev {
   int slot_bytes = 1, max_row = 0;
 };
 
+// shallowwaterHybridized side terms at npts side integration points (kernels/swhdg_side.hip); state order H, Hux, Huy
+struct SwhSideArgs {
+  int64_t npts = 0;
+  int side_type = 0, roe = 1;  // MHA_SWH_*; Roe-like (1) or max-eigenvalue (0) stabilisation
+  double g = 9.81;
+  const double *S = nullptr, *Shat = nullptr, *normals = nullptr, *Sinf = nullptr;  // [npts][3], [npts][3], [npts][2], [npts][3]
+  double *fluxvec = nullptr;   // [npts][3][2]  F(Shat)
+  double *term = nullptr;      // [npts][3]     stabilisation term (interface) or boundary term
+  double *iflux = nullptr;     // [npts][3]     wkset->flux of computeFlux
+  double *d_dS = nullptr, *d_dShat = nullptr;  // [npts][3][3] derivatives of iflux
+  double *L = nullptr, *lam = nullptr, *R = nullptr;  // eigendecomposition at Shat, [npts][3][3], [npts][3], [npts][3][3]
+};
+
 // Destination of the row-owner kernels.
 struct RowOut {
   double *res = nullptr;

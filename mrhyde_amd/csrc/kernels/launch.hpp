@@ -63,6 +63,9 @@ void launch_porous_boundary(const BlockDev &b, const SideTablesDev &st, const Bo
 void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *local_J, const double *local_res,
                        double *res, double *vals, int overwrite, hipStream_t stream);
 
+// swhdg_side.hip: shallowwaterHybridized side terms + derivatives, one thread per side point
+void launch_swhdg_side(const SwhSideArgs &a, hipStream_t stream);
+
 // point_engine.hip: multi-variable blocks, any physics module stated as a point function
 // slot: element-major CRS slot map (launch_build_elem_slot_map) or null for the column search
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,

@@ -113,12 +113,25 @@ __device__ __forceinline__ void navierstokes_point(const PointArgs<DIM> &a, Dual
   }
 }
 
+// shallowwaterHybridized (reference: src/physics/shallowwaterHybridized.cpp:113-184 with computeFluxVector(false)
+// :409-480); myvars {H, Hux, Huy} (2-D); functions {source H, source Hux, source Huy}; p = {g}
 template <int DIM>
-__device__ __forceinline__ void physics_point(const PointArgs<DIM> &a, Dual *F) {
-  switch (a.pp->physics) {
-    case MHA_PHYSICS_THERMAL: thermal_point<DIM>(a, F); break;
-    case MHA_PHYSICS_POROUS_MIXED: porous_point<DIM>(a, F); break;
-    default: navierstokes_point<DIM>(a, F); break;
+__device__ __forceinline__ void swhdg_point(const PointArgs<DIM> &a, Dual *F) {
+  static_assert(DIM >= 2, "");
+  constexpr int S = 1 + DIM;
+  const PhysParamsDev &pp = *a.pp;
+  const double g = pp.p[0];
+  const Dual H = a.U[0], Hux = a.U[S], Huy = a.U[2 * S];
+  const Dual hh = H * H * (0.5 * g);
+  Dual Fl[3][2];
+  Fl[0][0] = Hux; Fl[0][1] = Huy;
+  Fl[1][0] = Hux * Hux / H + hh; Fl[1][1] = Hux * Huy / H;
+  Fl[2][0] = Hux * Huy / H; Fl[2][1] = Huy * Huy / H + hh;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    F[i * S] = a.Ud[i * S] - eval_func<DIM>(pp.f[i], a.e, a.q, a.nq, a.x);  // (v, dS/dt) - (v, source)
+    F[i * S + 1] = -Fl[i][0];                                               // -(dv/dx, F_x)
+    F[i * S + 2] = -Fl[i][1];                                               // -(dv/dy, F_y)
   }
 }
 

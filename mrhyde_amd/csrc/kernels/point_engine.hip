@@ -52,6 +52,12 @@ struct Layout<MHA_PHYSICS_NAVIERSTOKES, DIM> {
   __host__ __device__ static constexpr int type(int) { return MHA_BASIS_HGRAD; }
 };
 
+template <int DIM>
+struct Layout<MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED, DIM> {
+  static constexpr int nvars = 3, NS = 3 * (1 + DIM);
+  __host__ __device__ static constexpr int type(int) { return MHA_BASIS_HGRAD; }
+};
+
 __host__ __device__ constexpr int slots_of(int type, int dim) { return type == MHA_BASIS_HVOL ? 1 : 1 + dim; }
 // slots that carry a time derivative: every value, not gradients / divergence
 __host__ __device__ constexpr bool value_like(int type, int s, int dim) {
@@ -281,6 +287,7 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
       pa.transient = tm.transient; pa.e = e; pa.q = q; pa.nq = NQ; pa.pp = &pp;
       if constexpr (PHYS == MHA_PHYSICS_THERMAL) thermal_point<DIM>(pa, F);
       else if constexpr (PHYS == MHA_PHYSICS_POROUS_MIXED) porous_point<DIM>(pa, F);
+      else if constexpr (PHYS == MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED) swhdg_point<DIM>(pa, F);
       else navierstokes_point<DIM>(pa, F);
 #pragma unroll
       for (int v = 0; v < L::nvars; ++v) {
@@ -475,6 +482,7 @@ void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysPa
     case 30 + MHA_PHYSICS_POROUS_MIXED: launch_typed<3, MHA_PHYSICS_POROUS_MIXED>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
     case 20 + MHA_PHYSICS_NAVIERSTOKES: launch_typed<2, MHA_PHYSICS_NAVIERSTOKES>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
     case 30 + MHA_PHYSICS_NAVIERSTOKES: launch_typed<3, MHA_PHYSICS_NAVIERSTOKES>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
+    case 20 + MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED: launch_typed<2, MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
     default: MHA_REQUIRE(false, MHA_ERR_INVALID, "no point-engine kernel for physics " << pp.physics << " in " << b.dim << "-D");
   }
 }

@@ -95,6 +95,19 @@ class navierstokes : public PhysicsBase {
   bool fix_uz_offsets = false;            // false reproduces navierstokes.cpp:688
 };
 
+// shallowwaterHybridized: HDG shallow water, interior unknowns H, Hux, Huy; the trace unknowns are the module's "aux"
+// variables (reference: src/physics/shallowwaterHybridized.hpp, .cpp:24-844).  volumeResidual runs on the point engine;
+// the side terms (computeFlux, boundaryResidual's fluxes) are the stateless batch entry point mha_swhdg_side_terms:
+// the workset-level aux-variable plumbing of the subgrid solver that feeds them is not built.
+class shallowwaterHybridized : public PhysicsBase {
+ public:
+  shallowwaterHybridized();
+  void defineFunctions(FunctionManager &fm) override;
+  void volumeResidual() override;
+  void setParameter(const std::string &name, double value) override;
+  double gravity = 9.81;  // settings "g" (shallowwaterHybridized.cpp:72)
+};
+
 // PhysicsImporter::import equivalent (reference: src/physics/physicsImporter.cpp:48-204)
 std::unique_ptr<PhysicsBase> import_physics(int physics_id);
 

@@ -162,10 +162,46 @@ void navierstokes::volumeResidual() {
   launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
 }
 
+// ---- shallowwaterHybridized --------------------------------------------------------------------------------------
+shallowwaterHybridized::shallowwaterHybridized() {
+  label = "shallowwaterHybridized";
+  myvars = {"H", "Hux", "Huy"};                // reference: shallowwaterHybridized.cpp:41-46
+  mybasistypes = {"HGRAD", "HGRAD", "HGRAD"};
+}
+
+// reference: shallowwaterHybridized::defineFunctions (:78-108): sources 0
+void shallowwaterHybridized::defineFunctions(FunctionManager &fm) {
+  functionManager = &fm;
+  auto constant = [](double v) { FuncDesc f; f.kind = MHA_FUNC_CONSTANT; f.amp = v; return f; };
+  for (const char *k : {"source H", "source Hux", "source Huy"})
+    if (!fm.has(k)) fm.addFunction(k, constant(0.0));
+}
+
+void shallowwaterHybridized::setParameter(const std::string &name, double value) {
+  if (name == "g") gravity = value;
+  else PhysicsBase::setParameter(name, value);
+}
+
+// reference: shallowwaterHybridized::volumeResidual (:113-184) as the point function swhdg_point
+void shallowwaterHybridized::volumeResidual() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "shallowwaterHybridized::volumeResidual called without a workset");
+  Workset &w = *wkset;
+  BlockDev b = w.dev;
+  b.e_begin = w.first_elem;
+  b.e_count = w.numElem;
+  PhysParamsDev pp;
+  pp.physics = MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED;
+  const char *names[3] = {"source H", "source Hux", "source Huy"};
+  for (int k = 0; k < 3; ++k) pp.f[k] = functionManager->evaluate(names[k]);
+  pp.p[0] = gravity;
+  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
+}
+
 std::unique_ptr<PhysicsBase> import_physics(int physics_id) {
   if (physics_id == MHA_PHYSICS_THERMAL) return std::unique_ptr<PhysicsBase>(new thermal());
   if (physics_id == MHA_PHYSICS_POROUS_MIXED) return std::unique_ptr<PhysicsBase>(new porousMixed());
   if (physics_id == MHA_PHYSICS_NAVIERSTOKES) return std::unique_ptr<PhysicsBase>(new navierstokes());
+  if (physics_id == MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED) return std::unique_ptr<PhysicsBase>(new shallowwaterHybridized());
   throw Error(MHA_ERR_INVALID, "unknown physics module id " + std::to_string(physics_id));
 }
 

@@ -1,0 +1,110 @@
+"""GPU parity of shallowwaterHybridized (the part built): the side point functions against the
+reference's own unit-test values and the oracle (with derivatives against finite differences of the oracle), and the
+volume residual on the point engine against the oracle's AD-array restatement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import swhdg_unit_values as V  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def close(a, b, tol=RTOL):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def dev(a):
+    return _torch().tensor(np.atleast_2d(np.asarray(a, dtype=np.float64)), device="cuda")
+
+
+def test_unit_test_values_on_device():
+    import mrhyde_amd
+    L, lam, R = mrhyde_amd.swhdg_eigendecomp(V.G, dev(V.EV2D["Shat"]), dev(V.EV2D["n"]))
+    assert close(lam.cpu()[0], V.EV2D["lam"]) and close(L.cpu()[0], V.EV2D["L"]) and close(R.cpu()[0], V.EV2D["R"])
+    s = V.STAB
+    out = mrhyde_amd.swhdg_side_terms(mrhyde_amd.api.SWH_INTERFACE, True, V.G, dev(s["S"]), dev(s["Shat"]), dev(s["n"]))
+    assert close(out["term"].cpu()[0], s["roe"])
+    out = mrhyde_amd.swhdg_side_terms(mrhyde_amd.api.SWH_INTERFACE, False, V.G, dev(s["S"]), dev(s["Shat"]), dev(s["n"]))
+    assert close(out["term"].cpu()[0], s["maxEV"])
+    f = V.FLUX
+    out = mrhyde_amd.swhdg_side_terms(mrhyde_amd.api.SWH_INTERFACE, True, V.G, dev(f["S"]), dev(f["Shat"]), dev([1.0, 0.0]))
+    assert close(out["fluxvec"].cpu()[0, :, 0], f["Fx_hat"]) and close(out["fluxvec"].cpu()[0, :, 1], f["Fy_hat"])
+    out = mrhyde_amd.swhdg_side_terms(mrhyde_amd.api.SWH_INTERFACE, True, V.G, dev(f["S"]), dev(f["S"]), dev([1.0, 0.0]))
+    assert close(out["fluxvec"].cpu()[0, :, 0], f["Fx"]) and close(out["fluxvec"].cpu()[0, :, 1], f["Fy"])
+    b = V.BOUND
+    out = mrhyde_amd.swhdg_side_terms(mrhyde_amd.api.SWH_FARFIELD, True, V.G, dev(b["S"]), dev(b["Shat"]), dev(b["n"]),
+                                      dev(b["Sinf"]))
+    assert close(out["term"].cpu()[0], b["farfield"]) and close(out["iflux"].cpu()[0], b["farfield"])
+
+
+@pytest.mark.parametrize("side_type,roe", [(0, True), (0, False), (1, True), (2, True)])
+def test_side_terms_match_oracle(oracle, side_type, roe):
+    torch = _torch()
+    import mrhyde_amd
+    rng = np.random.default_rng(41 + side_type)
+    npts = 500
+    S = np.column_stack([rng.uniform(0.5, 3.0, npts), rng.uniform(-4, 4, npts), rng.uniform(-4, 4, npts)])
+    Sh = S + rng.uniform(-0.2, 0.2, (npts, 3))
+    Sinf = np.column_stack([rng.uniform(0.5, 3.0, npts), rng.uniform(-2, 2, npts), rng.uniform(-2, 2, npts)])
+    th = rng.uniform(0, 2 * np.pi, npts)
+    n = np.column_stack([np.cos(th), np.sin(th)])
+    out = mrhyde_amd.swhdg_side_terms(side_type, roe, V.G, dev(S), dev(Sh), dev(n), dev(Sinf))
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for p in range(npts):
+        ref = oracle.swh_interface_flux(2, side_type, roe, S[p], Sh[p], Sinf[p], n[p], V.G)
+        assert close(out["iflux"][p], ref), p
+        assert close(out["fluxvec"][p], oracle.swh_flux_vector(2, Sh[p], V.G))
+        t = (oracle.swh_stab_term(2, S[p], Sh[p], n[p], V.G, roe) if side_type == 0 else
+             oracle.swh_boundary_term(2, side_type, S[p], Sh[p], Sinf[p], n[p], V.G))
+        assert close(out["term"][p], t)
+    # derivatives (forward AD on the device) against central differences of the oracle, away from the kinks of |.|
+    for p in range(0, npts, 25):
+        for which, key in ((0, "d_dS"), (1, "d_dShat")):
+            for j in range(3):
+                h = 1e-6
+                d = np.zeros(3)
+                d[j] = h
+                a = (S[p] + d, Sh[p]) if which == 0 else (S[p], Sh[p] + d)
+                b = (S[p] - d, Sh[p]) if which == 0 else (S[p], Sh[p] - d)
+                fd = (oracle.swh_interface_flux(2, side_type, roe, a[0], a[1], Sinf[p], n[p], V.G) -
+                      oracle.swh_interface_flux(2, side_type, roe, b[0], b[1], Sinf[p], n[p], V.G)) / (2 * h)
+                assert np.abs(out[key][p][:, j] - fd).max() < 2e-5 * max(1.0, np.abs(fd).max()), (p, key, j)
+
+
+@pytest.mark.parametrize("order,qdeg,ncell", [(1, 2, (5, 4)), (2, 4, (3, 3))])
+@pytest.mark.parametrize("transient", [False, True])
+def test_volume_residual_matches_oracle(oracle, order, qdeg, ncell, transient):
+    torch = _torch()
+    import mrhyde_amd
+    from test_multi_gpu import make_block, run_gpu, transient_state, warp
+    rng = np.random.default_rng(43)
+    H = oracle.HGRAD
+    m = warp(oracle.mesh_multi(2, ncell, [H, H, H], [order] * 3))
+    u = rng.uniform(-1, 1, m["ndof"])
+    u[m["dof_var"] == 0] = rng.uniform(1.0, 2.0, (m["dof_var"] == 0).sum())
+    tr = transient_state(rng, m["ndof"], u) if transient else None
+    if tr is not None:  # keep H of the seeded stage value positive
+        for k in ("u_prev", "u_stage"):
+            tr[k][m["dof_var"] == 0] = rng.uniform(1.0, 2.0, ((m["dof_var"] == 0).sum(), 2))
+    funcs = {"source H": 0.2, "source Hux": ("sinprod", 1.0, [1.0, 2.0]), "source Huy": -0.4}
+    ref = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, qdeg, u, funcs=funcs, params=[7.3], transient=tr,
+                                want_local=True)
+    blk = make_block(m, "shallowwaterHybridized", qdeg, graph=(ref["rowptr"], ref["colind"]))
+    for k, v in funcs.items():
+        blk.set_function(k, v)
+    blk.set_physics_parameter("g", 7.3)
+    out = run_gpu(blk, m, u, tr, len(ref["colind"]), local=True)
+    for k in ("crs_vals", "res", "local_J", "local_res"):
+        assert np.abs(out[k] - ref[k]).max() < RTOL * np.abs(ref[k]).max(), k
