@@ -17,14 +17,16 @@
 //   2 reference-slot fields U^(q) = sum_j u_j T^(j,q)
 //   3 one thread per (point, direction): the module's point function on Dual numbers -> one column of C^(q)
 //   4 residual rows
-//   5 Jacobian in panels of 16 rows: P = T^(i,.) C^ for the panel, then 2x4 register tiles (row pair x 4 dofs of one
-//     column variable) contract P with T^ -- the dense B^T C B product, operands read as 16-byte LDS vectors.
+//   5 Jacobian = the dense B^T C^ B product on the matrix cores (v_mfma_f64_16x16x4_f64): panels of 16 rows of one
+//     variable, P = T^(i,.) C^ with one MFMA per point, then 16x16 output tiles with K = points x slots of the column
+//     variable.  fp64 MFMA runs at the vector rate on gfx950; the gain is 1024 FMAs per two 8-byte LDS operands.
 // Output: dense local_J / local_res (updateJac / updateRes convention; the row-gather kernel turns them into CRS rows
 // without global atomics) or atomics into res / CRS through the element-major slot map.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -130,7 +132,7 @@ __device__ __forceinline__ void to_ref_T(int type, const double *phys, const dou
 #ifndef MHA_ENGINE_MINW
 #define MHA_ENGINE_MINW 2
 #endif
-constexpr int kEngineThreads = 256, kPanelRows = 16;
+constexpr int kEngineThreads = 512, kPanelRows = 16;
 
 // orders a wave's LDS writes before its later LDS reads (data private to the wave: no workgroup barrier needed)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -148,14 +150,14 @@ __host__ __device__ inline size_t engine_group_doubles(const VarLayoutDev &vl, i
   return (3 * n + NQ * geo + 3 * NQ * NS + NQ * NS * NS + NQ * NS * kPanelRows + n + 1) & ~size_t(1);  // even: 16-B aligned groups
 }
 
-// TPE threads work on one element; a workgroup holds 256/TPE elements at a time (TPE = 64: one wave per element and
-// only wave-level synchronisation inside the element loop; TPE = 256: the whole workgroup, block barriers).
+// TPE threads work on one element; a workgroup (512 threads) holds 512/TPE elements at a time (TPE = 64: one wave per
+// element and only wave-level synchronisation inside the element loop; TPE = 512: the whole workgroup, block barriers).
 // NQ1 = integration points per direction when it is 2 or 3 (the loops over points then have compile-time bounds and
 // the compiler batches their LDS loads), 0 = taken from the layout at run time.
 template <int DIM, int PHYS, int TPE, int NQ1>
-__global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) void point_engine_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
-                                                                      TimeDev tm, ElemOut out,
-                                                                      const uint8_t *slot8, const uint16_t *slot16) {
+__global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
+                                                                      TimeDev tm, ElemOut out_all,
+                                                                      const uint8_t *slot8_all, const uint16_t *slot16_all) {
   using L = Layout<PHYS, DIM>;
   constexpr int NS = L::NS, NN = 1 << DIM, GEO = geo_size<DIM>(), NG = kEngineThreads / TPE;
   extern __shared__ double smem[];
@@ -182,9 +184,17 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
   const int ngroups = gridDim.x * NG, gid = blockIdx.x * NG + group;
   const int chunk = (b.e_count + ngroups - 1) / ngroups;
   const int el_begin = gid * chunk, el_end = min(b.e_count, el_begin + chunk);
-  // TPE == 256: all threads of the block share el_begin/el_end, so the block barriers below are uniform
-  for (int el = el_begin; el < el_end; ++el) {
+  // TPE > 64 synchronises with block barriers, which every group of the workgroup must reach the same number of
+  // times: all groups run `chunk` iterations; a group past its range recomputes its last element with outputs off
+  const int iters = (TPE == 64) ? max(el_end - el_begin, 0) : (((int)blockIdx.x * NG * chunk < b.e_count) ? chunk : 0);
+  for (int it = 0; it < iters; ++it) {
+    const bool live = el_begin + it < el_end;
+    const int el = live ? el_begin + it : max(min(el_end, b.e_count) - 1, 0);
     const int e = b.e_begin + el;
+    ElemOut out = live ? out_all : ElemOut();
+    out.compute_jacobian = out_all.compute_jacobian;
+    const uint8_t *slot8 = slot8_all;
+    const uint16_t *slot16 = slot16_all;
     sync();  // previous element done with the group's LDS
     // ---- 1. gather + seeding values, geometry ----
     for (int f = gt; f < n; f += TPE) {
@@ -331,93 +341,89 @@ __global__ __launch_bounds__(kEngineThreads, TPE == 64 ? MHA_ENGINE_MINW : 2) vo
       if (out.res && !(b.fixed && b.fixed[row])) unsafeAtomicAdd(out.res + row, -r);
     }
     if (dbg_stop == 4) continue;
-    // ---- 5. Jacobian: panels of 16 rows; P[(q,m)][r] = T^(i_r,q) . C^(q)[:,m]; then 2x4 register tiles over
-    //         (row pair, 4 dofs of one column variable): J[i][j] = sum_(q,s) P[(q, sp_j+s)][i] T^[q][s][j] ----
+    // ---- 5. Jacobian = B^T C^ B on the matrix cores (v_mfma_f64_16x16x4_f64), in panels of 16 rows of ONE variable:
+    //   P[(q,m)][r] = sum_s T^[q][s][i_r] C^(q)[sp_i+s][m]      one MFMA per point and 16 slots m   (K = the row variable's slots)
+    //   J[i_r][j]   = sum_(q,s) P[(q,sp_j+s)][r] T^[q][s][j]     16x16 tiles over 16 dofs of one column variable, K = NQ*nslot_j
+    // operand maps (CDNA4): A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15], D reg t: row = (lane>>4) + 4t, col = lane&15
     if (out.compute_jacobian) {
+      typedef double v4d __attribute__((ext_vector_type(4)));
       double *lj_e = out.local_J ? out.local_J + (size_t)(e - out.local_base) * n * n : nullptr;
-      int ntile_cols = 0;  // column quads, enumerated variable by variable
-      for (int v = 0; v < vl.nvars; ++v) ntile_cols += vl.cardpad[v] >> 2;
-      for (int i0 = 0; i0 < n; i0 += kPanelRows) {
-        {  // P panel: thread = (row r, every (TPE/16)-th (q,m)); the row's table pointers are set up once
-          const int r = gt % kPanelRows, i = i0 + r;
-          int vi = 0;
-          if (i < n) while (i >= vl.varptr[vi + 1]) ++vi;
-          const int ns = vl.nslot[vi], sp = vl.slotptr[vi], cp = vl.cardpad[vi];
-          const double *Ti = tab + vl.table_off[vi] + (i < n ? i - vl.varptr[vi] : 0);
-#pragma unroll 4
-          for (int qm = gt / kPanelRows; qm < NQ * NS; qm += TPE / kPanelRows) {
-            const int q = qm / NS, m = qm - q * NS;
-            double a = 0.0;
-            if (i < n) {
-              const double *T = Ti + q * ns * cp;
-              const double *C = s_Ch + (q * NS + sp) * NS + m;
-              if (ns == 1) {
-                a = T[0] * C[0];
+      constexpr int NWV = TPE / 64;             // waves working on this element
+      const int wv = gt >> 6, lane = gt & 63, l15 = lane & 15, l4 = lane >> 4;
+      for (int vi = 0; vi < vl.nvars; ++vi) {
+        const int nsi = vl.nslot[vi], spi = vl.slotptr[vi], cpi = vl.cardpad[vi], cardi = vl.card[vi];
+        const double *Ti = tab + vl.table_off[vi];
+        for (int r0 = 0; r0 < cardi; r0 += kPanelRows) {
+          // P panel, computed transposed (D[m][dof]) so that the 16 lanes of a row store 16 consecutive doubles:
+          // conflict-free LDS writes; points q are dealt to the element's waves
+          for (int q = wv; q < NQ; q += NWV) {
+            const bool ka = l4 < nsi;
+            const double tb = (ka && r0 + l15 < cardi) ? Ti[(q * nsi + l4) * cpi + r0 + l15] : 0.0;  // B[k = s][col = dof]
+            for (int m0 = 0; m0 < NS; m0 += 16) {
+              const double ca = (ka && m0 + l15 < NS) ? s_Ch[(q * NS + spi + l4) * NS + m0 + l15] : 0.0;  // A[row = m][k = s]
+              v4d d = {0.0, 0.0, 0.0, 0.0};
+              d = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, tb, d, 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int m = m0 + l4 + 4 * t;
+                if (m < NS) s_P[(q * NS + m) * kPanelRows + l15] = d[t];
+              }
+            }
+          }
+          sync();
+          if (dbg_stop == 5) { sync(); continue; }
+          // column tiles: (variable vj, 16 dofs), dealt to the waves
+          int tile = 0;
+          for (int vj = 0; vj < vl.nvars; ++vj) {
+            const int nsj = vl.nslot[vj], spj = vl.slotptr[vj], cpj = vl.cardpad[vj], cardj = vl.card[vj];
+            const double *Tj = tab + vl.table_off[vj];
+            for (int c0 = 0; c0 < cardj; c0 += 16, ++tile) {
+              if (tile % NWV != wv) continue;
+              const bool cb = c0 + l15 < cardj;
+              v4d d = {0.0, 0.0, 0.0, 0.0};
+              if (nsj == 4) {  // one point per MFMA: k = slot
+                for (int q = 0; q < NQ; ++q) {
+                  const double a = s_P[(q * NS + spj + l4) * kPanelRows + l15];
+                  const double bb = cb ? Tj[(q * 4 + l4) * cpj + c0 + l15] : 0.0;
+                  d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, d, 0, 0, 0);
+                }
               } else {
+                const int K = NQ * nsj;
+                for (int k0 = 0; k0 < K; k0 += 4) {
+                  const int k = k0 + l4, q = k / nsj, sl = k - q * nsj;
+                  const bool kv = k < K;
+                  const double a = kv ? s_P[(q * NS + spj + sl) * kPanelRows + l15] : 0.0;
+                  const double bb = (kv && cb) ? Tj[(q * nsj + sl) * cpj + c0 + l15] : 0.0;
+                  d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, d, 0, 0, 0);
+                }
+              }
+              if (cb) {
+                const int j = vl.varptr[vj] + c0 + l15, pos_j = s_pos[j];
+                const double sgj = s_sgn[j];
 #pragma unroll
-                for (int sl = 0; sl < 1 + DIM; ++sl) a += T[sl * cp] * C[sl * NS];
+                for (int t = 0; t < 4; ++t) {
+                  const int r = r0 + l4 + 4 * t;
+                  if (r >= cardi) continue;
+                  const int i = vl.varptr[vi] + r, pos_i = s_pos[i], row_i = s_row[i];
+                  const double val = d[t] * s_sgn[i] * sgj;
+                  if (lj_e) {
+                    double *lj = lj_e + (pos_i * n + pos_j);
+                    *lj = out.local_store ? val : *lj + val;
+                  }
+                  if (out.crs_vals && !(b.fixed && b.fixed[row_i])) {
+                    const size_t so = ((size_t)e * n + pos_i) * n + pos_j;
+                    int p;
+                    if (slot8) p = b.rowptr[row_i] + slot8[so];
+                    else if (slot16) p = b.rowptr[row_i] + slot16[so];
+                    else p = find_col(b.colind, b.rowptr[row_i], b.rowptr[row_i + 1], s_row[j]);
+                    if (p >= 0) unsafeAtomicAdd(out.crs_vals + p, val);
+                  }
+                }
               }
             }
-            s_P[qm * kPanelRows + r] = a;
           }
+          sync();
         }
-        sync();
-        if (dbg_stop == 5) continue;
-        for (int t = gt; t < (kPanelRows / 2) * ntile_cols; t += TPE) {
-          const int rp = t % (kPanelRows / 2);
-          int cq = t / (kPanelRows / 2), vj = 0;
-          while (cq >= (vl.cardpad[vj] >> 2)) { cq -= vl.cardpad[vj] >> 2; ++vj; }
-          const int nsj = vl.nslot[vj], spj = vl.slotptr[vj], cpj = vl.cardpad[vj];
-          const double *T = tab + vl.table_off[vj] + 4 * cq;
-          const double *Pp = s_P + spj * kPanelRows + 2 * rp;
-          double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-          auto kstep = [&](const double *Pk, const double *Tk) {
-            const double2 a = *reinterpret_cast<const double2 *>(Pk);
-            const double2 b0 = *reinterpret_cast<const double2 *>(Tk);
-            const double2 b1 = *reinterpret_cast<const double2 *>(Tk + 2);
-            acc[0][0] += a.x * b0.x; acc[0][1] += a.x * b0.y; acc[0][2] += a.x * b1.x; acc[0][3] += a.x * b1.y;
-            acc[1][0] += a.y * b0.x; acc[1][1] += a.y * b0.y; acc[1][2] += a.y * b1.x; acc[1][3] += a.y * b1.y;
-          };
-          if (nsj == 1) {
-#pragma unroll 4
-            for (int q = 0; q < NQ; ++q) kstep(Pp + q * NS * kPanelRows, T + q * cpj);
-          } else {
-#pragma unroll 3
-            for (int q = 0; q < NQ; ++q) {
-              const double *Tq = T + q * (1 + DIM) * cpj;
-              const double *Pq = Pp + q * NS * kPanelRows;
-#pragma unroll
-              for (int sl = 0; sl < 1 + DIM; ++sl) kstep(Pq + sl * kPanelRows, Tq + sl * cpj);
-            }
-          }
-#pragma unroll
-          for (int x = 0; x < 2; ++x) {
-            const int i = i0 + 2 * rp + x;
-            if (i >= n) continue;
-            const int pos_i = s_pos[i], row_i = s_row[i];
-            const bool to_crs = out.crs_vals && !(b.fixed && b.fixed[row_i]);
-#pragma unroll
-            for (int y = 0; y < 4; ++y) {
-              const int dofj = 4 * cq + y;
-              if (dofj >= vl.card[vj]) continue;
-              const int j = vl.varptr[vj] + dofj, pos_j = s_pos[j];
-              const double a = acc[x][y] * s_sgn[i] * s_sgn[j];
-              if (out.local_J) {
-                double *lj = lj_e + (pos_i * n + pos_j);
-                *lj = out.local_store ? a : *lj + a;
-              }
-              if (to_crs) {
-                const size_t so = ((size_t)e * n + pos_i) * n + pos_j;
-                int p;
-                if (slot8) p = b.rowptr[row_i] + slot8[so];
-                else if (slot16) p = b.rowptr[row_i] + slot16[so];
-                else p = find_col(b.colind, b.rowptr[row_i], b.rowptr[row_i + 1], s_row[j]);
-                if (p >= 0) unsafeAtomicAdd(out.crs_vals + p, a);
-              }
-            }
-          }
-        }
-        sync();
       }
     }
   }
@@ -435,8 +441,11 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
   const size_t per_group = engine_group_doubles(vl, geo_size<DIM>()) * sizeof(double);
   const size_t tables = vl.tables_size * sizeof(double);
   // small elements: one wave per element, four elements per workgroup; large ones: the whole workgroup per element
-  const bool small = vl.n_tot <= 48 && tables + 4 * per_group <= 160 * 1024;
-  const size_t lds = tables + (small ? 4 : 1) * per_group;
+  // as many elements per workgroup as the LDS holds (8, 4, 2 or 1): TPE = 64, 128, 256 or 512 threads per element
+  int groups = 1;
+  for (int g = kEngineThreads / 64; g >= 1; g >>= 1)
+    if (tables + g * per_group <= 160 * 1024 && (g == 1 || vl.n_tot <= 64)) { groups = g; break; }
+  const size_t lds = tables + groups * per_group;
   MHA_REQUIRE(lds <= 160 * 1024, MHA_ERR_INVALID, "element needs " << lds << " B of LDS (limit 160 KB)");
   static int num_cu = 0;
   if (!num_cu) {
@@ -444,10 +453,9 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
     MHA_HIP(hipGetDevice(&dev));
     MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(small ? MHA_ENGINE_MINW : 1, (160 * 1024) / lds)));
+  const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(size_t(2), (160 * 1024) / lds)));
   PhysParamsDev ppd = pp;
   if (const char *st = std::getenv("MHA_ENGINE_STOP")) ppd.p[7] = std::atof(st);
-  const int groups = small ? 4 : 1;
   const int grid = std::max(1, std::min((b.e_count + groups - 1) / groups, num_cu * per_cu));
   const uint8_t *s8 = (slot && slot_bytes == 1) ? static_cast<const uint8_t *>(slot) : nullptr;
   const uint16_t *s16 = (slot && slot_bytes == 2) ? static_cast<const uint16_t *>(slot) : nullptr;
@@ -458,15 +466,16 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
     MHA_HIP(hipGetLastError());
   };
   const int nq1 = (vl.nq == (DIM == 2 ? 4 : 8)) ? 2 : (vl.nq == (DIM == 2 ? 9 : 27)) ? 3 : 0;
-  if (small) {
-    if (nq1 == 2) go(point_engine_kernel<DIM, PHYS, 64, 2>);
-    else if (nq1 == 3) go(point_engine_kernel<DIM, PHYS, 64, 3>);
-    else go(point_engine_kernel<DIM, PHYS, 64, 0>);
-  } else {
-    if (nq1 == 2) go(point_engine_kernel<DIM, PHYS, 256, 2>);
-    else if (nq1 == 3) go(point_engine_kernel<DIM, PHYS, 256, 3>);
-    else go(point_engine_kernel<DIM, PHYS, 256, 0>);
-  }
+  auto pick = [&](auto tpe) {
+    constexpr int T = decltype(tpe)::value;
+    if (nq1 == 2) go(point_engine_kernel<DIM, PHYS, T, 2>);
+    else if (nq1 == 3) go(point_engine_kernel<DIM, PHYS, T, 3>);
+    else go(point_engine_kernel<DIM, PHYS, T, 0>);
+  };
+  if (groups == 8) pick(std::integral_constant<int, 64>());
+  else if (groups == 4) pick(std::integral_constant<int, 128>());
+  else if (groups == 2) pick(std::integral_constant<int, 256>());
+  else pick(std::integral_constant<int, 512>());
 }
 
 }  // namespace
