@@ -118,7 +118,7 @@ __device__ __forceinline__ void eval_ref(const double *c, const double *phi, con
 // (reference call site: src/managers/assemblyManager.cpp:4138).
 __device__ __forceinline__ int find_col(const int32_t *colind, int lo, int hi, int col) {
   while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
+    const int mid = lo + ((hi - lo) >> 1);  // lo + hi overflows int once nnz > 2^30
     const int c = colind[mid];
     if (c == col) return mid;
     if (c < col) lo = mid + 1; else hi = mid;

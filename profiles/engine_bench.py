@@ -58,5 +58,28 @@ def run(kind, nc):
               (kind, nc, ms, m["nelem"] / ms * 1e3, m["nelem"] * B / ms / 1e6, m["nelem"] * B / ms / 1e6 / 80.0), flush=True)
 
 
+def cpu_baseline(kind, sample_nc):
+    """The oracle's AD-array restatement (1 thread) on a bounded sample of the same workload."""
+    dim = 3
+    if kind == "thermal":
+        types, orders, phys, qdeg = [orc.HGRAD], [2], orc.PHYS_THERMAL, 4
+    elif kind == "porous":
+        types, orders, phys, qdeg = [orc.HVOL, orc.HDIV], [0, 1], orc.PHYS_POROUS_MIXED, 2
+    else:
+        types, orders, phys, qdeg = [orc.HGRAD] * 4, [2, 1, 2, 2], orc.PHYS_NAVIERSTOKES, 4
+    m = orc.mesh_multi(dim, (sample_nc,) * 3, types, orders)
+    rowptr, colind = orc.build_graph(m["ndof"], m["lids"])
+    u = np.random.default_rng(5).uniform(-1, 1, m["ndof"])
+    t0 = time.time()
+    orc.assemble_block(m, phys, qdeg, u, rowptr=rowptr, colind=colind)
+    dt = time.time() - t0
+    return {"value": m["nelem"] / dt, "unit": "elements/s", "cores": 1, "kind": "port", "seconds": dt,
+            "sample": "%d^3 elements of the same block, oracle AD-array restatement, 1 thread" % sample_nc}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 4 and sys.argv[4] == "cpu":
+        import json
+        print(json.dumps({"workload": sys.argv[1], "cpu_baseline": cpu_baseline(sys.argv[1], int(sys.argv[2]))}))
+        sys.exit(0)
     run(sys.argv[1] if len(sys.argv) > 1 else "porous", int(sys.argv[2]) if len(sys.argv) > 2 else 32)
