@@ -129,9 +129,6 @@ __device__ __forceinline__ void to_ref_T(int type, const double *phys, const dou
   }
 }
 
-#ifndef MHA_ENGINE_MINW
-#define MHA_ENGINE_MINW 2
-#endif
 constexpr int kEngineThreads = 512, kPanelRows = 16;
 
 // orders a wave's LDS writes before its later LDS reads (data private to the wave: no workgroup barrier needed)

@@ -286,3 +286,42 @@ def test_porous_mixed_2d_gold_end_to_end(oracle):
         np.sum((uh[..., 1] + 2 * np.pi * s[..., 0] * c[..., 1]) ** 2 * w)
     g = gold_errors("porous_Mixed.gold")
     assert fmt(ep) == fmt(g["p"]) and fmt(np.sqrt(eu)) == fmt(g["u"])
+
+
+@pytest.mark.parametrize("physics", ["thermal", "porousMixed", "navierstokes", "shallowwaterHybridized"])
+def test_single_element_and_ragged_groups(oracle, physics):
+    """Edge cases of the engine's work split: a one-element block (workgroups with idle element slots), element counts
+    that are not a multiple of the elements-per-workgroup, a residual-only pass, NULL orientation."""
+    torch = _torch()
+    import mrhyde_amd
+    H, V, D = oracle.HGRAD, oracle.HVOL, oracle.HDIV
+    spec = {"thermal": (oracle.PHYS_THERMAL, [H], [2], 3, {"thermal source": 1.5}, []),
+            "porousMixed": (oracle.PHYS_POROUS_MIXED, [V, D], [0, 1], 3, {"source": 0.7}, []),
+            "navierstokes": (oracle.PHYS_NAVIERSTOKES, [H] * 3, [2, 1, 2], 2, {"source ux": 1.0, "viscosity": 0.1}, [1, 1, 0]),
+            "shallowwaterHybridized": (oracle.PHYS_SHALLOWWATER_HYBRIDIZED, [H] * 3, [1, 1, 1], 2, {"source H": 0.1}, [9.81])}
+    pid, types, orders, dim, funcs, params = spec[physics]
+    rng = np.random.default_rng(51)
+    for ncell in ([1] * dim, [3, 1, 1][:dim], [5, 3, 1][:dim]):
+        m = warp(oracle.mesh_multi(dim, ncell, types, orders))
+        u = rng.uniform(0.5, 1.5, m["ndof"])
+        qdeg = 2 * max(max(orders), 1)
+        ref = oracle.assemble_block(m, pid, qdeg, u, funcs=funcs, params=params)
+        blk = mrhyde_amd.Block(dim, quadrature=qdeg, physics=physics, variables=list(zip(types, orders)))
+        blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+        if physics == "porousMixed":
+            blk.set_orientation(m["orient"])
+        blk.set_graph(ref["rowptr"], ref["colind"])
+        for k, v in funcs.items():
+            blk.set_function(k, v)
+        for name, val in zip({"navierstokes": ("useSUPG", "usePSPG", "fix_uz_offsets"),
+                              "shallowwaterHybridized": ("g",)}.get(physics, ()), params):
+            blk.set_physics_parameter(name, val)
+        ud = torch.tensor(u, device="cuda")
+        res = torch.full((m["ndof"],), 3.0, dtype=torch.float64, device="cuda")
+        vals = torch.full((len(ref["colind"]),), 3.0, dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(ud, res, vals, overwrite=True)
+        assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL and rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+        res2 = torch.zeros_like(res)
+        blk.assemble_jacres(ud, res2, None, compute_jacobian=False, path=mrhyde_amd.PATH_POINT_ENGINE)
+        torch.cuda.synchronize()
+        assert rel_err(res2.cpu().numpy(), ref["res"]) < RTOL
