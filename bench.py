@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ncell", type=int, default=64, help="cells per direction of one GPU's block")
     ap.add_argument("--order", type=int, default=2)
-    ap.add_argument("--path", default="auto", choices=["auto", "element_atomic", "row_owner", "local_then_scatter"])
+    ap.add_argument("--path", default="auto", choices=["auto", "element_atomic", "row_owner", "local_then_scatter", "row_gather"])
     ap.add_argument("--mesh", default="affine", choices=["affine", "perturbed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-layers", type=int, default=0, help="z-layers of the CPU sample (0 = all)")
@@ -182,7 +182,8 @@ def main():
     vals = torch.zeros(nnz, dtype=torch.float64, device=dev)
     exch = SlabExchange(rowptr, colind, (order * args.ncell + 1) ** 2, nrows, rank, world, dev) if world > 1 else None
     path = {"auto": mrhyde_amd.PATH_AUTO, "element_atomic": mrhyde_amd.PATH_ELEMENT_ATOMIC,
-            "row_owner": mrhyde_amd.PATH_ROW_OWNER, "local_then_scatter": mrhyde_amd.PATH_LOCAL_THEN_SCATTER}[args.path]
+            "row_owner": mrhyde_amd.PATH_ROW_OWNER, "local_then_scatter": mrhyde_amd.PATH_LOCAL_THEN_SCATTER,
+            "row_gather": mrhyde_amd.PATH_ROW_GATHER}[args.path]
 
     def step():
         # MHA_ASSEMBLE_OVERWRITE: the zeroing of res/J the Newton loop does before assembling is part of the step
@@ -235,7 +236,8 @@ def main():
             "config": {"workload": "3D thermal Q%d hex, %d^3 structured mesh per GPU (%s), quadrature %d, "
                                    "volume Jacobian+residual assembled into CRS" % (order, args.ncell, args.mesh, qdeg),
                        "elements_per_gpu": E, "dofs_per_gpu": nrows, "nnz_per_gpu": nnz,
-                       "path": {1: "element_atomic", 2: "row_owner", 3: "local_then_scatter"}.get(blk.info("last_path")),
+                       "path": {1: "element_atomic", 2: "row_owner", 3: "local_then_scatter", 4: "point_engine",
+                                5: "row_gather"}.get(blk.info("last_path")),
                        "affine_elements": blk.info("num_affine_elems"), "row_blocks": blk.info("row_blocks"),
                        "row_owner_lds_bytes": blk.info("row_owner_lds_bytes"),
                        "partition": "z-slabs, 1 per GPU" if world > 1 else "single block",
@@ -243,8 +245,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, blk),
                          "kernel_ms": kernel_ms, "bytes_per_elem": b_elem,
-                         "kernels": "thermal_affine_element_kernel + row_owner_jacobian_persistent_kernel (HIP events "
-                                    "around both on the context's stream)"},
+                         "kernels": {2: "thermal_affine_element_kernel + row_owner_jacobian_persistent_kernel",
+                                     5: "thermal_general_element_kernel (dense element matrices) + row_gather_kernel"
+                                     }.get(blk.info("last_path"), "element kernel + scatter") +
+                                    " (HIP events around the assembly's kernels on the context's stream)"},
         }
         if not args.no_cpu_baseline:
             threads = host_threads()

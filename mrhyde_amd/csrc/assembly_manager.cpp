@@ -409,7 +409,9 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
   }
   if (path == MHA_PATH_AUTO) {
     if (!ro_.ready && thermal_row_owner_supported(dim_, order_, ref_.nq1)) prepareRowOwner();
-    path = rowOwnerUsable(nullptr) ? MHA_PATH_ROW_OWNER : MHA_PATH_ELEMENT_ATOMIC;
+    // affine elements with constant coefficients: fused row-owner kernels; otherwise dense element matrices + the
+    // atomic-free row gather (4.1 ms against 7.4 ms for the atomic scatter on the perturbed config-2 mesh)
+    path = rowOwnerUsable(nullptr) ? MHA_PATH_ROW_OWNER : MHA_PATH_ROW_GATHER;
   }
   if (path == MHA_PATH_ROW_OWNER) {
     if (!ro_.ready) prepareRowOwner();
@@ -447,7 +449,18 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
       o.local_store = 1;
       o.local_J = compute_jacobian ? d_gather_J_.data() : nullptr;
       o.local_res = d_gather_res_.data();
-      launchPointEngine(compute_jacobian, o, 0, nelem_);
+      // thermal: the element matrices come from the specialised general-element kernel (kernels/thermal_general.hip;
+      // perturbed config 2: 4.1 ms against 7.7 ms with the point engine); MHA_ROW_GATHER_KERNEL=engine forces the engine
+      static const bool use_general = [] { const char *m = std::getenv("MHA_ROW_GATHER_KERNEL"); return !(m && m[0] == 'e'); }();
+      if (physics_id_ == MHA_PHYSICS_THERMAL && use_general && thermal_row_owner_supported(dim_, order_, ref_.nq1)) {
+        wkset_.first_elem = 0;
+        wkset_.numElem = nelem_;
+        wkset_.res = o;
+        useGeneralKernel(false);
+        physics_->volumeResidual();
+      } else {
+        launchPointEngine(compute_jacobian, o, 0, nelem_);
+      }
       RowGatherDev g;
       g.inc_ptr = d_inc_ptr_.data();
       g.inc_elem = d_inc_elem_.data();

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void thermal_general_element_kernel(BlockDev b
         for (int a = 0; a < DIM; ++a) r += E[S::O_F + q * DIM + a] * sh[S::S_GT + (q * DIM + a) * NP + i];
       }
       const int slot = s_offs[i];
-      if (out.local_res) out.local_res[(size_t)(e - out.local_base) * N + slot] -= r;
+      if (out.local_res) {
+        double *lr = out.local_res + (size_t)(e - out.local_base) * N + slot;
+        *lr = out.local_store ? -r : *lr - r;
+      }
       if (out.res) {
         const int row = L[slot];
         if (!(b.fixed && b.fixed[row])) atomicAdd(out.res + row, -r);
@@ -287,7 +290,10 @@ __global__ __launch_bounds__(256) void thermal_general_element_kernel(BlockDev b
         const int j = 4 * tj + c;
         if (j >= N) continue;
         const int sj = s_offs[j];
-        if (out.local_J) out.local_J[((size_t)(e - out.local_base) * N + si) * N + sj] += acc[a][c];
+        if (out.local_J) {
+          double *lj = out.local_J + ((size_t)(e - out.local_base) * N + si) * N + sj;
+          *lj = out.local_store ? acc[a][c] : *lj + acc[a][c];
+        }
         if (out.crs_vals && !fx) {
           const size_t sidx = ((size_t)e * N + si) * N + sj;
           const int sl = slot8 ? (int)slot8[sidx] : (int)slot16[sidx];

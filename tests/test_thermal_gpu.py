@@ -347,12 +347,13 @@ def test_row_owner_transient_and_source_array(oracle):
 
 
 def test_auto_path_selection(oracle):
-    """AUTO = row-owner on affine meshes with constant coefficients, element kernel otherwise; both correct."""
+    """AUTO = row-owner on affine meshes with constant coefficients, element matrices + row gather otherwise; both
+    correct (the row-gather path also with accumulate semantics, fixed rows and a residual-only pass)."""
     torch = _torch()
     import mrhyde_amd
     dim, order, qdeg, ncell = 3, 2, 4, (3, 3, 3)
     for mesh_fn, expect in ((lambda: affine_mesh(oracle, dim, order, ncell), mrhyde_amd.PATH_ROW_OWNER),
-                            (lambda: perturbed(oracle, dim, order, ncell, seed=2), mrhyde_amd.PATH_ELEMENT_ATOMIC)):
+                            (lambda: perturbed(oracle, dim, order, ncell, seed=2), mrhyde_amd.PATH_ROW_GATHER)):
         m = mesh_fn()
         u = np.random.default_rng(5).uniform(-1, 1, m["ndof"])
         ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, source=("const", 1.0))
@@ -365,9 +366,28 @@ def test_auto_path_selection(oracle):
         assert blk.info("last_path") == expect
         assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
         assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
-        if expect == mrhyde_amd.PATH_ELEMENT_ATOMIC:
+        if expect == mrhyde_amd.PATH_ROW_GATHER:
             with pytest.raises(mrhyde_amd.MhaError):
                 blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, path=mrhyde_amd.PATH_ROW_OWNER)
+            # accumulate on top of the first result, then a residual-only overwrite
+            blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals)
+            torch.cuda.synchronize()
+            assert rel_err(vals.cpu().numpy(), 2 * ref["crs_vals"]) < RTOL and rel_err(res.cpu().numpy(), 2 * ref["res"]) < RTOL
+            blk.assemble_jacres(torch.tensor(u, device="cuda"), res, None, compute_jacobian=False, overwrite=True)
+            torch.cuda.synchronize()
+            assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+            # fixed rows: skipped by the gather, zeroed by the overwrite
+            fixed = m["boundary"]
+            reff = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed,
+                                           source=("const", 1.0))
+            blk2 = make_block(m, dim, order, qdeg, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+            blk2.set_function("thermal source", 1.0)
+            res.fill_(5.0)
+            vals.fill_(5.0)
+            blk2.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True)
+            torch.cuda.synchronize()
+            assert blk2.info("last_path") == mrhyde_amd.PATH_ROW_GATHER
+            assert rel_err(vals.cpu().numpy(), reff["crs_vals"]) < RTOL and rel_err(res.cpu().numpy(), reff["res"]) < RTOL
 
 
 def test_error_behaviour_on_device():
