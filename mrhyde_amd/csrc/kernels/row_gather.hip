@@ -36,39 +36,69 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
   const int nwaves = gridDim.x * 4;
   for (int k = lane; k < g.max_row; k += 64) acc[k] = 0.0;
   wave_lds_sync();
-  for (int row = blockIdx.x * 4 + wave; row < b.nrows; row += nwaves) {
-    const int lo = b.rowptr[row], len = b.rowptr[row + 1] - lo;
-    const bool fixed = b.fixed && b.fixed[row];  // isFixedDOF rows are skipped by the scatter (assemblyManager.cpp:4075,4120)
-    if (fixed) {
+  // Two-deep software pipeline over the wave's rows: a row needs rowptr/inc_ptr (level 1), then its incidences
+  // (level 2), then the element-matrix rows (level 3) -- three dependent global latencies.  While row r is summed, the
+  // incidences of row r+1 and the pointers of row r+2 are already in flight.
+  struct Meta { int lo, len, i0, ni, fixed; };
+  auto load_meta = [&](int row) {
+    Meta m = {0, 0, 0, 0, 1};
+    if (row < b.nrows) {
+      m.lo = b.rowptr[row];
+      m.len = b.rowptr[row + 1] - m.lo;
+      m.i0 = g.inc_ptr[row];
+      m.ni = g.inc_ptr[row + 1] - m.i0;
+      m.fixed = (b.fixed && b.fixed[row]) ? 1 : 0;
+    }
+    return m;
+  };
+  const int row0 = blockIdx.x * 4 + wave;
+  Meta m_cur = load_meta(row0), m_nxt = load_meta(row0 + nwaves);
+  int e_cur = (lane < m_cur.ni) ? g.inc_elem[m_cur.i0 + lane] : 0, p_cur = (lane < m_cur.ni) ? g.inc_pos[m_cur.i0 + lane] : 0;
+  for (int row = row0; row < b.nrows; row += nwaves) {
+    // prefetch: incidences of the next row (its pointers were requested one iteration ago), pointers of the one after
+    const int e_nxt = (lane < m_nxt.ni) ? g.inc_elem[m_nxt.i0 + lane] : 0;
+    const int p_nxt = (lane < m_nxt.ni) ? g.inc_pos[m_nxt.i0 + lane] : 0;
+    const Meta m_nn = load_meta(row + 2 * nwaves);
+    const int lo = m_cur.lo, len = m_cur.len, i0 = m_cur.i0, ni = m_cur.ni;
+    if (m_cur.fixed) {  // isFixedDOF rows are skipped by the scatter (assemblyManager.cpp:4075,4120)
       if (overwrite) {
         if (vals) for (int k = lane; k < len; k += 64) vals[lo + k] = 0.0;
         if (res && lane == 0) res[row] = 0.0;
       }
-      continue;
-    }
-    const int i0 = g.inc_ptr[row], ni = g.inc_ptr[row + 1] - i0;
-    if (vals) {
-      const int total = ni * n;
-      for (int t = lane; t < total; t += 64) {
-        const int k = t / n, sj = t - k * n;
-        const size_t off = ((size_t)g.inc_elem[i0 + k] * n + g.inc_pos[i0 + k]) * n + sj;
-        unsafeAtomicAdd(acc + slot[off], local_J[off]);
+    } else {
+      if (vals) {
+        const int total = ni * n;
+        for (int t = lane; t < total; t += 64) {
+          const int k = t / n, sj = t - k * n;
+          // incidences 0..63 sit in the wave's registers; longer rows (never for quads / hexes) re-read them
+          const int e = k < 64 ? __shfl(e_cur, k) : g.inc_elem[i0 + k];
+          const int pos = k < 64 ? __shfl(p_cur, k) : g.inc_pos[i0 + k];
+          const size_t off = ((size_t)e * n + pos) * n + sj;
+          unsafeAtomicAdd(acc + slot[off], local_J[off]);
+        }
+        wave_lds_sync();
+        for (int k = lane; k < len; k += 64) {
+          const double a = acc[k];
+          acc[k] = 0.0;
+          vals[lo + k] = overwrite ? a : vals[lo + k] + a;
+        }
+        wave_lds_sync();
       }
-      wave_lds_sync();
-      for (int k = lane; k < len; k += 64) {
-        const double a = acc[k];
-        acc[k] = 0.0;
-        vals[lo + k] = overwrite ? a : vals[lo + k] + a;
-      }
-      wave_lds_sync();
-    }
-    if (res) {
-      double r = 0.0;
-      for (int k = lane; k < ni; k += 64) r += local_res[(size_t)g.inc_elem[i0 + k] * n + g.inc_pos[i0 + k]];
+      if (res) {
+        double r = 0.0;
+        for (int k = lane; k < ni; k += 64) {
+          const int e = k < 64 ? e_cur : g.inc_elem[i0 + k], pos = k < 64 ? p_cur : g.inc_pos[i0 + k];
+          r += local_res[(size_t)e * n + pos];
+        }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
-      if (lane == 0) res[row] = overwrite ? r : res[row] + r;
+        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+        if (lane == 0) res[row] = overwrite ? r : res[row] + r;
+      }
     }
+    m_cur = m_nxt;
+    m_nxt = m_nn;
+    e_cur = e_nxt;
+    p_cur = p_nxt;
   }
 }
 
