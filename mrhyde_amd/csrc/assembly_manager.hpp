@@ -158,6 +158,8 @@ class AssemblyManager {
   bool timing_ = false;
   double last_ms_ = 0.0;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  hipStream_t side_stream_ = nullptr;  // MHA_K1K2_OVERLAP
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
 };
 
 }  // namespace mha
