@@ -59,6 +59,10 @@ void launch_thermal_boundary(const BlockDev &b, const SideTablesDev &st, const B
 void launch_porous_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const VarLayoutDev &vl,
                             const ElemOut &out, hipStream_t stream);
 
+// porous_element.hip: porousMixed volume terms, one thread per element, dense element arrays out
+void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
+                           const ElemOut &out, hipStream_t stream);
+
 // row_gather.hip: CRS rows summed from dense element matrices, no global atomics
 void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *local_J, const double *local_res,
                        double *res, double *vals, int overwrite, hipStream_t stream);

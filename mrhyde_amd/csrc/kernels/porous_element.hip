@@ -1,0 +1,162 @@
+// porous_element.hip -- porousMixed volume terms, one THREAD per element.
+//
+// The lowest-order mixed element has 1 + 2*dim dofs (7 on a hex) and 2^dim integration points: far too small for a
+// wavefront.  Here every thread owns one element and keeps the whole element matrix in registers; the module is linear,
+// so the Sacado derivative array of the reference (porousMixed.cpp:158-338) is written down directly:
+//   res_p      = sum_q (source - div u) w                      d res_p / d u_j   = -alpha_u div_j w
+//   res_{u,i}  = sum_q (Kinv u . v_i / mobility - p div_i) w   d res_{u,i}/d p   = -alpha_u div_i w
+//                                                              d res_{u,i}/d u_j = alpha_u (v_i . Kinv v_j / mobility) w
+// with v_i = s_i J phihat_i / detJ, div_i = s_i divhat_i / detJ (HDIVtransformVALUE / DIV,
+// discretizationInterface.cpp:1019,1053; s_i the orientation sign), phihat_{2c+h} = (1 -/+ x_c)/2 e_c.
+// Output: dense local_J / local_res in LID-position order (updateJac / updateRes convention), from which
+// kernels/row_gather.hip builds the CRS rows.  Same gather / seeding conventions as the point engine.
+#include <hip/hip_runtime.h>
+
+#include "device_math.hpp"
+#include "launch.hpp"
+
+namespace mha {
+namespace {
+
+template <int DIM>
+__global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm,
+                                                             ElemOut out) {
+  constexpr int NN = 1 << DIM, NU = 2 * DIM, N = 1 + NU;
+  const int el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el >= b.e_count) return;
+  const int e = b.e_begin + el, NQ = vl.nq;
+  const int32_t *L = b.lids + (size_t)e * N;
+  // gather + seeding values; positions: p at offsets[0], u_i at offsets[1 + i]
+  int pos[N];
+  double u[N], sg[N];
+#pragma unroll
+  for (int f = 0; f < N; ++f) {
+    pos[f] = b.offsets[f];
+    const int row = L[pos[f]];
+    sg[f] = (vl.orient && f > 0) ? (double)vl.orient[(size_t)e * N + f] : 1.0;
+    const double cu = tm.u[row];
+    double ue = cu;
+    if (tm.transient) {  // Workset::computeSolnTransientSeeded (workset.cpp:589-623); the module has no time derivative
+      const double *cp = tm.u_prev + (size_t)row * tm.nsteps, *cs = tm.u_stage + (size_t)row * tm.nstages;
+      double beta_u = (1.0 - tm.alpha_u) * cp[0];
+      for (int s = 0; s < tm.stage; ++s) beta_u += tm.stage_ratio[s] * (cs[s] - cp[0]);
+      ue = tm.alpha_u * cu + beta_u;
+    }
+    u[f] = ue;
+  }
+  double xn[NN][DIM];
+#pragma unroll
+  for (int k = 0; k < NN; ++k)
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) xn[k][d] = b.nodes[((size_t)e * NN + k) * DIM + d];
+  double A[NU][NU], Bv[NU], rp = 0.0, ru[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    Bv[i] = 0.0;
+    ru[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) A[i][j] = 0.0;
+  }
+  for (int q = 0; q < NQ; ++q) {
+    double J[DIM * DIM], Ji[DIM * DIM], det, x[DIM], xi[DIM];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NN; ++k) s += xn[k][r] * b.nodegrad[(k * NQ + q) * DIM + c];
+        J[r * DIM + c] = s;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < NN; ++k) s += xn[k][r] * b.nodeval[k * NQ + q];
+      x[r] = s;
+    }
+    invert<DIM>(J, Ji, det);
+    // reference point from the geometry basis of the vertex with all +1 signs: N_k = prod (1 + s x)/2 -> use the
+    // u table instead: phihat_{2c+1}(q) = (1 + x_c)/2
+    const double *Tu = vl.tables + vl.table_off[1] + (size_t)q * (DIM + 1) * vl.cardpad[1];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) xi[c] = 2.0 * Tu[c * vl.cardpad[1] + 2 * c + 1] - 1.0;
+    const double w = b.ref_wts[q] * det, rdet = 1.0 / det;
+    const double src = eval_func<DIM>(pp.f[0], e, q, NQ, x), mob = eval_func<DIM>(pp.f[4], e, q, NQ, x);
+    double kinv[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) kinv[d] = eval_func<DIM>(pp.f[1 + d], e, q, NQ, x);
+    // v_i = sg_i * ph_i * J[:,c_i] / det, div_i = sg_i * (+-1/2) / det
+    double ph[NU], dv[NU], uq[DIM], divu = 0.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) uq[d] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int c = i >> 1;
+      ph[i] = sg[1 + i] * ((i & 1) ? 0.5 * (1.0 + xi[c]) : 0.5 * (1.0 - xi[c])) * rdet;
+      dv[i] = sg[1 + i] * ((i & 1) ? 0.5 : -0.5) * rdet;
+      divu += u[1 + i] * dv[i];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) uq[d] += u[1 + i] * ph[i] * J[d * DIM + c];
+    }
+    rp += (src - divu) * w;
+    // M[c][c'] = sum_d J[d][c] kinv_d J[d][c'] / mobility
+    double M[DIM][DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c)
+#pragma unroll
+      for (int c2 = 0; c2 < DIM; ++c2) {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) s += J[d * DIM + c] * kinv[d] * J[d * DIM + c2];
+        M[c][c2] = s / mob;
+      }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int c = i >> 1;
+      double kuv = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) kuv += kinv[d] * uq[d] * J[d * DIM + c];
+      ru[i] += (kuv * ph[i] / mob - u[0] * dv[i]) * w;
+      Bv[i] -= dv[i] * w;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1] * w;
+    }
+  }
+  // dense output, LID-position order
+  const double au = tm.alpha_u;
+  if (out.local_res) {
+    double *lr = out.local_res + (size_t)(e - out.local_base) * N;
+    lr[pos[0]] = out.local_store ? -rp : lr[pos[0]] - rp;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) lr[pos[1 + i]] = out.local_store ? -ru[i] : lr[pos[1 + i]] - ru[i];
+  }
+  if (out.local_J && out.compute_jacobian) {
+    double *lj = out.local_J + (size_t)(e - out.local_base) * N * N;
+    auto put = [&](int pi, int pj, double v) {
+      double *d = lj + pi * N + pj;
+      *d = out.local_store ? v : *d + v;
+    };
+    put(pos[0], pos[0], 0.0);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      put(pos[0], pos[1 + i], au * Bv[i]);
+      put(pos[1 + i], pos[0], au * Bv[i]);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) put(pos[1 + i], pos[1 + j], au * A[i][j]);
+    }
+  }
+}
+
+}  // namespace
+
+void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
+                           const ElemOut &out, hipStream_t stream) {
+  if (b.e_count <= 0) return;
+  MHA_REQUIRE(out.res == nullptr && out.crs_vals == nullptr, MHA_ERR_INVALID,
+              "porous element kernel writes dense element arrays only");
+  const int grid = (b.e_count + 127) / 128;
+  if (b.dim == 2) hipLaunchKernelGGL(porous_element_kernel<2>, dim3(grid), dim3(128), 0, stream, b, vl, pp, tm, out);
+  else hipLaunchKernelGGL(porous_element_kernel<3>, dim3(grid), dim3(128), 0, stream, b, vl, pp, tm, out);
+  MHA_HIP(hipGetLastError());
+}
+
+}  // namespace mha

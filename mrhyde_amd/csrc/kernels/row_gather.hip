@@ -25,16 +25,19 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename SlotT>
+// LPR lanes per row: 64 (one row per wavefront) or 16 (four short rows per wavefront: mixed lowest-order elements have
+// CRS rows of ~10 entries)
+template <typename SlotT, int LPR>
 __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDev g, const double *__restrict__ local_J,
                                                          const double *__restrict__ local_res, double *res, double *vals,
                                                          int overwrite) {
   extern __shared__ double acc_all[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = b.n;
-  double *acc = acc_all + (size_t)wave * g.max_row;
+  constexpr int RPW = 64 / LPR;  // rows per wavefront
+  const int wave = threadIdx.x >> 6, sub = (threadIdx.x & 63) / LPR, lane = threadIdx.x & (LPR - 1), n = b.n;
+  double *acc = acc_all + (size_t)(wave * RPW + sub) * g.max_row;
   const SlotT *slot = static_cast<const SlotT *>(g.slot);
-  const int nwaves = gridDim.x * 4;
-  for (int k = lane; k < g.max_row; k += 64) acc[k] = 0.0;
+  const int nwaves = gridDim.x * 4 * RPW;  // row streams
+  for (int k = lane; k < g.max_row; k += LPR) acc[k] = 0.0;
   wave_lds_sync();
   // Two-deep software pipeline over the wave's rows: a row needs rowptr/inc_ptr (level 1), then its incidences
   // (level 2), then the element-matrix rows (level 3) -- three dependent global latencies.  While row r is summed, the
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
     }
     return m;
   };
-  const int row0 = blockIdx.x * 4 + wave;
+  const int row0 = (blockIdx.x * 4 + wave) * RPW + sub;
   Meta m_cur = load_meta(row0), m_nxt = load_meta(row0 + nwaves);
   int e_cur = (lane < m_cur.ni) ? g.inc_elem[m_cur.i0 + lane] : 0, p_cur = (lane < m_cur.ni) ? g.inc_pos[m_cur.i0 + lane] : 0;
   for (int row = row0; row < b.nrows; row += nwaves) {
@@ -62,22 +65,26 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
     const int lo = m_cur.lo, len = m_cur.len, i0 = m_cur.i0, ni = m_cur.ni;
     if (m_cur.fixed) {  // isFixedDOF rows are skipped by the scatter (assemblyManager.cpp:4075,4120)
       if (overwrite) {
-        if (vals) for (int k = lane; k < len; k += 64) vals[lo + k] = 0.0;
+        if (vals) for (int k = lane; k < len; k += LPR) vals[lo + k] = 0.0;
         if (res && lane == 0) res[row] = 0.0;
       }
     } else {
       if (vals) {
         const int total = ni * n;
-        for (int t = lane; t < total; t += 64) {
-          const int k = t / n, sj = t - k * n;
-          // incidences 0..63 sit in the wave's registers; longer rows (never for quads / hexes) re-read them
-          const int e = k < 64 ? __shfl(e_cur, k) : g.inc_elem[i0 + k];
-          const int pos = k < 64 ? __shfl(p_cur, k) : g.inc_pos[i0 + k];
-          const size_t off = ((size_t)e * n + pos) * n + sj;
-          unsafeAtomicAdd(acc + slot[off], local_J[off]);
+        for (int t0 = 0; t0 < total; t0 += LPR) {  // trip count uniform in the row group: every lane takes part in the shuffles
+          const int t = t0 + lane;
+          const bool valid = t < total;
+          const int k = valid ? t / n : 0, sj = t - k * n;
+          // incidences 0..LPR-1 sit in the row group's registers; longer rows (never for quads / hexes) re-read them
+          int e = __shfl(e_cur, k & (LPR - 1), LPR), pos = __shfl(p_cur, k & (LPR - 1), LPR);
+          if (valid) {
+            if (k >= LPR) { e = g.inc_elem[i0 + k]; pos = g.inc_pos[i0 + k]; }
+            const size_t off = ((size_t)e * n + pos) * n + sj;
+            unsafeAtomicAdd(acc + slot[off], local_J[off]);
+          }
         }
         wave_lds_sync();
-        for (int k = lane; k < len; k += 64) {
+        for (int k = lane; k < len; k += LPR) {
           const double a = acc[k];
           acc[k] = 0.0;
           vals[lo + k] = overwrite ? a : vals[lo + k] + a;
@@ -86,12 +93,12 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
       }
       if (res) {
         double r = 0.0;
-        for (int k = lane; k < ni; k += 64) {
-          const int e = k < 64 ? e_cur : g.inc_elem[i0 + k], pos = k < 64 ? p_cur : g.inc_pos[i0 + k];
+        for (int k = lane; k < ni; k += LPR) {
+          const int e = k < LPR ? e_cur : g.inc_elem[i0 + k], pos = k < LPR ? p_cur : g.inc_pos[i0 + k];
           r += local_res[(size_t)e * n + pos];
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+        for (int o = LPR / 2; o > 0; o >>= 1) r += __shfl_xor(r, o, LPR);
         if (lane == 0) res[row] = overwrite ? r : res[row] + r;
       }
     }
@@ -107,15 +114,16 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
 void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *local_J, const double *local_res,
                        double *res, double *vals, int overwrite, hipStream_t stream) {
   if (b.nrows <= 0) return;
-  const size_t lds = sizeof(double) * 4 * (size_t)g.max_row;
+  const bool small_rows = g.max_row <= 32 && b.n <= 16;
+  const int rpw = small_rows ? 4 : 1;
+  const size_t lds = sizeof(double) * 4 * rpw * (size_t)g.max_row;
   MHA_REQUIRE(lds <= 64 * 1024, MHA_ERR_INVALID, "CRS rows of " << g.max_row << " entries do not fit the row-gather kernel");
-  const int grid = std::min((b.nrows + 3) / 4, 256 * 8);
-  if (g.slot_bytes == 1)
-    hipLaunchKernelGGL(row_gather_kernel<uint8_t>, dim3(grid), dim3(256), lds, stream, b, g, local_J, local_res, res, vals,
-                       overwrite);
-  else
-    hipLaunchKernelGGL(row_gather_kernel<uint16_t>, dim3(grid), dim3(256), lds, stream, b, g, local_J, local_res, res, vals,
-                       overwrite);
+  const int grid = std::min((b.nrows + 4 * rpw - 1) / (4 * rpw), 256 * 8);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, b, g, local_J, local_res, res, vals, overwrite);
+  };
+  if (g.slot_bytes == 1) { if (small_rows) go(row_gather_kernel<uint8_t, 16>); else go(row_gather_kernel<uint8_t, 64>); }
+  else { if (small_rows) go(row_gather_kernel<uint16_t, 16>); else go(row_gather_kernel<uint16_t, 64>); }
   MHA_HIP(hipGetLastError());
 }
 

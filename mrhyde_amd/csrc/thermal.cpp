@@ -1,5 +1,7 @@
 #include "physics.hpp"
 
+#include <cstdlib>
+
 namespace mha {
 
 thermal::thermal() {
@@ -106,7 +108,13 @@ void porousMixed::volumeResidual() {
   pp.physics = MHA_PHYSICS_POROUS_MIXED;
   const char *names[5] = {"source", "Kinv_xx", "Kinv_yy", "Kinv_zz", "total_mobility"};
   for (int k = 0; k < 5; ++k) pp.f[k] = functionManager->evaluate(names[k]);
-  launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
+  // dense element arrays (row-gather path, mha_compute_local_jacres): the thread-per-element kernel; global outputs
+  // (atomic scatter): the point engine.  MHA_POROUS_KERNEL=engine forces the engine.
+  static const bool force_engine = [] { const char *m = std::getenv("MHA_POROUS_KERNEL"); return m && m[0] == 'e'; }();
+  if (!force_engine && w.res.res == nullptr && w.res.crs_vals == nullptr)
+    launch_porous_element(b, w.layout, pp, w.time_dev, w.res, w.stream);
+  else
+    launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
 }
 
 // reference: porousMixed::boundaryResidual (porousMixed.cpp:345-432): bcs(pnum, side) == "Dirichlet" adds
