@@ -74,6 +74,7 @@ AssemblyManager::AssemblyManager(const mha_block_desc &desc) {
   wkset_.dimension = dim_;
   wkset_.numip = nq_;
   wkset_.numVars = static_cast<int>(vars_.size());
+  wkset_.single_hgrad = single_hgrad_;
   buildVarLayout();
   wkset_.order = order_;
   wkset_.nq1 = ref_.nq1;

@@ -53,6 +53,7 @@ class Workset {
   // multi-variable point engine (kernels/point_engine.hip): variable/slot layout, orientation signs
   VarLayoutDev layout;
   bool use_point_engine = false;
+  bool single_hgrad = true;  // basis / basis_grad views exist for single-variable HGRAD blocks only
   hipStream_t stream = nullptr;
   int order = 0, nq1 = 0;
 
@@ -83,15 +84,17 @@ class Workset {
 inline void Workset::update_views() {
   const size_t ne = static_cast<size_t>(numElem), n = dev.n, nq = dev.nq, d = dev.dim;
   const size_t cap = static_cast<size_t>(maxElem > numElem ? maxElem : numElem);
-  if (basis_.size() < cap * n * nq) {
+  if (single_hgrad && basis_.size() < cap * n * nq) {
     basis_.resize(cap * n * nq);
     basis_grad_.resize(cap * n * nq * d);
+  }
+  if (wts_.size() < cap * nq) {
     wts_.resize(cap * nq);
     for (size_t k = 0; k < d; ++k) xyz_[k].resize(cap * nq);
   }
   WorksetViewsDev v;
-  v.basis = basis_.data();
-  v.basis_grad = basis_grad_.data();
+  v.basis = single_hgrad ? basis_.data() : nullptr;
+  v.basis_grad = single_hgrad ? basis_grad_.data() : nullptr;
   v.wts = wts_.data();
   for (size_t k = 0; k < d; ++k) v.xyz[k] = xyz_[k].data();
   launch_workset_views(dev, first_elem, static_cast<int>(ne), v, stream);
@@ -105,7 +108,9 @@ inline View Workset::get(const std::string &name) const {
   auto need_views = [&]() {
     MHA_REQUIRE(views_first_ >= 0, MHA_ERR_STATE, "workset views requested before mha_workset_update");
   };
-  if (name == "basis") {
+  if ((name == "basis" || name == "basis_grad") && !single_hgrad) {
+    throw Error(MHA_ERR_UNKNOWN_FIELD, "'" + name + "' views are available for single-variable HGRAD blocks");
+  } else if (name == "basis") {
     need_views();
     v.ptr = basis_.data(); v.rank = 4; v.extent[0] = ne; v.extent[1] = n; v.extent[2] = nq; v.extent[3] = 1;
   } else if (name == "basis_grad") {

@@ -325,3 +325,20 @@ def test_single_element_and_ragged_groups(oracle, physics):
         blk.assemble_jacres(ud, res2, None, compute_jacobian=False, path=mrhyde_amd.PATH_POINT_ENGINE)
         torch.cuda.synchronize()
         assert rel_err(res2.cpu().numpy(), ref["res"]) < RTOL
+
+
+def test_workset_views_of_multi_variable_blocks(oracle):
+    """Geometry views (wts, x, y, z) work for any block; per-variable basis views are not built and say so."""
+    _torch()
+    import mrhyde_amd
+    m = warp(oracle.mesh_multi(3, (3, 2, 2), [oracle.HVOL, oracle.HDIV], [0, 1]))
+    blk = make_block(m, "porousMixed", 2)
+    ref = oracle.physical_basis_var(3, oracle.HVOL, 0, 2, m["nodes"])
+    blk.workset_update(0)
+    assert rel_err(blk.workset_view_numpy("wts"), ref["wts"]) < RTOL
+    for d, c in enumerate("xyz"):
+        assert rel_err(blk.workset_view_numpy(c), ref["ip"][..., d]) < RTOL
+    assert np.array_equal(blk.workset_view_numpy("LIDs"), m["lids"])
+    with pytest.raises(mrhyde_amd.MhaError) as e:
+        blk.workset_view("basis")
+    assert e.value.code == 4
