@@ -163,6 +163,11 @@ int mha_assemble_jacres(mha_context *ctx, int flags, int path, const double *u_d
 int mha_compute_local_jacres(mha_context *ctx, int compute_jacobian, const double *u_dev,
                              const double *u_prev_dev, const double *u_stage_dev, double *local_J_dev,
                              double *local_res_dev);
+/* replaces: getMass / getWeightedMass  assemblyManager.cpp:7776-7840, 7847-7925: dense element mass matrices
+ * local_mass_dev[E][n][n] += sum_q basis_v(i,q) . basis_v(j,q) wts(q) * masswts[v] at (offsets(v,i), offsets(v,j)),
+ * every variable of the block (HGRAD / HVOL values, HDIV vector values); masswts_host[num_vars] or NULL (= 1).
+ * mha_scatter_local turns them into CRS values.                                                          */
+int mha_get_mass(mha_context *ctx, const double *masswts_host, double *local_mass_dev);
 /* replaces: scatterJac / scatterRes  assemblyManager.cpp:3882-3935, 3943-3978          */
 int mha_scatter_local(mha_context *ctx, const double *local_J_dev, const double *local_res_dev,
                       double *res_dev, double *crs_vals_dev);

@@ -542,6 +542,31 @@ void AssemblyManager::computeLocalJacRes(int compute_jacobian, const double *u, 
   timedEnd();
 }
 
+// reference: AssemblyManager::getMass / getWeightedMass (assemblyManager.cpp:7776-7925): dense element mass matrices,
+// accumulated (+=) into local_mass[E][n][n] in LID-position order.  Runs the point engine with the value slots as
+// the "flux" (kernels/point_engine.hip, mass mode): the mass matrix is the B^T C B product with C = weights.
+void AssemblyManager::getMass(const double *masswts, double *local_mass) {
+  requireReady(false);
+  MHA_REQUIRE(local_mass != nullptr, MHA_ERR_INVALID, "local_mass is null");
+  DeviceBuffer<double> zero_u(static_cast<size_t>(nrows_));
+  MHA_HIP(hipMemsetAsync(zero_u.data(), 0, sizeof(double) * nrows_, stream_));
+  TimeDev steady;
+  steady.u = zero_u.data();
+  BlockDev b = blockDev();
+  VarLayoutDev vl = layout_;
+  vl.orient = has_orient_ ? d_orient_.data() : nullptr;
+  PhysParamsDev pp;
+  pp.physics = -physics_id_;  // negative id = mass mode on the module's variable layout
+  for (size_t v = 0; v < vars_.size(); ++v) pp.p[v] = masswts ? masswts[v] : 1.0;
+  ElemOut o;
+  o.compute_jacobian = 1;
+  o.local_J = local_mass;
+  timedBegin();
+  launch_point_engine(b, vl, pp, steady, o, nullptr, 1, stream_);
+  timedEnd();
+  MHA_HIP(hipStreamSynchronize(stream_));  // zero_u is released on return
+}
+
 void AssemblyManager::scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals) {
   requireReady(true);
   timedBegin();

@@ -36,6 +36,7 @@ class AssemblyManager {
                       const double *u_stage, double *res, double *crs_vals);
   void computeLocalJacRes(int compute_jacobian, const double *u, const double *u_prev, const double *u_stage,
                           double *local_J, double *local_res);
+  void getMass(const double *masswts, double *local_mass);
   void scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals);
   // boundary groups (reference: src/tools/boundaryGroup.hpp, assemblyManager.cpp:2518-2638)
   int addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,

@@ -125,6 +125,10 @@ int mha_compute_local_jacres(mha_context *ctx, int compute_jacobian, const doubl
   return guarded([&] { mgr(ctx).computeLocalJacRes(compute_jacobian, u, u_prev, u_stage, local_J, local_res); });
 }
 
+int mha_get_mass(mha_context *ctx, const double *masswts_host, double *local_mass_dev) {
+  return guarded([&] { mgr(ctx).getMass(masswts_host, local_mass_dev); });
+}
+
 int mha_scatter_local(mha_context *ctx, const double *local_J, const double *local_res, double *res,
                       double *crs_vals) {
   return guarded([&] { mgr(ctx).scatterLocal(local_J, local_res, res, crs_vals); });

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
   double *s_u = s_geo + NQ * GEO, *s_ud = s_u + n, *s_sgn = s_ud + n;
   int *s_row = reinterpret_cast<int *>(s_sgn + n), *s_pos = s_row + n;
 
-  const int dbg_stop = (int)pp.p[7];  // profiling aid (MHA_ENGINE_STOP): leave the element after phase k
+  const bool mass_mode = pp.physics < 0;  // launch_point_engine_mass: p[v] = mass weight of variable v
+  const int dbg_stop = mass_mode ? 0 : (int)pp.p[7];  // profiling aid (MHA_ENGINE_STOP): leave the element after phase k
   for (int k = tid; k < vl.tables_size; k += kEngineThreads) tab[k] = vl.tables[k];
   __syncthreads();
 
@@ -292,7 +293,15 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       PointArgs<DIM> pa;
       pa.U = U; pa.Ud = Ud; pa.x = g + 2 * DIM * DIM + 2; pa.h = h; pa.dt = tm.dt;
       pa.transient = tm.transient; pa.e = e; pa.q = q; pa.nq = NQ; pa.pp = &pp;
-      if constexpr (PHYS == MHA_PHYSICS_THERMAL) thermal_point<DIM>(pa, F);
+      if (mass_mode) {
+        // getWeightedMass: F = masswts[var] * value on the value-like slots, nothing on gradients / divergence
+#pragma unroll
+        for (int v = 0; v < L::nvars; ++v) {
+          const int type = L::type(v), sp = slotptr_of<L, DIM>(v), ns = slots_of(type, DIM);
+#pragma unroll
+          for (int sl = 0; sl < ns; ++sl) F[sp + sl] = value_like(type, sl, DIM) ? U[sp + sl] * pp.p[v] : mk(0.0);
+        }
+      } else if constexpr (PHYS == MHA_PHYSICS_THERMAL) thermal_point<DIM>(pa, F);
       else if constexpr (PHYS == MHA_PHYSICS_POROUS_MIXED) porous_point<DIM>(pa, F);
       else if constexpr (PHYS == MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED) swhdg_point<DIM>(pa, F);
       else navierstokes_point<DIM>(pa, F);
@@ -452,7 +461,7 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
   }
   const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(size_t(2), (160 * 1024) / lds)));
   PhysParamsDev ppd = pp;
-  if (const char *st = std::getenv("MHA_ENGINE_STOP")) ppd.p[7] = std::atof(st);
+  if (const char *st = std::getenv("MHA_ENGINE_STOP")) { if (pp.physics > 0) ppd.p[7] = std::atof(st); }
   const int grid = std::max(1, std::min((b.e_count + groups - 1) / groups, num_cu * per_cu));
   const uint8_t *s8 = (slot && slot_bytes == 1) ? static_cast<const uint8_t *>(slot) : nullptr;
   const uint16_t *s16 = (slot && slot_bytes == 2) ? static_cast<const uint16_t *>(slot) : nullptr;
@@ -482,7 +491,7 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
                          const ElemOut &out, const void *slot, int slot_bytes, hipStream_t stream) {
   if (b.e_count <= 0) return;
-  const int key = b.dim * 10 + pp.physics;
+  const int key = b.dim * 10 + (pp.physics < 0 ? -pp.physics : pp.physics);
   switch (key) {
     case 20 + MHA_PHYSICS_THERMAL: launch_typed<2, MHA_PHYSICS_THERMAL>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;
     case 30 + MHA_PHYSICS_THERMAL: launch_typed<3, MHA_PHYSICS_THERMAL>(b, vl, pp, tm, out, slot, slot_bytes, stream); break;

@@ -246,6 +246,11 @@ typedef struct orc_block_args {
 /* volume terms: gather -> seed -> fields -> <physics>::volumeResidual -> scatter, AD arrays of width n_tot
  * (porousMixed.cpp:158-338, navierstokes.cpp:82-849, thermal.cpp:71-165)                                  */
 int orc_assemble_block(const orc_block_args *a);
+/* AssemblyManager::getWeightedMass (assemblyManager.cpp:7847-7925; getMass :7776-7840 = all weights 1): dense element
+ * mass matrices mass[E][n_tot][n_tot] += sum_q basis_v(i,q) . basis_v(j,q) wts(q) masswts[v] at (off_v(i), off_v(j)),
+ * HGRAD/HVOL: value; HDIV: dot product of the vector values.  Uses dim, qdeg, nvars, types, orders, nelem, nodes,
+ * offsets, orient of the block description.                                                                  */
+int orc_get_mass(const orc_block_args *a, const double *masswts, double *mass);
 /* boundary terms (porousMixed::boundaryResidual, porousMixed.cpp:345-432)                                  */
 int orc_assemble_block_boundary(const orc_block_args *a);
 /* HDIV side basis of boundary entries: basis[nb][n][nqs][dim] = J phi/detJ at the side points (with orientation) */

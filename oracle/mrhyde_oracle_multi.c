@@ -765,6 +765,30 @@ int orc_assemble_block(const orc_block_args *a) {
   return 0;
 }
 
+int orc_get_mass(const orc_block_args *a, const double *masswts, double *mass) {
+  blk_ctx c;
+  if (ctx_init(&c, a)) return -1;
+  const int n = c.n_tot, nq = c.nq, dim = a->dim;
+  for (size_t e = 0; e < (size_t)a->nelem; ++e) {
+    const double *xn = a->nodes + e * c.nn * dim;
+    for (int v = 0; v < a->nvars; ++v)
+      orc_physical_basis_var(dim, a->types[v], a->orders[v], a->qdeg, 1, xn, a->orient ? a->orient + e * n : NULL, 0,
+                             c.varptr[v], c.basis[v], c.grad[v], c.div[v], v == 0 ? c.wts : NULL, NULL);
+    for (int v = 0; v < a->nvars; ++v) {
+      const int card = c.varptr[v + 1] - c.varptr[v], nc = ncomp_of(dim, a->types[v]);
+      const double mwt = masswts ? masswts[v] : 1.0;
+      for (int i = 0; i < card; ++i)
+        for (int j = 0; j < card; ++j)
+          for (int k = 0; k < nq; ++k)
+            for (int d = 0; d < nc; ++d)
+              mass[(e * n + a->offsets[c.varptr[v] + i]) * n + a->offsets[c.varptr[v] + j]] +=
+                  c.basis[v][((size_t)i * nq + k) * nc + d] * c.basis[v][((size_t)j * nq + k) * nc + d] * c.wts[k] * mwt;
+    }
+  }
+  ctx_free(&c);
+  return 0;
+}
+
 int orc_assemble_block_boundary(const orc_block_args *a) {
   blk_ctx c;
   if (ctx_init(&c, a)) return -1;

@@ -503,6 +503,27 @@ def assemble_block(m, physics, qdeg, u, *, funcs=None, params=None, fixed=None, 
     return out
 
 
+def get_mass(m, qdeg, masswts=None):
+    """Dense element mass matrices [E][n_tot][n_tot] (getWeightedMass)."""
+    keep = []
+    a = _block_args(m, PHYS_THERMAL if len(m["types"]) == 1 else PHYS_POROUS_MIXED, qdeg, np.zeros(m["ndof"]), None, None,
+                    None, None, True, keep) if False else None
+    a = BlockArgs()
+    a.dim, a.qdeg, a.nvars = m["dim"], qdeg, len(m["types"])
+    for v, (t, o) in enumerate(zip(m["types"], m["orders"])):
+        a.types[v], a.orders[v] = int(t), int(o)
+    nodes = np.ascontiguousarray(m["nodes"], dtype=np.float64)
+    offsets = np.ascontiguousarray(m["offsets"], dtype=np.int32)
+    orient = np.ascontiguousarray(m["orient"], dtype=np.int8)
+    a.nelem, a.nodes, a.offsets, a.orient = nodes.shape[0], _d(nodes), _i(offsets), orient.ctypes.data_as(_sp)
+    E, n = m["lids"].shape
+    mass = np.zeros((E, n, n))
+    w = None if masswts is None else np.ascontiguousarray(masswts, dtype=np.float64)
+    rc = lib().orc_get_mass(C.byref(a), _d(w), _d(mass))
+    assert rc == 0, rc
+    return mass
+
+
 def assemble_block_boundary(m, physics, qdeg, u, belem, bside, bc_type, data, *, rowptr, colind, crs_vals, res,
                             funcs=None, params=None, fixed=None, transient=None, compute_jacobian=True):
     keep = []
