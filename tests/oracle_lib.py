@@ -505,9 +505,6 @@ def assemble_block(m, physics, qdeg, u, *, funcs=None, params=None, fixed=None, 
 
 def get_mass(m, qdeg, masswts=None):
     """Dense element mass matrices [E][n_tot][n_tot] (getWeightedMass)."""
-    keep = []
-    a = _block_args(m, PHYS_THERMAL if len(m["types"]) == 1 else PHYS_POROUS_MIXED, qdeg, np.zeros(m["ndof"]), None, None,
-                    None, None, True, keep) if False else None
     a = BlockArgs()
     a.dim, a.qdeg, a.nvars = m["dim"], qdeg, len(m["types"])
     for v, (t, o) in enumerate(zip(m["types"], m["orders"])):
