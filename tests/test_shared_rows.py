@@ -118,3 +118,70 @@ def test_two_slabs_equal_single_domain(oracle, order, nxy, nz_per):
                 k += 1
             assert k == len(remote_vals)
             assert wire == (up_rowptr[P] + P) * 8
+
+
+def _worker_ns(rank, world, port, nxy, nz_per, q):
+    """Same exchange for a multi-variable block (navierstokes Q2/Q1: ux, pr, uy, uz interleaved per node): the shared
+    plane is still the first / last P rows of a slab, P = dofs of all variables on the plane."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import oracle_lib as orc
+    from mrhyde_amd.shared_rows import SlabExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H = orc.HGRAD
+        m = orc.mesh_multi(3, (nxy, nxy, nz_per), [H] * 4, [2, 1, 2, 2], lo=[0.0, 0.0, float(rank)],
+                           hi=[1.0, 1.0, float(rank + 1)])
+        nrows = m["ndof"]
+        P = int(((m["side_mask"] >> 4) & 1).sum())  # dofs on the z- plane
+        assert np.all(((m["side_mask"][:P] >> 4) & 1) == 1) and np.all(((m["side_mask"][-P:] >> 5) & 1) == 1)
+        rng = np.random.default_rng(77)
+        u_glob = rng.uniform(-1, 1, P + world * (nrows - P))
+        off = rank * (nrows - P)
+        u = u_glob[off:off + nrows]
+        funcs = {"source ux": 0.3, "viscosity": 0.05, "density": 1.3}
+        out = orc.assemble_block(m, orc.PHYS_NAVIERSTOKES, 4, u, funcs=funcs, params=[0, 0, 1])
+        vals, res = torch.tensor(out["crs_vals"]), torch.tensor(out["res"])
+        ex = SlabExchange(out["rowptr"], out["colind"], P, nrows, rank, world, torch.device("cpu"))
+        ex.export_add(res, vals)
+        q.put((rank, out["rowptr"], out["colind"], vals.numpy(), res.numpy(), off, P))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_slabs_navierstokes_block(oracle):
+    nxy, nz_per, world = 2, 1, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ns, args=(r, world, port, nxy, nz_per, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=180)
+        got[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H = oracle.HGRAD
+    mg = oracle.mesh_multi(3, (nxy, nxy, nz_per * world), [H] * 4, [2, 1, 2, 2], hi=[1.0, 1.0, float(world)])
+    rng = np.random.default_rng(77)
+    u_glob = rng.uniform(-1, 1, mg["ndof"])
+    ref = oracle.assemble_block(mg, oracle.PHYS_NAVIERSTOKES, 4, u_glob,
+                                funcs={"source ux": 0.3, "viscosity": 0.05, "density": 1.3}, params=[0, 0, 1])
+    Jg = sp.csr_matrix((ref["crs_vals"], ref["colind"], ref["rowptr"]), shape=(mg["ndof"],) * 2).toarray()
+    scale = np.abs(Jg).max()
+    for rank in range(world):
+        _, rowptr, colind, vals, res, off, P = got[rank]
+        nrows = len(rowptr) - 1
+        Jl = sp.csr_matrix((vals, colind, rowptr), shape=(nrows, nrows)).toarray()
+        owned = np.arange(nrows) if rank == 0 else np.arange(P, nrows)
+        for r in owned:
+            assert np.abs(Jl[r] - Jg[r + off][off:off + nrows]).max() <= 1e-12 * scale, (rank, r)
+            assert abs(res[r] - ref["res"][r + off]) <= 1e-12 * np.abs(ref["res"]).max()
