@@ -211,6 +211,15 @@ int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t
  * "basis side" (num,n,numip,1) "basis_grad side" (num,n,numip,dim).                        */
 #define MHA_BC_NEUMANN 1
 #define MHA_BC_WEAK_DIRICHLET 2
+/* shallowwaterHybridized side types (bcs(H_num, side): "interface", "Far-field", "Slip",
+ * shallowwaterHybridized.cpp:286-300, 612-620): the group's entries are element sides (all four sides of every
+ * element for the HDG interior problem); the trace state comes from the functions "aux H <sidename>",
+ * "aux Hux <sidename>", "aux Huy <sidename>" (constants or dev arrays [num_sides][side numip]), the far-field state
+ * from "Far-field H <sidename>", ... (:648-653).  mha_assemble_boundary adds boundaryResidual (:190-263) and its
+ * derivative with respect to the interior unknowns; settings "Roe-like stabilization" (default 1; 0 = max EV), "g". */
+#define MHA_BC_SWH_INTERFACE 10
+#define MHA_BC_SWH_FARFIELD 11
+#define MHA_BC_SWH_SLIP 12
 int mha_add_boundary_group(mha_context *ctx, const char *sidename, int bc_type, int num_sides,
                            const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id);
 int mha_clear_boundary_groups(mha_context *ctx);

@@ -31,6 +31,7 @@ PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3, "shallowwaterH
 PATH_POINT_ENGINE = 4
 PATH_ROW_GATHER = 5
 BC_NEUMANN, BC_WEAK_DIRICHLET = 1, 2
+BC_SWH_INTERFACE, BC_SWH_FARFIELD, BC_SWH_SLIP = 10, 11, 12
 
 
 class MhaError(RuntimeError):

@@ -649,8 +649,9 @@ BoundaryDev AssemblyManager::boundaryDev(const BoundaryGroupData &g) const {
 int AssemblyManager::addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,
                                       const int32_t *side_ids) {
   MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
-  MHA_REQUIRE(bc_type == MHA_BC_NEUMANN || bc_type == MHA_BC_WEAK_DIRICHLET, MHA_ERR_INVALID,
-              "boundary-condition type must be MHA_BC_NEUMANN or MHA_BC_WEAK_DIRICHLET");
+  MHA_REQUIRE(bc_type == MHA_BC_NEUMANN || bc_type == MHA_BC_WEAK_DIRICHLET ||
+                  (bc_type >= MHA_BC_SWH_INTERFACE && bc_type <= MHA_BC_SWH_SLIP),
+              MHA_ERR_INVALID, "boundary-condition type must be one of MHA_BC_*");
   MHA_REQUIRE(num >= 0 && (num == 0 || (elem_ids && side_ids)), MHA_ERR_INVALID, "bad boundary entry arrays");
   MHA_REQUIRE(!sidename.empty(), MHA_ERR_INVALID, "side name is empty");
   prepareSideTables();

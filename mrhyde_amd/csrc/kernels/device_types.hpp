@@ -165,6 +165,14 @@ struct SwhSideArgs {
   double *L = nullptr, *lam = nullptr, *R = nullptr;  // eigendecomposition at Shat, [npts][3][3], [npts][3], [npts][3][3]
 };
 
+// shallowwaterHybridized::boundaryResidual on a boundary group (kernels/swhdg_boundary.hip)
+struct SwhBoundaryDev {
+  int side_type = 0, roe = 1;   // MHA_SWH_*; Roe-like (1) or max-eigenvalue (0) stabilisation
+  double g = 9.81;
+  FuncDesc aux[3];              // trace state "aux H|Hux|Huy <side>" at the side points ([num][nqs] arrays or constants)
+  FuncDesc farfield[3];         // "Far-field H|Hux|Huy <side>"
+};
+
 // Destination of the row-owner kernels.
 struct RowOut {
   double *res = nullptr;

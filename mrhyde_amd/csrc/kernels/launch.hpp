@@ -70,6 +70,10 @@ void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *l
 // swhdg_side.hip: shallowwaterHybridized side terms + derivatives, one thread per side point
 void launch_swhdg_side(const SwhSideArgs &a, hipStream_t stream);
 
+// swhdg_boundary.hip: shallowwaterHybridized::boundaryResidual, trace state given at the side points
+void launch_swhdg_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const SwhBoundaryDev &sw,
+                           const TimeDev &tm, const ElemOut &out, hipStream_t stream);
+
 // point_engine.hip: multi-variable blocks, any physics module stated as a point function
 // slot: element-major CRS slot map (launch_build_elem_slot_map) or null for the column search
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,

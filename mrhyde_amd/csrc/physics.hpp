@@ -104,6 +104,8 @@ class shallowwaterHybridized : public PhysicsBase {
   shallowwaterHybridized();
   void defineFunctions(FunctionManager &fm) override;
   void volumeResidual() override;
+  void boundaryResidual() override;
+  bool roestab = true;    // settings "Roe-like stabilization" / "max EV stabilization" (shallowwaterHybridized.cpp:60-66)
   void setParameter(const std::string &name, double value) override;
   double gravity = 9.81;  // settings "g" (shallowwaterHybridized.cpp:72)
 };

@@ -187,6 +187,8 @@ void shallowwaterHybridized::defineFunctions(FunctionManager &fm) {
 
 void shallowwaterHybridized::setParameter(const std::string &name, double value) {
   if (name == "g") gravity = value;
+  else if (name == "Roe-like stabilization") roestab = value != 0.0;
+  else if (name == "max EV stabilization") roestab = value == 0.0;
   else PhysicsBase::setParameter(name, value);
 }
 
@@ -203,6 +205,27 @@ void shallowwaterHybridized::volumeResidual() {
   for (int k = 0; k < 3; ++k) pp.f[k] = functionManager->evaluate(names[k]);
   pp.p[0] = gravity;
   launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
+}
+
+// reference: shallowwaterHybridized::boundaryResidual (:190-263) on the current boundary group; the trace ("aux") state
+// and the far-field state are functions evaluated at the side points
+void shallowwaterHybridized::boundaryResidual() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "shallowwaterHybridized::boundaryResidual called without a workset");
+  Workset &w = *wkset;
+  if (w.current_bc < MHA_BC_SWH_INTERFACE || w.current_bc > MHA_BC_SWH_SLIP) return;
+  SwhBoundaryDev sw;
+  sw.side_type = w.current_bc - MHA_BC_SWH_INTERFACE;
+  sw.roe = roestab ? 1 : 0;
+  sw.g = gravity;
+  const char *vars[3] = {"H", "Hux", "Huy"};
+  for (int i = 0; i < 3; ++i) {
+    sw.aux[i] = functionManager->evaluate(std::string("aux ") + vars[i] + " " + w.sidename);
+    if (w.current_bc == MHA_BC_SWH_FARFIELD)
+      sw.farfield[i] = functionManager->evaluate(std::string("Far-field ") + vars[i] + " " + w.sidename);
+    else
+      sw.farfield[i] = sw.aux[i];
+  }
+  launch_swhdg_boundary(w.dev, w.side_tables, w.bnd, sw, w.time_dev, w.res, w.stream);
 }
 
 std::unique_ptr<PhysicsBase> import_physics(int physics_id) {

@@ -240,8 +240,12 @@ typedef struct orc_block_args {
   /* boundary entries (orc_assemble_block_boundary only) */
   int nb;
   const int *belem, *bside;
-  int bc_type;                  /* porousMixed: 1 = "Dirichlet" on p (weak, porousMixed.cpp:400-418) */
+  int bc_type;                  /* porousMixed: 1 = "Dirichlet" on p (weak, porousMixed.cpp:400-418);
+                                   shallowwaterHybridized: 10 interface, 11 Far-field, 12 Slip                */
   orc_func bdata;               /* "Dirichlet p <side>" at the side ip */
+  /* shallowwaterHybridized: trace ("aux") state and far-field state at the side ip, [nb][nqs][3] (H, Hux, Huy);
+   * params = {g, Roe-like stabilisation (1) or max-EV (0)}                                                     */
+  const double *aux_ip, *farfield_ip;
 } orc_block_args;
 /* volume terms: gather -> seed -> fields -> <physics>::volumeResidual -> scatter, AD arrays of width n_tot
  * (porousMixed.cpp:158-338, navierstokes.cpp:82-849, thermal.cpp:71-165)                                  */

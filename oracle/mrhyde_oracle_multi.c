@@ -789,7 +789,79 @@ int orc_get_mass(const orc_block_args *a, const double *masswts, double *mass) {
   return 0;
 }
 
+/* shallowwaterHybridized::boundaryResidual (shallowwaterHybridized.cpp:190-263): res(off_i(dof)) += (F(Shat).n +
+ * stab)_i wts basis_side(dof) on interface sides, the boundary term B on Far-field / Slip sides (computeFlux :270-368
+ * stores the same quantity per point).  The eigendecomposition depends on the trace state only, so the flux is affine
+ * in the interior state on interface / far-field sides: flux = c + M (S_AD - Shat); Slip is written out in AD ops. */
+static int swh_boundary(const orc_block_args *a) {
+  blk_ctx c;
+  if (ctx_init(&c, a)) return -1;
+  g_w1 = c.n_tot + 1;
+  int ns, nqs;
+  orc_side_sizes(a->dim, a->qdeg, &ns, &nqs);
+  const int dim = 2, nv = 3, nb = a->nb, order = a->orders[0], n = c.varptr[1];
+  const double g = a->params[0];
+  const int roe = a->params[1] != 0.0, stype = a->bc_type - 10;
+  double *wts = malloc(sizeof(double) * (size_t)nb * nqs), *nrm = malloc(sizeof(double) * (size_t)nb * nqs * dim);
+  double *bas = malloc(sizeof(double) * (size_t)nb * n * nqs);
+  orc_physical_side_basis(dim, order, a->qdeg, nb, a->nodes, a->belem, a->bside, wts, nrm, NULL, bas, NULL);
+  ad_t *res = malloc(sizeof(ad_t) * c.n_tot);
+  for (int k = 0; k < nb; ++k) {
+    const size_t e = (size_t)a->belem[k];
+    gather_seed(&c, e);
+    for (int j = 0; j < c.n_tot; ++j) res[j] = ad_c(0.0);
+    for (int pt = 0; pt < nqs; ++pt) {
+      const double w = wts[(size_t)k * nqs + pt], *nq = nrm + ((size_t)k * nqs + pt) * dim;
+      const double *Sh = a->aux_ip + ((size_t)k * nqs + pt) * nv;
+      const double *Sinf = a->farfield_ip ? a->farfield_ip + ((size_t)k * nqs + pt) * nv : Sh;
+      ad_t S[3], flux[3];
+      double Sv[3];
+      for (int i = 0; i < nv; ++i) { /* side solution fields (evaluateSideSolutionField, workset.cpp:1069-1176) */
+        S[i] = ad_c(0.0);
+        for (int dof = 0; dof < n; ++dof) {
+          const double b = bas[((size_t)k * n + dof) * nqs + pt];
+          const ad_t *s = &c.uAD[c.varptr[i] + dof];
+          for (int j = 0; j < g_w1; ++j) S[i].v[j] += s->v[j] * b;
+        }
+        Sv[i] = S[i].v[0];
+      }
+      if (stype == 2) { /* Slip (:729-745) */
+        ad_t ux = ad_div(&S[1], &S[0]), uy = ad_div(&S[2], &S[0]);
+        ad_t vn = ad_scale(ux, nq[0]);
+        ad_t t = ad_scale(uy, nq[1]);
+        vn = ad_add(vn, &t);
+        flux[0] = S[0]; flux[0].v[0] -= Sh[0];
+        ad_t a1 = ad_scale(vn, nq[0]), a2 = ad_scale(vn, nq[1]);
+        flux[1] = ad_sub(ux, &a1); flux[1].v[0] -= Sh[1] / Sh[0];
+        flux[2] = ad_sub(uy, &a2); flux[2].v[0] -= Sh[2] / Sh[0];
+      } else { /* value from the point functions, slope M = d flux / d S by columns (affine in S) */
+        double f0[3], M[9];
+        orc_swh_interface_flux(dim, stype, roe, Sv, Sh, Sinf, nq, g, f0);
+        for (int j = 0; j < nv; ++j) {
+          double Sp[3] = {Sv[0], Sv[1], Sv[2]}, f1[3];
+          Sp[j] += 1.0;
+          orc_swh_interface_flux(dim, stype, roe, Sp, Sh, Sinf, nq, g, f1);
+          for (int i = 0; i < nv; ++i) M[i * 3 + j] = f1[i] - f0[i];
+        }
+        for (int i = 0; i < nv; ++i) {
+          flux[i] = ad_c(f0[i]);
+          for (int j = 0; j < nv; ++j)
+            for (int q = 1; q < g_w1; ++q) flux[i].v[q] += M[i * 3 + j] * S[j].v[q];
+        }
+      }
+      for (int i = 0; i < nv; ++i)
+        for (int dof = 0; dof < n; ++dof)
+          res_add(res, a->offsets[c.varptr[i] + dof], &flux[i], w * bas[((size_t)k * n + dof) * nqs + pt]);
+    }
+    scatter(&c, e, res);
+  }
+  free(wts); free(nrm); free(bas); free(res);
+  ctx_free(&c);
+  return 0;
+}
+
 int orc_assemble_block_boundary(const orc_block_args *a) {
+  if (a->physics == ORC_PHYS_SHALLOWWATER_HYBRIDIZED) return (a->dim == 2 && a->bc_type >= 10 && a->bc_type <= 12 && a->aux_ip) ? swh_boundary(a) : -2;
   blk_ctx c;
   if (ctx_init(&c, a)) return -1;
   if (a->physics != ORC_PHYS_POROUS_MIXED || a->bc_type != 1) { ctx_free(&c); return -2; }

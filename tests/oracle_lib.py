@@ -364,6 +364,7 @@ class BlockArgs(C.Structure):
         ("compute_jacobian", C.c_int),
         ("rowptr", _ip), ("colind", _ip), ("crs_vals", _dp), ("res", _dp), ("local_J", _dp), ("local_res", _dp),
         ("nb", C.c_int), ("belem", _ip), ("bside", _ip), ("bc_type", C.c_int), ("bdata", Func),
+        ("aux_ip", _dp), ("farfield_ip", _dp),
     ]
 
 
@@ -522,13 +523,22 @@ def get_mass(m, qdeg, masswts=None):
 
 
 def assemble_block_boundary(m, physics, qdeg, u, belem, bside, bc_type, data, *, rowptr, colind, crs_vals, res,
-                            funcs=None, params=None, fixed=None, transient=None, compute_jacobian=True):
+                            funcs=None, params=None, fixed=None, transient=None, compute_jacobian=True, aux=None,
+                            farfield=None):
     keep = []
     a = _block_args(m, physics, qdeg, u, funcs, params, fixed, transient, compute_jacobian, keep)
     belem = np.ascontiguousarray(belem, dtype=np.int32)
     bside = np.ascontiguousarray(bside, dtype=np.int32)
     a.nb, a.belem, a.bside, a.bc_type = len(belem), _i(belem), _i(bside), bc_type
     a.bdata = _func(data, keep)
+    if aux is not None:
+        aux = np.ascontiguousarray(aux, dtype=np.float64)
+        keep.append(aux)
+        a.aux_ip = _d(aux)
+    if farfield is not None:
+        farfield = np.ascontiguousarray(farfield, dtype=np.float64)
+        keep.append(farfield)
+        a.farfield_ip = _d(farfield)
     a.rowptr, a.colind, a.crs_vals, a.res = _i(rowptr), _i(colind), _d(crs_vals), _d(res)
     rc = lib().orc_assemble_block_boundary(C.byref(a))
     assert rc == 0, rc

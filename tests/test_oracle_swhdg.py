@@ -89,3 +89,52 @@ def test_volume_residual_is_consistent(oracle):
     c = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, uc, params=[9.81])
     for v in range(3):
         assert abs(c["res"][m["dof_var"] == v].sum()) < 1e-12
+
+
+def all_element_sides(ncell):
+    """Every (element, local side) of a structured quad mesh: the HDG residual visits all four sides of every element."""
+    E = ncell[0] * ncell[1]
+    return np.repeat(np.arange(E, dtype=np.int32), 4), np.tile(np.arange(4, dtype=np.int32), E)
+
+
+def test_hdg_element_residual_is_consistent(oracle):
+    """boundaryResidual (:190-263) + volumeResidual: with the trace equal to a constant interior state the element
+    residual vanishes (divergence theorem: int_dK F.n N - int_K F.grad N = 0), the stabilisation drops out, and the
+    Jacobian of the side term is the derivative of its residual (Roe-like, max-EV, far-field, slip)."""
+    import scipy.sparse as sp
+    H = oracle.HGRAD
+    ncell = (3, 2)
+    m = oracle.mesh_multi(2, ncell, [H, H, H], [1, 1, 1])
+    v = m["verts"].copy()
+    v[:, 0] += 0.07 * np.sin(2.0 * v[:, 1])
+    v[:, 1] += 0.05 * v[:, 0] ** 2
+    m["verts"], m["nodes"] = v, np.ascontiguousarray(v[m["cell2vert"]])
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    be, bs = all_element_sides(ncell)
+    nqs = oracle.side_sizes(2, 2)[1]
+    const = np.array([1.7, 0.4, -0.3])
+    uc = np.zeros(m["ndof"])
+    for k in range(3):
+        uc[m["dof_var"] == k] = const[k]
+    vol = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, uc, params=[9.81, 1], rowptr=rowptr,
+                                colind=colind)
+    aux = np.tile(const, (len(be), nqs, 1))
+    oracle.assemble_block_boundary(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, uc, be, bs, 10, 0.0, rowptr=rowptr,
+                                   colind=colind, crs_vals=vol["crs_vals"], res=vol["res"], params=[9.81, 1], aux=aux)
+    assert np.abs(vol["res"]).max() < 1e-12
+    rng = np.random.default_rng(8)
+    u = rng.uniform(-1, 1, m["ndof"])
+    u[m["dof_var"] == 0] = rng.uniform(1.0, 2.0, (m["dof_var"] == 0).sum())
+    aux = np.dstack([rng.uniform(1.0, 2.0, (len(be), nqs)), rng.uniform(-1, 1, (len(be), nqs)), rng.uniform(-1, 1, (len(be), nqs))])
+    ff = np.dstack([rng.uniform(1.0, 2.0, (len(be), nqs)), rng.uniform(-1, 1, (len(be), nqs)), rng.uniform(-1, 1, (len(be), nqs))])
+    for bc, roe in ((10, 1), (10, 0), (11, 1), (12, 1)):
+        def bnd(uu):
+            vals, res = np.zeros(rowptr[-1]), np.zeros(m["ndof"])
+            oracle.assemble_block_boundary(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, uu, be, bs, bc, 0.0, rowptr=rowptr,
+                                           colind=colind, crs_vals=vals, res=res, params=[9.81, roe], aux=aux, farfield=ff)
+            return sp.csr_matrix((vals, colind, rowptr), shape=(m["ndof"],) * 2), res
+        J, r0 = bnd(u)
+        du = 1e-6 * rng.uniform(-1, 1, m["ndof"])
+        _, r1 = bnd(u + du)
+        lin = -(J @ du)
+        assert np.abs((r1 - r0) - lin).max() < 1e-4 * np.abs(lin).max(), (bc, roe)

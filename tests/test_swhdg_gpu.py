@@ -108,3 +108,72 @@ def test_volume_residual_matches_oracle(oracle, order, qdeg, ncell, transient):
     out = run_gpu(blk, m, u, tr, len(ref["colind"]), local=True)
     for k in ("crs_vals", "res", "local_J", "local_res"):
         assert np.abs(out[k] - ref[k]).max() < RTOL * np.abs(ref[k]).max(), k
+
+
+@pytest.mark.parametrize("order,qdeg,ncell", [(1, 2, (4, 3)), (2, 4, (3, 2))])
+@pytest.mark.parametrize("bc,roe", [(10, 1), (10, 0), (11, 1), (12, 1)])
+def test_boundary_residual_matches_oracle(oracle, order, qdeg, ncell, bc, roe):
+    """shallowwaterHybridized::boundaryResidual on ALL sides of every element (the HDG interior problem), trace and
+    far-field states as per-point arrays, against the oracle's AD-array restatement."""
+    torch = _torch()
+    import mrhyde_amd
+    from test_multi_gpu import make_block, warp
+    from test_oracle_swhdg import all_element_sides
+    rng = np.random.default_rng(61)
+    H = oracle.HGRAD
+    m = warp(oracle.mesh_multi(2, ncell, [H, H, H], [order] * 3))
+    u = rng.uniform(-1, 1, m["ndof"])
+    u[m["dof_var"] == 0] = rng.uniform(1.0, 2.0, (m["dof_var"] == 0).sum())
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    be, bs = all_element_sides(ncell)
+    nqs = oracle.side_sizes(2, qdeg)[1]
+    shp = (len(be), nqs)
+    aux = np.dstack([rng.uniform(1.0, 2.0, shp), rng.uniform(-1, 1, shp), rng.uniform(-1, 1, shp)])
+    ff = np.dstack([rng.uniform(1.0, 2.0, shp), rng.uniform(-1, 1, shp), rng.uniform(-1, 1, shp)])
+    vals_ref, res_ref = np.zeros(rowptr[-1]), np.zeros(m["ndof"])
+    oracle.assemble_block_boundary(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, qdeg, u, be, bs, bc, 0.0, rowptr=rowptr,
+                                   colind=colind, crs_vals=vals_ref, res=res_ref, params=[9.81, roe], aux=aux, farfield=ff)
+    blk = make_block(m, "shallowwaterHybridized", qdeg, graph=(rowptr, colind))
+    blk.set_physics_parameter("Roe-like stabilization", roe)
+    blk.add_boundary_group("skeleton", bc, be, bs)
+    keep = []
+    for i, v in enumerate(("H", "Hux", "Huy")):
+        t = torch.tensor(np.ascontiguousarray(aux[..., i]), device="cuda")
+        f = torch.tensor(np.ascontiguousarray(ff[..., i]), device="cuda")
+        keep += [t, f]
+        blk.set_function("aux %s skeleton" % v, t)
+        blk.set_function("Far-field %s skeleton" % v, f)
+    res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(colind), dtype=torch.float64, device="cuda")
+    blk.assemble_boundary(torch.tensor(u, device="cuda"), res, vals)
+    torch.cuda.synchronize()
+    assert np.abs(res.cpu().numpy() - res_ref).max() < RTOL * np.abs(res_ref).max()
+    assert np.abs(vals.cpu().numpy() - vals_ref).max() < RTOL * np.abs(vals_ref).max()
+
+
+def test_hdg_element_residual_vanishes_for_constant_state(oracle):
+    """volumeResidual + boundaryResidual on all element sides with trace = constant interior state: zero residual
+    (divergence theorem), on the device."""
+    torch = _torch()
+    import mrhyde_amd
+    from test_multi_gpu import make_block, warp
+    from test_oracle_swhdg import all_element_sides
+    H = oracle.HGRAD
+    ncell = (4, 3)
+    m = warp(oracle.mesh_multi(2, ncell, [H, H, H], [2, 2, 2]))
+    blk = make_block(m, "shallowwaterHybridized", 4)
+    be, bs = all_element_sides(ncell)
+    blk.add_boundary_group("skeleton", mrhyde_amd.api.BC_SWH_INTERFACE, be, bs)
+    const = (1.7, 0.4, -0.3)
+    uc = np.zeros(m["ndof"])
+    for k, v in enumerate(("H", "Hux", "Huy")):
+        uc[m["dof_var"] == k] = const[k]
+        blk.set_function("aux %s skeleton" % v, const[k])
+    ud = torch.tensor(uc, device="cuda")
+    res = torch.empty(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.empty(len(blk.get_graph()[1]), dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(ud, res, vals, overwrite=True)
+    assert res.abs().max().item() > 1e-3  # the volume term alone does not vanish
+    blk.assemble_boundary(ud, res, vals)
+    torch.cuda.synchronize()
+    assert res.abs().max().item() < 1e-12
