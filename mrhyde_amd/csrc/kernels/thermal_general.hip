@@ -40,7 +40,11 @@ struct GK {
   static constexpr int QC = NQ < 9 ? NQ : 9;      // integration points per GEMM chunk
   static constexpr int NCH = (NQ + QC - 1) / QC;
   static constexpr int KC = QC * DIM + (TR ? QC : 0);  // GEMM depth of one chunk (+ mass columns)
-  static constexpr int EPB = 4;                   // elements (waves) per workgroup
+#ifndef MHA_TG_EPB
+#define MHA_TG_EPB 4
+#endif
+  static constexpr int EPB = MHA_TG_EPB;          // elements (waves) per workgroup
+  static constexpr int NT = EPB * 64;             // threads per workgroup
   // shared tables (doubles)
   static constexpr int S_GT = 0;                  // Ghat^T  [NQ*DIM][NP]
   static constexpr int S_NT = S_GT + NQ * DIM * NP;   // Nhat^T  [NQ][NP]
@@ -61,7 +65,7 @@ struct GK {
 };
 
 template <int DIM, int P, int NQ1, bool TR>
-__global__ __launch_bounds__(256) void thermal_general_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
+__global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
                                                                        const uint8_t *__restrict__ slot8,
                                                                        const uint16_t *__restrict__ slot16, ElemOut out) {
   using S = GK<DIM, P, NQ1, TR>;
@@ -80,19 +84,19 @@ __global__ __launch_bounds__(256) void thermal_general_element_kernel(BlockDev b
   __shared__ int s_offs[N];
 
   // ---- shared tables ----
-  for (int i = tid; i < NQ * DIM * NP; i += 256) {
+  for (int i = tid; i < NQ * DIM * NP; i += S::NT) {
     const int k = i / NP, j = i - k * NP;  // k = q*DIM + a
     sh[S::S_GT + i] = (j < N) ? b.ref_grad[((size_t)j * NQ + k / DIM) * DIM + k % DIM] : 0.0;
   }
-  for (int i = tid; i < NQ * NP; i += 256) {
+  for (int i = tid; i < NQ * NP; i += S::NT) {
     const int q = i / NP, j = i - q * NP;
     sh[S::S_NT + i] = (j < N) ? b.ref_basis[j * NQ + q] : 0.0;
   }
-  for (int i = tid; i < NN * NQ * DIM; i += 256) sh[S::S_NG + i] = b.nodegrad[i];
-  for (int i = tid; i < NN * NQ; i += 256) sh[S::S_NV + i] = b.nodeval[i];
-  for (int i = tid; i < NQ; i += 256) sh[S::S_W + i] = b.ref_wts[i];
-  for (int i = tid; i < M * NQ1; i += 256) { tab[i] = af.phi1d[i]; tab[M * NQ1 + i] = af.dphi1d[i]; }
-  for (int i = tid; i < N; i += 256) s_offs[i] = b.offsets[i];
+  for (int i = tid; i < NN * NQ * DIM; i += S::NT) sh[S::S_NG + i] = b.nodegrad[i];
+  for (int i = tid; i < NN * NQ; i += S::NT) sh[S::S_NV + i] = b.nodeval[i];
+  for (int i = tid; i < NQ; i += S::NT) sh[S::S_W + i] = b.ref_wts[i];
+  for (int i = tid; i < M * NQ1; i += S::NT) { tab[i] = af.phi1d[i]; tab[M * NQ1 + i] = af.dphi1d[i]; }
+  for (int i = tid; i < N; i += S::NT) s_offs[i] = b.offsets[i];
   if (active)
     for (int i = lane; i < NN * DIM; i += 64) E[S::O_XN + i] = b.nodes[(size_t)e * NN * DIM + i];
   __syncthreads();
@@ -335,7 +339,7 @@ void launch_one(const BlockDev &b, const ThermalDev &ph, const AffineDev &af, co
   const uint16_t *s16 = slot_bytes == 2 ? static_cast<const uint16_t *>(slot) : nullptr;
   auto go = [&](auto kern) {
     MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, b, ph, af, s8, s16, out);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(S0::NT), lds, stream, b, ph, af, s8, s16, out);
     MHA_HIP(hipGetLastError());
   };
   if (tr) go(thermal_general_element_kernel<DIM, P, NQ1, true>);
