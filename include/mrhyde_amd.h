@@ -254,6 +254,19 @@ int mha_swhdg_side_terms(int side_type, int roe_stabilization, double g, int64_t
                          const double *Shat_dev, const double *normals_dev, const double *Sinf_dev,
                          double *fluxvec_dev, double *term_dev, double *iflux_dev, double *d_iflux_dS_dev,
                          double *d_iflux_dShat_dev, void *hip_stream);
+/* The HDG element, side part: residual and derivative blocks of the 12 interior unknowns (H, Hux, Huy, HGRAD
+ * order 1, flattened (variable, dof)) and the 24 trace unknowns of every element of a shallowwaterHybridized block.
+ * replaces: boundaryResidual :190-263 on the four sides (interior rows), computeFlux :270-368 integrated against the
+ * trace basis as SubGridDtN_Solver::updateFlux does (src/subgrid/subgridDtN_solver.cpp:1583-1601, trace rows), with
+ * Basis_HFACE_QUAD_In_FEM of degree 1 (src/tools/Intrepid2_HFACE_QUAD_In_FEMdef.hpp:84-196: per edge the two linear
+ * Lagrange functions of the edge's reference coordinate; edges left x=-1, bottom y=-1, right x=+1, top y=+1).
+ * lambda_dev[E][24]: variable, edge, function.  side_types_dev[E][4] u8 in shards side order (bottom, right, top,
+ * left): MHA_SWH_*; NULL = all interface.  farfield_host[3] (Far-field sides).  Outputs, element-major, rows/columns
+ * = 12 interior then 24 traces: res_dev[E][36] = -res.val(), blocks_dev[E][36][36] = res(r).dx(c) (stored); either may
+ * be NULL.  The volume part of the interior block comes from mha_compute_local_jacres.                           */
+int mha_swhdg_element_blocks(mha_context *ctx, const double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
+                             const double *lambda_dev, const uint8_t *side_types_dev, const double *farfield_host,
+                             double *res_dev, double *blocks_dev);
 /* L[npts][3][3], lam[npts][3], R[npts][3][3] (row-major) of the normal flux Jacobian at Shat */
 int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat_dev, const double *normals_dev,
                           double *L_dev, double *lam_dev, double *R_dev, void *hip_stream);

@@ -23,7 +23,7 @@ EXPORTS = [
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
-    "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass",
+    "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks",
 ]
 SWH_INTERFACE, SWH_FARFIELD, SWH_SLIP = 0, 1, 2
 BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
@@ -98,6 +98,7 @@ def load_library():
         _lib.mha_set_physics_parameter.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         _lib.mha_set_orientation.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mha_get_mass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_swhdg_element_blocks.argtypes = [C.c_void_p] * 9
         _lib.mha_swhdg_side_terms.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int64] + [C.c_void_p] * 10
         _lib.mha_swhdg_eigendecomp.argtypes = [C.c_double, C.c_int64] + [C.c_void_p] * 6
     return _lib
@@ -296,6 +297,12 @@ class Block:
     def get_mass(self, local_mass, masswts=None):
         w = None if masswts is None else _np(masswts, np.float64)
         _check(load_library().mha_get_mass(self._h, None if w is None else w.ctypes.data_as(C.c_void_p), _ptr(local_mass)))
+
+    def swhdg_element_blocks(self, u, lam, res, blocks, side_types=None, farfield=None, u_prev=None, u_stage=None):
+        ff = None if farfield is None else _np(farfield, np.float64)
+        _check(load_library().mha_swhdg_element_blocks(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(lam),
+                                                       _ptr(side_types), None if ff is None else ff.ctypes.data_as(C.c_void_p),
+                                                       _ptr(res), _ptr(blocks)))
 
     def scatter_local(self, local_J, local_res, res, crs_vals):
         _check(load_library().mha_scatter_local(self._h, _ptr(local_J), _ptr(local_res), _ptr(res), _ptr(crs_vals)))

@@ -567,6 +567,30 @@ void AssemblyManager::getMass(const double *masswts, double *local_mass) {
   MHA_HIP(hipStreamSynchronize(stream_));  // zero_u is released on return
 }
 
+// HDG element of shallowwaterHybridized, side part (kernels/swhdg_element.hip): residual and derivative blocks of the
+// interior + trace unknowns; settings g / stabilisation from the module
+void AssemblyManager::swhdgElementBlocks(const double *u, const double *u_prev, const double *u_stage, const double *lambda,
+                                         const uint8_t *side_types, const double *farfield, double *res, double *blocks) {
+  requireReady(false);
+  shallowwaterHybridized *sw = dynamic_cast<shallowwaterHybridized *>(physics_.get());
+  MHA_REQUIRE(sw != nullptr, MHA_ERR_INVALID, "the block's physics module is not shallowwaterHybridized");
+  MHA_REQUIRE(lambda && (res || blocks), MHA_ERR_INVALID, "null trace values or outputs");
+  for (const auto &vi : vars_) MHA_REQUIRE(vi.order == 1, MHA_ERR_INVALID, "the HDG element is built for order-1 variables");
+  bindState(u, u_prev, u_stage);
+  prepareSideTables();
+  SwhElementDev a;
+  a.lambda = lambda;
+  a.side_types = side_types;
+  if (farfield) for (int i = 0; i < 3; ++i) a.farfield[i] = farfield[i];
+  a.g = sw->gravity;
+  a.roe = sw->roestab ? 1 : 0;
+  a.res = res;
+  a.blocks = blocks;
+  timedBegin();
+  launch_swhdg_element(blockDev(), sideTablesDev(), a, time_, stream_);
+  timedEnd();
+}
+
 void AssemblyManager::scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals) {
   requireReady(true);
   timedBegin();

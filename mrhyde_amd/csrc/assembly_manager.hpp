@@ -37,6 +37,8 @@ class AssemblyManager {
   void computeLocalJacRes(int compute_jacobian, const double *u, const double *u_prev, const double *u_stage,
                           double *local_J, double *local_res);
   void getMass(const double *masswts, double *local_mass);
+  void swhdgElementBlocks(const double *u, const double *u_prev, const double *u_stage, const double *lambda,
+                          const uint8_t *side_types, const double *farfield, double *res, double *blocks);
   void scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals);
   // boundary groups (reference: src/tools/boundaryGroup.hpp, assemblyManager.cpp:2518-2638)
   int addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,

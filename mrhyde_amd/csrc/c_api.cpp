@@ -215,6 +215,12 @@ int mha_swhdg_side_terms(int side_type, int roe_stabilization, double g, int64_t
   });
 }
 
+int mha_swhdg_element_blocks(mha_context *ctx, const double *u, const double *u_prev, const double *u_stage,
+                             const double *lambda, const uint8_t *side_types, const double *farfield_host, double *res,
+                             double *blocks) {
+  return guarded([&] { mgr(ctx).swhdgElementBlocks(u, u_prev, u_stage, lambda, side_types, farfield_host, res, blocks); });
+}
+
 int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat, const double *normals, double *L, double *lam,
                           double *R, void *hip_stream) {
   return guarded([&] {

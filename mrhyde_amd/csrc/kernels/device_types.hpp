@@ -173,6 +173,17 @@ struct SwhBoundaryDev {
   FuncDesc farfield[3];         // "Far-field H|Hux|Huy <side>"
 };
 
+// HDG element of shallowwaterHybridized, side part (kernels/swhdg_element.hip)
+struct SwhElementDev {
+  const double *lambda = nullptr;        // [E][24] trace unknowns: variable, HFACE edge (left, bottom, right, top), function
+  const uint8_t *side_types = nullptr;   // [E][4] in shards side order: MHA_SWH_*; null = all interface
+  double farfield[3] = {0, 0, 0};
+  double g = 9.81;
+  int roe = 1;
+  double *res = nullptr;                 // [E][36]     -res.val()
+  double *blocks = nullptr;              // [E][36][36] res(r).dx(c), stored
+};
+
 // Destination of the row-owner kernels.
 struct RowOut {
   double *res = nullptr;

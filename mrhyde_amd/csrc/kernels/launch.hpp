@@ -74,6 +74,10 @@ void launch_swhdg_side(const SwhSideArgs &a, hipStream_t stream);
 void launch_swhdg_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const SwhBoundaryDev &sw,
                            const TimeDev &tm, const ElemOut &out, hipStream_t stream);
 
+// swhdg_element.hip: HDG element blocks of shallowwaterHybridized (interior + trace unknowns), side part
+void launch_swhdg_element(const BlockDev &b, const SideTablesDev &st, const SwhElementDev &a, const TimeDev &tm,
+                          hipStream_t stream);
+
 // point_engine.hip: multi-variable blocks, any physics module stated as a point function
 // slot: element-major CRS slot map (launch_build_elem_slot_map) or null for the column search
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,

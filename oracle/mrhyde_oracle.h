@@ -276,6 +276,23 @@ void orc_swh_boundary_term(int dim, int type, const double *S, const double *Sha
 void orc_swh_interface_flux(int dim, int side_type, int roe, const double *S, const double *Shat, const double *Sinf,
                             const double *nrm, double g, double *out);
 
+/* ---- shallowwaterHybridized, the HDG element (side part) ------------------------------------------------------
+ * Per element: 12 interior unknowns (H, Hux, Huy; HGRAD order 1, flattened (variable, dof)) and 24 trace unknowns
+ * (3 variables x Basis_HFACE_QUAD_In_FEM of degree 1, vendored in the reference: src/tools/Intrepid2_HFACE_QUAD_In_FEMdef.hpp
+ * :84-196 -- per edge the 2 linear Lagrange functions of the edge's reference coordinate, edges in the order left x=-1,
+ * bottom y=-1, right x=+1, top y=+1, zero off their edge).  With derivative arrays of width 36 (interior slots 0..11,
+ * trace slots 12..35) the reference's operators give
+ *   interior rows: boundaryResidual (shallowwaterHybridized.cpp:190-263) on all four sides,
+ *                  res_(i,a) += flux_i wts N_a(side point)
+ *   trace rows:    computeFlux (:270-368) integrated against the trace basis (SubGridDtN_Solver::updateFlux,
+ *                  src/subgrid/subgridDtN_solver.cpp:1583-1601): res_(i,(edge,k)) += mu_k flux_i wts
+ * with flux = F(Shat).n + Stab (S - Shat) on interface sides, the boundary term on Far-field / Slip sides.
+ * lambda[E][24] (variable-major, then edge, then function), side_types[E][4] in shards side order (0 interface,
+ * 1 Far-field, 2 Slip), farfield[3]; outputs res[E][36] = -res.val(), blocks[E][36][36] = res(r).dx(c) (stored).
+ * Uses dim (2), qdeg, orders, nelem, nodes, lids, offsets, u, the time-integration data and params {g, Roe} of `a`. */
+int orc_swh_hdg_element(const orc_block_args *a, const double *lambda, const unsigned char *side_types,
+                        const double *farfield, double *blocks, double *res);
+
 #ifdef __cplusplus
 }
 #endif

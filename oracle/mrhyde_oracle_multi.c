@@ -894,3 +894,151 @@ int orc_assemble_block_boundary(const orc_block_args *a) {
   ctx_free(&c);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* shallowwaterHybridized: HDG element, side part, derivative arrays of width 36 */
+/* ------------------------------------------------------------------------ */
+
+static ad_t ad_abs(const ad_t *a) { return a->v[0] < 0.0 ? ad_scale(*a, -1.0) : *a; }
+static ad_t ad_max(const ad_t *a, const ad_t *b) { return a->v[0] > b->v[0] ? *a : *b; }
+
+static void adm_matvec(const ad_t A[3][3], const ad_t *x, ad_t *y) {
+  for (int i = 0; i < 3; ++i) {
+    y[i] = ad_c(0.0);
+    for (int j = 0; j < 3; ++j) { ad_t t = ad_mul(&A[i][j], &x[j]); y[i] = ad_add(y[i], &t); }
+  }
+}
+
+/* eigendecompFluxJacobian, 2-D (:793-823) on AD numbers */
+static void adm_eigen(const ad_t *Sh, double nx, double ny, double g, ad_t L[3][3], ad_t *lam, ad_t R[3][3]) {
+  ad_t ux = ad_div(&Sh[1], &Sh[0]), uy = ad_div(&Sh[2], &Sh[0]);
+  ad_t t1 = ad_scale(ux, nx), t2 = ad_scale(uy, ny), vn = ad_add(t1, &t2);
+  ad_t gh = ad_scale(Sh[0], g), a = ad_sqrt(&gh), one = ad_c(1.0), zero = ad_c(0.0);
+  ad_t anx = ad_scale(a, nx), any = ad_scale(a, ny);
+  R[0][0] = one; R[1][0] = ad_add(ux, &anx); R[2][0] = ad_add(uy, &any);
+  R[0][1] = zero; R[1][1] = ad_scale(any, -1.0); R[2][1] = anx;
+  R[0][2] = one; R[1][2] = ad_sub(ux, &anx); R[2][2] = ad_sub(uy, &any);
+  ad_t two_a = ad_scale(a, 2.0), vn2a = ad_div(&vn, &two_a), half = ad_c(0.5);
+  ad_t nx2a = ad_c(nx); nx2a = ad_div(&nx2a, &two_a);
+  ad_t ny2a = ad_c(ny); ny2a = ad_div(&ny2a, &two_a);
+  ad_t nxa = ad_c(nx); nxa = ad_div(&nxa, &a);
+  ad_t nya = ad_c(ny); nya = ad_div(&nya, &a);
+  L[0][0] = ad_sub(half, &vn2a); L[0][1] = nx2a; L[0][2] = ny2a;
+  { ad_t p1 = ad_scale(ux, ny), p2 = ad_scale(uy, nx), d = ad_sub(p1, &p2); L[1][0] = ad_div(&d, &a); }
+  L[1][1] = ad_scale(nya, -1.0); L[1][2] = nxa;
+  L[2][0] = ad_add(half, &vn2a); L[2][1] = ad_scale(nx2a, -1.0); L[2][2] = ad_scale(ny2a, -1.0);
+  lam[0] = ad_add(vn, &a); lam[1] = vn; lam[2] = ad_sub(vn, &a);
+}
+
+/* computeFlux (:270-368) with computeFluxVector(true), computeStabilizationTerm, computeBoundaryTerm on AD numbers */
+static void adm_interface_flux(int stype, int roe, const ad_t *S, const ad_t *Sh, const double *Sinf, double nx, double ny,
+                               double g, ad_t *out) {
+  if (stype == 0) {
+    ad_t hh = ad_scale(ad_mul(&Sh[0], &Sh[0]), 0.5 * g);
+    ad_t uu = ad_mul(&Sh[1], &Sh[1]), uv = ad_mul(&Sh[1], &Sh[2]), vv = ad_mul(&Sh[2], &Sh[2]);
+    ad_t F[3][2];
+    F[0][0] = Sh[1]; F[0][1] = Sh[2];
+    F[1][0] = ad_add(ad_div(&uu, &Sh[0]), &hh); F[1][1] = ad_div(&uv, &Sh[0]);
+    F[2][0] = ad_div(&uv, &Sh[0]); F[2][1] = ad_add(ad_div(&vv, &Sh[0]), &hh);
+    ad_t dS[3], st[3];
+    for (int i = 0; i < 3; ++i) dS[i] = ad_sub(S[i], &Sh[i]);
+    if (roe) {
+      ad_t L[3][3], lam[3], R[3][3], tmp[3];
+      adm_eigen(Sh, nx, ny, g, L, lam, R);
+      adm_matvec(L, dS, tmp);
+      for (int i = 0; i < 3; ++i) { ad_t al = ad_abs(&lam[i]); tmp[i] = ad_mul(&tmp[i], &al); }
+      adm_matvec(R, tmp, st);
+    } else {
+      ad_t ux = ad_div(&Sh[1], &Sh[0]), uy = ad_div(&Sh[2], &Sh[0]);
+      ad_t t1 = ad_scale(ux, nx), t2 = ad_scale(uy, ny), vn = ad_add(t1, &t2);
+      ad_t gh = ad_scale(Sh[0], g), a = ad_sqrt(&gh);
+      ad_t p = ad_add(vn, &a), m = ad_sub(vn, &a), ap = ad_abs(&p), am = ad_abs(&m), lmax = ad_max(&ap, &am);
+      for (int i = 0; i < 3; ++i) st[i] = ad_mul(&dS[i], &lmax);
+    }
+    for (int i = 0; i < 3; ++i) {
+      ad_t fx = ad_scale(F[i][0], nx), fy = ad_scale(F[i][1], ny);
+      out[i] = ad_add(ad_add(fx, &fy), &st[i]);
+    }
+  } else if (stype == 1) {
+    ad_t L[3][3], lam[3], R[3][3], tmp[3], dS[3], neg[3];
+    adm_eigen(Sh, nx, ny, g, L, lam, R);
+    for (int i = 0; i < 3; ++i) dS[i] = ad_sub(S[i], &Sh[i]);
+    adm_matvec(L, dS, tmp);
+    for (int i = 0; i < 3; ++i) { ad_t al = ad_abs(&lam[i]); ad_t f = ad_scale(ad_add(lam[i], &al), 0.5); tmp[i] = ad_mul(&tmp[i], &f); }
+    adm_matvec(R, tmp, out);
+    for (int i = 0; i < 3; ++i) { dS[i] = ad_scale(Sh[i], -1.0); dS[i].v[0] += Sinf[i]; }
+    adm_matvec(L, dS, tmp);
+    for (int i = 0; i < 3; ++i) { ad_t al = ad_abs(&lam[i]); ad_t f = ad_scale(ad_sub(lam[i], &al), 0.5); tmp[i] = ad_mul(&tmp[i], &f); }
+    adm_matvec(R, tmp, neg);
+    for (int i = 0; i < 3; ++i) out[i] = ad_sub(out[i], &neg[i]);
+  } else {
+    ad_t ux = ad_div(&S[1], &S[0]), uy = ad_div(&S[2], &S[0]);
+    ad_t t1 = ad_scale(ux, nx), t2 = ad_scale(uy, ny), vn = ad_add(t1, &t2);
+    ad_t hx = ad_div(&Sh[1], &Sh[0]), hy = ad_div(&Sh[2], &Sh[0]);
+    ad_t a1 = ad_scale(vn, nx), a2 = ad_scale(vn, ny);
+    out[0] = ad_sub(S[0], &Sh[0]);
+    out[1] = ad_sub(ad_sub(ux, &a1), &hx);
+    out[2] = ad_sub(ad_sub(uy, &a2), &hy);
+  }
+}
+
+int orc_swh_hdg_element(const orc_block_args *a, const double *lambda, const unsigned char *side_types,
+                        const double *farfield, double *blocks, double *res_out) {
+  blk_ctx c;
+  if (a->dim != 2 || a->nvars != 3 || ctx_init(&c, a)) return -1;
+  const int dim = 2, n = c.varptr[1], ni = 3 * n, nl = 24, W = ni + nl;
+  if (n != 4 || W + 1 > ADMAX) { ctx_free(&c); return -2; }
+  g_w1 = W + 1;
+  int ns, nqs;
+  orc_side_sizes(dim, a->qdeg, &ns, &nqs);
+  static const int hface_edge[4] = {1, 2, 3, 0}; /* shards side -> HFACE edge (left, bottom, right, top) */
+  const double g = a->params[0];
+  const int roe = a->params[1] != 0.0;
+  double *sip = malloc(sizeof(double) * ns * nqs * dim), *sw = malloc(sizeof(double) * nqs);
+  double *tu = malloc(sizeof(double) * ns * dim), *tv = malloc(sizeof(double) * ns * dim);
+  double *sb = malloc(sizeof(double) * ns * n * nqs), *sg = malloc(sizeof(double) * ns * n * nqs * dim);
+  double *snv = malloc(sizeof(double) * ns * 4 * nqs), *sng = malloc(sizeof(double) * ns * 4 * nqs * dim);
+  orc_side_tables(dim, 1, a->qdeg, sip, sw, tu, tv, sb, sg, snv, sng);
+  double *wts = malloc(sizeof(double) * nqs), *nrm = malloc(sizeof(double) * nqs * dim);
+  ad_t *R = malloc(sizeof(ad_t) * W), *lamAD = malloc(sizeof(ad_t) * nl);
+  for (size_t e = 0; e < (size_t)a->nelem; ++e) {
+    gather_seed(&c, e); /* interior unknowns: value and derivative slot = position in the LID list */
+    /* re-seed in the element-local numbering of this routine: interior (variable, dof) -> slot f, traces -> ni + t */
+    ad_t uloc[12];
+    for (int f = 0; f < ni; ++f) {
+      uloc[f] = ad_c(c.uAD[f].v[0]);
+      uloc[f].v[1 + f] = c.uAD[f].v[1 + a->offsets[f]];
+    }
+    for (int t = 0; t < nl; ++t) { lamAD[t] = ad_c(lambda[e * nl + t]); lamAD[t].v[1 + ni + t] = 1.0; }
+    for (int r = 0; r < W; ++r) R[r] = ad_c(0.0);
+    const int be = (int)e;
+    for (int s = 0; s < 4; ++s) {
+      orc_physical_side_basis(dim, 1, a->qdeg, 1, a->nodes, &be, &s, wts, nrm, NULL, NULL, NULL);
+      const int edge = hface_edge[s];
+      for (int pt = 0; pt < nqs; ++pt) {
+        const double *xr = sip + (s * nqs + pt) * dim;
+        const double tcoord = (edge == 0 || edge == 2) ? xr[1] : xr[0];
+        const double mu[2] = {0.5 * (1.0 - tcoord), 0.5 * (1.0 + tcoord)};
+        ad_t S[3], Sh[3], flux[3];
+        for (int i = 0; i < 3; ++i) {
+          S[i] = ad_c(0.0);
+          for (int dof = 0; dof < n; ++dof) { ad_t t = ad_scale(uloc[i * n + dof], sb[(s * n + dof) * nqs + pt]); S[i] = ad_add(S[i], &t); }
+          Sh[i] = ad_c(0.0);
+          for (int k = 0; k < 2; ++k) { ad_t t = ad_scale(lamAD[i * 8 + edge * 2 + k], mu[k]); Sh[i] = ad_add(Sh[i], &t); }
+        }
+        adm_interface_flux(side_types[e * 4 + s], roe, S, Sh, farfield, nrm[pt * dim], nrm[pt * dim + 1], g, flux);
+        for (int i = 0; i < 3; ++i) {
+          for (int dof = 0; dof < n; ++dof) res_add(R, i * n + dof, &flux[i], wts[pt] * sb[(s * n + dof) * nqs + pt]);
+          for (int k = 0; k < 2; ++k) res_add(R, ni + i * 8 + edge * 2 + k, &flux[i], wts[pt] * mu[k]);
+        }
+      }
+    }
+    for (int r = 0; r < W; ++r) {
+      res_out[e * W + r] = -R[r].v[0];
+      for (int col = 0; col < W; ++col) blocks[(e * W + r) * W + col] = R[r].v[1 + col];
+    }
+  }
+  free(sip); free(sw); free(tu); free(tv); free(sb); free(sg); free(snv); free(sng); free(wts); free(nrm); free(R); free(lamAD);
+  ctx_free(&c);
+  return 0;
+}

@@ -625,3 +625,17 @@ def swh_matvec(A, x):
     f.argtypes = [C.c_int, _dp, _dp, _dp]
     f(len(x), _d(A), _d(x), _d(y))
     return y
+
+
+def swh_hdg_element(m, qdeg, u, lam, side_types, farfield, g=9.81, roe=True, transient=None):
+    """HDG element, side part: -> (res [E][36], blocks [E][36][36]) (orc_swh_hdg_element)."""
+    keep = []
+    a = _block_args(m, PHYS_SHALLOWWATER_HYBRIDIZED, qdeg, u, None, [g, 1.0 if roe else 0.0], None, transient, True, keep)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    st = np.ascontiguousarray(side_types, dtype=np.uint8)
+    ff = np.ascontiguousarray(farfield, dtype=np.float64)
+    E = m["nelem"]
+    res, blocks = np.zeros((E, 36)), np.zeros((E, 36, 36))
+    rc = lib().orc_swh_hdg_element(C.byref(a), _d(lam), _u(st), _d(ff), _d(blocks), _d(res))
+    assert rc == 0, rc
+    return res, blocks

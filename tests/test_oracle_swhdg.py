@@ -138,3 +138,59 @@ def test_hdg_element_residual_is_consistent(oracle):
         _, r1 = bnd(u + du)
         lin = -(J @ du)
         assert np.abs((r1 - r0) - lin).max() < 1e-4 * np.abs(lin).max(), (bc, roe)
+
+
+def hdg_case(oracle, ncell=(3, 2), seed=12):
+    H = oracle.HGRAD
+    m = oracle.mesh_multi(2, ncell, [H, H, H], [1, 1, 1])
+    v = m["verts"].copy()
+    v[:, 0] += 0.07 * np.sin(2.0 * v[:, 1])
+    v[:, 1] += 0.05 * v[:, 0] ** 2
+    m["verts"], m["nodes"] = v, np.ascontiguousarray(v[m["cell2vert"]])
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1, 1, m["ndof"])
+    u[m["dof_var"] == 0] = rng.uniform(1.0, 2.0, (m["dof_var"] == 0).sum())
+    E = m["nelem"]
+    lam = rng.uniform(-1, 1, (E, 3, 4, 2))
+    lam[:, 0] = rng.uniform(1.0, 2.0, (E, 4, 2))
+    st = rng.integers(0, 3, (E, 4)).astype(np.uint8)
+    return m, u, lam.reshape(E, 24), st, np.array([1.4, -0.3, 0.5])
+
+
+def test_hdg_element_blocks(oracle):
+    """HDG element (interior rows = boundaryResidual on the four sides, trace rows = computeFlux against the HFACE
+    basis): blocks are the derivative of the residual with respect to interior AND trace unknowns; the interior rows
+    agree with the boundary-group restatement fed with the traces evaluated at the side points."""
+    from test_oracle_swhdg import all_element_sides  # noqa: F401 (self-import keeps the helper usable from GPU tests)
+    m, u, lam, st, ff = hdg_case(oracle)
+    E = m["nelem"]
+    for roe in (True, False):
+        res, blk = oracle.swh_hdg_element(m, 2, u, lam, st, ff, roe=roe)
+        rng = np.random.default_rng(3)
+        du, dl = 1e-6 * rng.uniform(-1, 1, m["ndof"]), 1e-6 * rng.uniform(-1, 1, lam.shape)
+        res2, _ = oracle.swh_hdg_element(m, 2, u + du, lam + dl, st, ff, roe=roe)
+        ue = du[m["lids"][:, m["offsets"]]]                      # [E][12] interior perturbation, flattened (var, dof)
+        lin = -np.einsum("erc,ec->er", blk, np.hstack([ue, dl]))
+        assert np.abs((res2 - res) - lin).max() < 2e-4 * np.abs(lin).max()
+    # interior rows against orc_assemble_block_boundary: one group per (element, side) type, aux = traces at the points
+    res, blk = oracle.swh_hdg_element(m, 2, u, lam, st, ff, roe=True)
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    vals, rg = np.zeros(rowptr[-1]), np.zeros(m["ndof"])
+    sip = oracle.side_tables(2, 1, 2)["sip"]                       # [4][nqs][2] reference side points
+    hedge = [1, 2, 3, 0]
+    for t in range(3):
+        be, bs = np.nonzero(st == t)
+        if len(be) == 0:
+            continue
+        nqs = sip.shape[1]
+        aux = np.zeros((len(be), nqs, 3))
+        for k, (e, s) in enumerate(zip(be, bs)):
+            tc = sip[s, :, 1] if hedge[s] in (0, 2) else sip[s, :, 0]
+            mu = np.stack([0.5 * (1 - tc), 0.5 * (1 + tc)], axis=1)    # [nqs][2]
+            aux[k] = np.einsum("vk,qk->qv", lam[e].reshape(3, 4, 2)[:, hedge[s]], mu)
+        oracle.assemble_block_boundary(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, u, be.astype(np.int32),
+                                       bs.astype(np.int32), 10 + t, 0.0, rowptr=rowptr, colind=colind, crs_vals=vals,
+                                       res=rg, params=[9.81, 1], aux=aux, farfield=np.tile(ff, (len(be), nqs, 1)))
+    rsum = np.zeros(m["ndof"])
+    np.add.at(rsum, m["lids"][:, m["offsets"]].ravel(), res[:, :12].ravel())
+    assert np.abs(rsum - rg).max() < 1e-12 * np.abs(rg).max()

@@ -177,3 +177,36 @@ def test_hdg_element_residual_vanishes_for_constant_state(oracle):
     blk.assemble_boundary(ud, res, vals)
     torch.cuda.synchronize()
     assert res.abs().max().item() < 1e-12
+
+
+@pytest.mark.parametrize("roe", [True, False])
+@pytest.mark.parametrize("transient", [False, True])
+def test_hdg_element_blocks_match_oracle(oracle, roe, transient):
+    """The HDG element (12 interior + 24 HFACE trace unknowns, mixed interface / far-field / slip sides): residual and
+    the four derivative blocks against the oracle's width-36 AD-array restatement."""
+    torch = _torch()
+    from test_multi_gpu import make_block, transient_state
+    from test_oracle_swhdg import hdg_case
+    m, u, lam, st, ff = hdg_case(oracle, ncell=(5, 4), seed=13)
+    rng = np.random.default_rng(14)
+    tr = None
+    if transient:
+        tr = transient_state(rng, m["ndof"], u)
+        for k in ("u_prev", "u_stage"):
+            tr[k][m["dof_var"] == 0] = rng.uniform(1.0, 2.0, ((m["dof_var"] == 0).sum(), 2))
+    res_ref, blk_ref = oracle.swh_hdg_element(m, 2, u, lam, st, ff, g=7.3, roe=roe, transient=tr)
+    blk = make_block(m, "shallowwaterHybridized", 2)
+    blk.set_physics_parameter("g", 7.3)
+    blk.set_physics_parameter("Roe-like stabilization", 1 if roe else 0)
+    kw = {}
+    if tr is not None:
+        blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+        kw = dict(u_prev=torch.tensor(tr["u_prev"], device="cuda"), u_stage=torch.tensor(tr["u_stage"], device="cuda"))
+    E = m["nelem"]
+    res = torch.zeros((E, 36), dtype=torch.float64, device="cuda")
+    blocks = torch.zeros((E, 36, 36), dtype=torch.float64, device="cuda")
+    blk.swhdg_element_blocks(torch.tensor(u, device="cuda"), torch.tensor(lam, device="cuda"), res, blocks,
+                             side_types=torch.tensor(st, device="cuda"), farfield=ff, **kw)
+    torch.cuda.synchronize()
+    assert np.abs(res.cpu().numpy() - res_ref).max() < RTOL * np.abs(res_ref).max()
+    assert np.abs(blocks.cpu().numpy() - blk_ref).max() < RTOL * np.abs(blk_ref).max()
