@@ -58,6 +58,41 @@ def run(kind, nc):
               (kind, nc, ms, m["nelem"] / ms * 1e3, m["nelem"] * B / ms / 1e6, m["nelem"] * B / ms / 1e6 / 80.0), flush=True)
 
 
+def run_hdg(nc):
+    """Config 5 shape: shallowwaterHybridized on nc^2 quads, Q1 interior + HFACE-1 traces: volume element matrices
+    (point engine, dense) + the HDG element blocks of all four sides (11 056 algorithmic bytes per element)."""
+    H = orc.HGRAD
+    m = orc.mesh_multi(2, (nc, nc), [H, H, H], [1, 1, 1])
+    blk = mrhyde_amd.Block(2, quadrature=2, physics="shallowwaterHybridized", variables=[(0, 1)] * 3)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+    blk.set_graph()
+    rng = np.random.default_rng(6)
+    E = m["nelem"]
+    r2 = ((m["verts"] - 0.5) ** 2).sum(axis=1)
+    u = 0.01 * rng.uniform(-1, 1, m["ndof"])
+    hdofs = m["dof_var"] == 0
+    u[hdofs] = 1.0 + 0.2 * rng.uniform(0, 1, hdofs.sum())
+    lam = 0.01 * rng.uniform(-1, 1, (E, 3, 4, 2))
+    lam[:, 0] = 1.0 + 0.2 * rng.uniform(0, 1, (E, 4, 2))
+    ud, ld = torch.tensor(u, device="cuda"), torch.tensor(lam.reshape(E, 24), device="cuda")
+    res = torch.zeros((E, 36), dtype=torch.float64, device="cuda")
+    blocks = torch.zeros((E, 36, 36), dtype=torch.float64, device="cuda")
+    lJ = torch.zeros((E, 12, 12), dtype=torch.float64, device="cuda")
+    lr = torch.zeros((E, 12), dtype=torch.float64, device="cuda")
+    blk.set_timing(True)
+    B = 11056
+    for it in range(3):
+        blk.swhdg_element_blocks(ud, ld, res, blocks)
+        torch.cuda.synchronize()
+        t_side = blk.last_kernel_ms()
+        blk.compute_local_jacres(ud, lJ, lr)
+        torch.cuda.synchronize()
+        t_vol = blk.last_kernel_ms()
+        ms = t_side + t_vol
+        print("hdg %d^2: sides %.3f ms + volume %.3f ms = %.3f ms  %.3e elements/s  %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" %
+              (nc, t_side, t_vol, ms, E / ms * 1e3, E * B / ms / 1e6, E * B / ms / 1e6 / 80.0), flush=True)
+
+
 def cpu_baseline(kind, sample_nc):
     """The oracle's AD-array restatement (1 thread) on a bounded sample of the same workload."""
     dim = 3
@@ -81,5 +116,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 4 and sys.argv[4] == "cpu":
         import json
         print(json.dumps({"workload": sys.argv[1], "cpu_baseline": cpu_baseline(sys.argv[1], int(sys.argv[2]))}))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "hdg":
+        run_hdg(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
         sys.exit(0)
     run(sys.argv[1] if len(sys.argv) > 1 else "porous", int(sys.argv[2]) if len(sys.argv) > 2 else 32)
