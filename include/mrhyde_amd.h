@@ -267,6 +267,17 @@ int mha_swhdg_side_terms(int side_type, int roe_stabilization, double g, int64_t
 int mha_swhdg_element_blocks(mha_context *ctx, const double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
                              const double *lambda_dev, const uint8_t *side_types_dev, const double *farfield_host,
                              double *res_dev, double *blocks_dev);
+/* Batched static condensation of element blocks: eliminates the n_int interior unknowns of every element.
+ * replaces: the element-local direct solve of the subgrid solver and its forward sensitivities d u / d lambda
+ * (SubGridDtN_Solver, src/subgrid/subgridDtN_solver.cpp:681-903, 1542-1616) in Schur-complement form.
+ * blocks_dev[E][n][n], res_dev[E][n] with n = n_int + n_trace, interior unknowns first (the layout of
+ * mha_swhdg_element_blocks; add the volume block of mha_compute_local_jacres to the interior part first);
+ * outputs: schur_dev[E][n_trace][n_trace] = A_ll - A_lu A_uu^-1 A_ul, gvec_dev[E][n_trace] = r_l - A_lu A_uu^-1 r_u,
+ * du_dev[E][n_int] = A_uu^-1 r_u (any may be NULL).  Gauss-Jordan with partial pivoting, one wavefront per
+ * element; n_int <= 32, n_int + n_trace + 1 <= 64.  Singular interior blocks: counted into *num_singular_host
+ * if given, MHA_ERR_INVALID otherwise.  Stateless; synchronises the stream.                                  */
+int mha_batched_condense(int n_int, int n_trace, int64_t num_elems, const double *blocks_dev, const double *res_dev,
+                         double *schur_dev, double *gvec_dev, double *du_dev, int *num_singular_host, void *hip_stream);
 /* L[npts][3][3], lam[npts][3], R[npts][3][3] (row-major) of the normal flux Jacobian at Shat */
 int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat_dev, const double *normals_dev,
                           double *L_dev, double *lam_dev, double *R_dev, void *hip_stream);

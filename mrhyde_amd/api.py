@@ -23,7 +23,7 @@ EXPORTS = [
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
-    "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks",
+    "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense",
 ]
 SWH_INTERFACE, SWH_FARFIELD, SWH_SLIP = 0, 1, 2
 BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
@@ -99,6 +99,7 @@ def load_library():
         _lib.mha_set_orientation.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mha_get_mass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mha_swhdg_element_blocks.argtypes = [C.c_void_p] * 9
+        _lib.mha_batched_condense.argtypes = [C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 7
         _lib.mha_swhdg_side_terms.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int64] + [C.c_void_p] * 10
         _lib.mha_swhdg_eigendecomp.argtypes = [C.c_double, C.c_int64] + [C.c_void_p] * 6
     return _lib
@@ -141,6 +142,19 @@ def swhdg_side_terms(side_type, roe, g, S, Shat, normals, Sinf=None, want=("flux
                                                _ptr(out.get("iflux")), _ptr(out.get("d_dS")), _ptr(out.get("d_dShat")),
                                                None))
     return out
+
+
+def batched_condense(n_int, n_trace, blocks, res, want_du=True):
+    """Static condensation of element blocks [E][n][n] / [E][n] (CUDA tensors) -> (schur, gvec, du, num_singular)."""
+    import torch
+    E = blocks.shape[0]
+    schur = torch.zeros((E, n_trace, n_trace), dtype=torch.float64, device=blocks.device)
+    gvec = torch.zeros((E, n_trace), dtype=torch.float64, device=blocks.device)
+    du = torch.zeros((E, n_int), dtype=torch.float64, device=blocks.device) if want_du else None
+    ns = C.c_int()
+    _check(load_library().mha_batched_condense(n_int, n_trace, E, _ptr(blocks), _ptr(res), _ptr(schur), _ptr(gvec), _ptr(du),
+                                               C.byref(ns), None))
+    return schur, gvec, du, ns.value
 
 
 def swhdg_eigendecomp(g, Shat, normals):

@@ -221,6 +221,22 @@ int mha_swhdg_element_blocks(mha_context *ctx, const double *u, const double *u_
   return guarded([&] { mgr(ctx).swhdgElementBlocks(u, u_prev, u_stage, lambda, side_types, farfield_host, res, blocks); });
 }
 
+int mha_batched_condense(int n_int, int n_trace, int64_t num_elems, const double *blocks, const double *res, double *schur,
+                         double *gvec, double *du, int *num_singular_host, void *hip_stream) {
+  return guarded([&] {
+    MHA_REQUIRE(num_elems >= 0 && (num_elems == 0 || (blocks && res)), MHA_ERR_INVALID, "null element blocks");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    mha::DeviceBuffer<int> flag(1);
+    MHA_HIP(hipMemsetAsync(flag.data(), 0, sizeof(int), st));
+    mha::launch_condense(n_int, n_trace, num_elems, blocks, res, schur, gvec, du, flag.data(), st);
+    int h = 0;
+    MHA_HIP(hipMemcpyAsync(&h, flag.data(), sizeof(int), hipMemcpyDeviceToHost, st));
+    MHA_HIP(hipStreamSynchronize(st));
+    if (num_singular_host) *num_singular_host = h;
+    MHA_REQUIRE(h == 0 || num_singular_host, MHA_ERR_INVALID, h << " element(s) with a singular interior block");
+  });
+}
+
 int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat, const double *normals, double *L, double *lam,
                           double *R, void *hip_stream) {
   return guarded([&] {

@@ -78,6 +78,10 @@ void launch_swhdg_boundary(const BlockDev &b, const SideTablesDev &st, const Bou
 void launch_swhdg_element(const BlockDev &b, const SideTablesDev &st, const SwhElementDev &a, const TimeDev &tm,
                           hipStream_t stream);
 
+// condense.hip: batched static condensation of element blocks (one wavefront per element)
+void launch_condense(int n_int, int n_trace, int64_t nelem, const double *blocks, const double *res, double *schur,
+                     double *gvec, double *du, int *singular, hipStream_t stream);
+
 // point_engine.hip: multi-variable blocks, any physics module stated as a point function
 // slot: element-major CRS slot map (launch_build_elem_slot_map) or null for the column search
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,

@@ -210,3 +210,45 @@ def test_hdg_element_blocks_match_oracle(oracle, roe, transient):
     torch.cuda.synchronize()
     assert np.abs(res.cpu().numpy() - res_ref).max() < RTOL * np.abs(res_ref).max()
     assert np.abs(blocks.cpu().numpy() - blk_ref).max() < RTOL * np.abs(blk_ref).max()
+
+
+def test_batched_condensation(oracle):
+    """mha_batched_condense: Schur complement, condensed right-hand side and interior update of every element against
+    numpy, on random diagonally-dominant blocks and on the real HDG element (volume + side blocks, transient)."""
+    torch = _torch()
+    import mrhyde_amd
+    from test_multi_gpu import make_block, transient_state
+    from test_oracle_swhdg import hdg_case
+    rng = np.random.default_rng(71)
+
+    def check(blocks, res, ni, nt):
+        S, g, du, ns = mrhyde_amd.batched_condense(ni, nt, torch.tensor(blocks, device="cuda"), torch.tensor(res, device="cuda"))
+        assert ns == 0
+        Auu, Aul, Alu, All = blocks[:, :ni, :ni], blocks[:, :ni, ni:], blocks[:, ni:, :ni], blocks[:, ni:, ni:]
+        X = np.linalg.solve(Auu, np.concatenate([Aul, res[:, :ni, None]], axis=2))
+        S_ref = All - Alu @ X[:, :, :nt]
+        g_ref = res[:, ni:] - (Alu @ X[:, :, nt:])[..., 0]
+        for got, ref in ((S.cpu().numpy(), S_ref), (g.cpu().numpy(), g_ref), (du.cpu().numpy(), X[:, :, nt])):
+            assert np.abs(got - ref).max() < 1e-10 * np.abs(ref).max()
+
+    for ni, nt in ((12, 24), (5, 3), (32, 31), (1, 1)):
+        E = 37
+        blocks = rng.uniform(-1, 1, (E, ni + nt, ni + nt))
+        blocks[:, np.arange(ni), np.arange(ni)] += 0.1 * ni * np.sign(rng.uniform(-1, 1, (E, ni)))  # pivoting still matters
+        check(blocks, rng.uniform(-1, 1, (E, ni + nt)), ni, nt)
+    # the real thing
+    m, u, lam, st, ff = hdg_case(oracle, ncell=(4, 3), seed=15)
+    tr = transient_state(rng, m["ndof"], u)
+    for k in ("u_prev", "u_stage"):
+        tr[k][m["dof_var"] == 0] = rng.uniform(1.0, 2.0, ((m["dof_var"] == 0).sum(), 2))
+    res, blk = oracle.swh_hdg_element(m, 2, u, lam, st, ff, transient=tr)
+    vol = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, u, params=[9.81], transient=tr, want_local=True)
+    off = m["offsets"]
+    blk[:, :12, :12] += vol["local_J"][:, off][:, :, off]       # LID-position order -> flattened (variable, dof)
+    res[:, :12] += vol["local_res"][:, off]
+    check(blk, res, 12, 24)
+    # a singular interior block is reported, not silently divided through
+    bad = np.zeros((2, 3, 3))
+    bad[1] = np.eye(3)
+    _, _, _, ns = mrhyde_amd.batched_condense(2, 1, torch.tensor(bad, device="cuda"), torch.zeros((2, 3), dtype=torch.float64, device="cuda"))
+    assert ns == 1
