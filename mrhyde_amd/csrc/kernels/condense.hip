@@ -20,6 +20,7 @@ namespace {
 
 constexpr int kCondMaxInt = 32, kCondWaves = 4;
 
+template <int MAXI>
 __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int nt, int64_t nelem,
                                                                    const double *__restrict__ blocks,
                                                                    const double *__restrict__ res, double *schur,
@@ -30,9 +31,9 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
   const int n = ni + nt, ncol = n + 1;
   const double *B = blocks + e * n * n, *r = res + e * n;
   // column `lane` of [A_uu | A_ul | r_u], rows 0..ni-1
-  double col[kCondMaxInt];
+  double col[MAXI];
 #pragma unroll
-  for (int i = 0; i < kCondMaxInt; ++i) {
+  for (int i = 0; i < MAXI; ++i) {
     double v = 0.0;
     if (i < ni && lane < ncol) v = lane < n ? B[(size_t)i * n + lane] : r[i];
     col[i] = v;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
     double best = -1.0;
     int piv = k;
 #pragma unroll
-    for (int i = 0; i < kCondMaxInt; ++i) {
+    for (int i = 0; i < MAXI; ++i) {
       const double a = fabs(__shfl(col[i], k));
       if (i >= k && i < ni && a > best) { best = a; piv = i; }
     }
@@ -51,17 +52,17 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
     // swap rows k and piv of this lane's column (dynamic index -> select chain)
     double ck = 0.0, cp = 0.0;
 #pragma unroll
-    for (int i = 0; i < kCondMaxInt; ++i) { if (i == k) ck = col[i]; if (i == piv) cp = col[i]; }
+    for (int i = 0; i < MAXI; ++i) { if (i == k) ck = col[i]; if (i == piv) cp = col[i]; }
 #pragma unroll
-    for (int i = 0; i < kCondMaxInt; ++i) { if (i == k) col[i] = cp; else if (i == piv) col[i] = ck; }
+    for (int i = 0; i < MAXI; ++i) { if (i == k) col[i] = cp; else if (i == piv) col[i] = ck; }
     // eliminate: row_i -= (a_ik / a_kk) row_k for all i != k, row_k /= a_kk
     double pk = 0.0;
 #pragma unroll
-    for (int i = 0; i < kCondMaxInt; ++i) if (i == k) pk = col[i];
+    for (int i = 0; i < MAXI; ++i) if (i == k) pk = col[i];
     const double akk = __shfl(pk, k);
     const double rk = pk / akk;  // this lane's entry of the normalised pivot row
 #pragma unroll
-    for (int i = 0; i < kCondMaxInt; ++i) {
+    for (int i = 0; i < MAXI; ++i) {
       const double aik = __shfl(col[i], k);  // multiplier source: column k before the update
       if (i < ni) col[i] = (i == k) ? rk : col[i] - aik * rk;
     }
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
       const double *Alu = B + (size_t)(ni + a) * n;  // row a of [A_lu | A_ll]
       double s = (lane < n) ? Alu[lane] : r[ni + a];
 #pragma unroll
-      for (int i = 0; i < kCondMaxInt; ++i)
+      for (int i = 0; i < MAXI; ++i)
         if (i < ni) s -= Alu[i] * col[i];
       if (lane < n) { if (schur) schur[(e * nt + a) * nt + b] = s; }
       else if (gvec) gvec[e * nt + a] = s;
@@ -93,8 +94,15 @@ void launch_condense(int ni, int nt, int64_t nelem, const double *blocks, const 
   MHA_REQUIRE(ni >= 1 && ni <= kCondMaxInt && nt >= 1 && ni + nt + 1 <= 64, MHA_ERR_INVALID,
               "condensation: need 1 <= n_int <= " << kCondMaxInt << " and n_int + n_trace + 1 <= 64");
   const int grid = (int)((nelem + kCondWaves - 1) / kCondWaves);
-  hipLaunchKernelGGL(condense_kernel, dim3(grid), dim3(64 * kCondWaves), 0, stream, ni, nt, nelem, blocks, res, schur,
-                     gvec, du, singular);
+  if (ni <= 8)
+    hipLaunchKernelGGL(condense_kernel<8>, dim3(grid), dim3(64 * kCondWaves), 0, stream, ni, nt, nelem, blocks, res, schur,
+                       gvec, du, singular);
+  else if (ni <= 16)
+    hipLaunchKernelGGL(condense_kernel<16>, dim3(grid), dim3(64 * kCondWaves), 0, stream, ni, nt, nelem, blocks, res, schur,
+                       gvec, du, singular);
+  else
+    hipLaunchKernelGGL(condense_kernel<kCondMaxInt>, dim3(grid), dim3(64 * kCondWaves), 0, stream, ni, nt, nelem, blocks,
+                       res, schur, gvec, du, singular);
   MHA_HIP(hipGetLastError());
 }
 
