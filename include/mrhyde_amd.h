@@ -112,6 +112,7 @@ int mha_physics_select(mha_context *ctx, int physics_id);
 #define MHA_FUNC_CONSTANT 0
 #define MHA_FUNC_IP_ARRAY 1     /* dev pointer to [E][numip] f64                    */
 #define MHA_FUNC_SINPROD 2      /* amp * prod_d sin(freq[d]*x_d), evaluated at ip   */
+#define MHA_FUNC_EXPRESSION 3   /* a deck string, see mha_set_function_expression    */
 /* thermal: "thermal source","thermal diffusion","specific heat","density" (thermal.cpp:52-63);
  * porousMixed: "source","Kinv_xx","Kinv_yy","Kinv_zz","total_mobility" (porousMixed.cpp:141-151);
  * navierstokes: "source ux","source pr","source uy","source uz","density","viscosity"
@@ -120,6 +121,19 @@ int mha_physics_select(mha_context *ctx, int physics_id);
  * data function "Neumann e <sidename>" / "Dirichlet e <sidename>" (see boundary groups)    */
 int mha_set_function(mha_context *ctx, const char *name, int kind, double amp, const double *freq3,
                      const double *ip_array_dev);
+
+/* A function given as the string of the reference's input deck ("Functions:" / boundary-condition entries), e.g.
+ * "8*(pi*pi)*sin(2*pi*x)*sin(2*pi*y)": compiled on the host, interpreted at the integration points on the device.
+ * replaces: FunctionManager::addFunction + decomposeFunctions + evaluate for position/time expressions
+ *   src/managers/functionManager.cpp:60-93, 95-540, 543-860, src/tools/interpreter.cpp.
+ * Grammar: numbers; x y z t nx ny nz h pi (functionManager.cpp:21); + - * / ^, unary minus, < > <= >=, parentheses;
+ * sin cos tan exp log abs sqrt sinh cosh (:22).  Solution fields, other named functions and the view reductions
+ * max/min/mean/emax/emin/emean are rejected (MHA_ERR_INVALID).  `t` is the time given to mha_set_time.              */
+int mha_set_function_expression(mha_context *ctx, const char *name, const char *expression);
+/* syntax / vocabulary check of a deck string without a context (host only, no GPU needed): MHA_OK or MHA_ERR_INVALID */
+int mha_check_expression(const char *expression);
+/* replaces: Workset::setTime (src/tools/workset.hpp:127): the value of `t` in expressions                         */
+int mha_set_time(mha_context *ctx, double time);
 
 /* ---- time integration state -----------------------------------------------
  * replaces: Workset::setDeltat/setStage + butcher/BDF tables consumed by

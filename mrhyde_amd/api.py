@@ -23,7 +23,7 @@ EXPORTS = [
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
-    "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense",
+    "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense", "mha_set_function_expression", "mha_set_time", "mha_check_expression",
 ]
 SWH_INTERFACE, SWH_FARFIELD, SWH_SLIP = 0, 1, 2
 BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
@@ -99,6 +99,8 @@ def load_library():
         _lib.mha_set_orientation.argtypes = [C.c_void_p, C.c_void_p]
         _lib.mha_get_mass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mha_swhdg_element_blocks.argtypes = [C.c_void_p] * 9
+        _lib.mha_set_function_expression.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        _lib.mha_set_time.argtypes = [C.c_void_p, C.c_double]
         _lib.mha_batched_condense.argtypes = [C.c_int, C.c_int, C.c_int64] + [C.c_void_p] * 7
         _lib.mha_swhdg_side_terms.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int64] + [C.c_void_p] * 10
         _lib.mha_swhdg_eigendecomp.argtypes = [C.c_double, C.c_int64] + [C.c_void_p] * 6
@@ -155,6 +157,13 @@ def batched_condense(n_int, n_trace, blocks, res, want_du=True):
     _check(load_library().mha_batched_condense(n_int, n_trace, E, _ptr(blocks), _ptr(res), _ptr(schur), _ptr(gvec), _ptr(du),
                                                C.byref(ns), None))
     return schur, gvec, du, ns.value
+
+
+def check_expression(text):
+    """Raises MhaError if the deck string is not in the supported grammar (host only)."""
+    lib = load_library()
+    lib.mha_check_expression.argtypes = [C.c_char_p]
+    _check(lib.mha_check_expression(text.encode()))
 
 
 def swhdg_eigendecomp(g, Shat, normals):
@@ -277,9 +286,11 @@ class Block:
         return rowptr, colind
 
     def set_function(self, name, value):
-        """value: float | ("sinprod", amp, freq[dim]) | CUDA tensor [E, numip]."""
+        """value: float | deck string ("8*pi*pi*sin(2*pi*x)") | ("sinprod", amp, freq[dim]) | CUDA tensor [E, numip]."""
         lib = load_library()
-        if isinstance(value, (int, float)):
+        if isinstance(value, str):
+            _check(lib.mha_set_function_expression(self._h, name.encode(), value.encode()))
+        elif isinstance(value, (int, float)):
             _check(lib.mha_set_function(self._h, name.encode(), FUNC_CONSTANT, float(value), None, None))
         elif isinstance(value, tuple) and value[0] == "sinprod":
             fr = np.zeros(3)
@@ -289,6 +300,9 @@ class Block:
         else:
             self._keep.append(value)
             _check(lib.mha_set_function(self._h, name.encode(), FUNC_IP_ARRAY, 0.0, None, _ptr(value)))
+
+    def set_time(self, t):
+        _check(load_library().mha_set_time(self._h, float(t)))
 
     def set_time_integration(self, transient, nsteps=0, nstages=0, stage=0, dt=1.0, butcher_A=None, butcher_b=None,
                              bdf=None):

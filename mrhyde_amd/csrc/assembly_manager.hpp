@@ -29,6 +29,8 @@ class AssemblyManager {
   void setGraph(const int32_t *rowptr, const int32_t *colind);
   void selectPhysics(int physics_id);
   void setFunction(const std::string &name, int kind, double amp, const double *freq3, const double *ip_dev);
+  void setFunctionExpression(const std::string &name, const std::string &text) { functions_.addExpression(name, text); }
+  void setTime(double t) { functions_.setTime(t); wkset_.setTime(t); }
   void setTimeIntegration(int transient, int nsteps, int nstages, int stage, double dt, const double *A,
                           const double *b, const double *bdf);
 

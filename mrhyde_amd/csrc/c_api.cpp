@@ -3,6 +3,7 @@
 #include <string>
 
 #include "assembly_manager.hpp"
+#include "expression.hpp"
 #include "mesh.hpp"
 #include "row_blocks.hpp"
 
@@ -108,6 +109,26 @@ int mha_set_function(mha_context *ctx, const char *name, int kind, double amp, c
     MHA_REQUIRE(name != nullptr, MHA_ERR_INVALID, "null function name");
     mgr(ctx).setFunction(name, kind, amp, freq3, ip_array_dev);
   });
+}
+
+int mha_set_function_expression(mha_context *ctx, const char *name, const char *expression) {
+  return guarded([&] {
+    MHA_REQUIRE(name && expression, MHA_ERR_INVALID, "null argument");
+    mgr(ctx).setFunctionExpression(name, expression);
+  });
+}
+
+int mha_check_expression(const char *expression) {
+  return guarded([&] {
+    MHA_REQUIRE(expression, MHA_ERR_INVALID, "null argument");
+    std::vector<int32_t> code;
+    std::vector<double> consts;
+    mha::compile_expression(expression, code, consts);
+  });
+}
+
+int mha_set_time(mha_context *ctx, double time) {
+  return guarded([&] { mgr(ctx).setTime(time); });
 }
 
 int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int num_stages, int stage,

@@ -52,11 +52,75 @@ __device__ __forceinline__ double sin_moderate(double x) {
   return (k & 2) ? -v : v;
 }
 
-// Value of a named function at integration point (e,q) with physical coordinates x.
+// MHA_FUNC_EXPRESSION: postfix program over x y z t nx ny nz h pi (expression.hpp); normals / h are 0 when the caller
+// has none.  The reference evaluates one kernel per node of the expression DAG (functionManager.cpp:543-860).
 template <int DIM>
-__device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int nq, const double *x) {
+__device__ __noinline__ double eval_expression(const FuncDesc &f, const double *x, const double *nrm, double h) {
+  double st[kExprStack];
+  int sp = 0;
+  for (const int32_t *pc = f.code;; ++pc) {
+    const int op = *pc;
+    if (op == EXPR_END) break;
+    if (op == EXPR_CONST) { st[sp++] = f.consts[*++pc]; continue; }
+    if (op <= EXPR_PI) {
+      double v = 0.0;
+      switch (op) {
+        case EXPR_X: v = x[0]; break;
+        case EXPR_Y: v = x[1]; break;
+        case EXPR_Z: v = DIM > 2 ? x[DIM - 1] : 0.0; break;
+        case EXPR_T: v = f.t; break;
+        case EXPR_NX: v = nrm ? nrm[0] : 0.0; break;
+        case EXPR_NY: v = nrm ? nrm[1] : 0.0; break;
+        case EXPR_NZ: v = (nrm && DIM > 2) ? nrm[DIM - 1] : 0.0; break;
+        case EXPR_H: v = h; break;
+        default: v = 3.141592653589793238; break;
+      }
+      st[sp++] = v;
+      continue;
+    }
+    if (op <= EXPR_GE) {
+      const double b = st[--sp], a = st[sp - 1];
+      double v;
+      switch (op) {
+        case EXPR_ADD: v = a + b; break;
+        case EXPR_SUB: v = a - b; break;
+        case EXPR_MUL: v = a * b; break;
+        case EXPR_DIV: v = a / b; break;
+        case EXPR_POW: v = pow(a, b); break;
+        case EXPR_LT: v = a < b ? 1.0 : 0.0; break;
+        case EXPR_GT: v = a > b ? 1.0 : 0.0; break;
+        case EXPR_LE: v = a <= b ? 1.0 : 0.0; break;
+        default: v = a >= b ? 1.0 : 0.0; break;
+      }
+      st[sp - 1] = v;
+      continue;
+    }
+    const double a = st[sp - 1];
+    double v;
+    switch (op) {
+      case EXPR_NEG: v = -a; break;
+      case EXPR_SIN: v = sin(a); break;
+      case EXPR_COS: v = cos(a); break;
+      case EXPR_TAN: v = tan(a); break;
+      case EXPR_EXP: v = exp(a); break;
+      case EXPR_LOG: v = log(a); break;
+      case EXPR_ABS: v = fabs(a); break;
+      case EXPR_SQRT: v = sqrt(a); break;
+      case EXPR_SINH: v = sinh(a); break;
+      default: v = cosh(a); break;
+    }
+    st[sp - 1] = v;
+  }
+  return st[0];
+}
+
+// Value of a named function at integration point (e,q) with physical coordinates x (nrm: unit normal on sides).
+template <int DIM>
+__device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int nq, const double *x,
+                                            const double *nrm = nullptr, double h = 0.0) {
   if (f.kind == MHA_FUNC_CONSTANT) return f.amp;
   if (f.kind == MHA_FUNC_IP_ARRAY) return f.ip[(size_t)e * nq + q];
+  if (f.kind == MHA_FUNC_EXPRESSION) return eval_expression<DIM>(f, x, nrm, h);
   double s = f.amp;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) s *= sin_moderate(f.freq[d] * x[d]);

@@ -11,11 +11,23 @@ constexpr int kGeoRec = 20, kGeoDet = 6, kGeoJ = 7, kGeoXc = 16;
 
 // What FunctionManager::evaluate(name,"ip") yields for one named function
 // (reference: src/managers/functionManager.cpp:543-760): constant, per-ip data, or a closed form.
+// postfix program of MHA_FUNC_EXPRESSION (expression.hpp compiles, device_math.hpp interprets)
+enum ExprOp : int32_t {
+  EXPR_END = 0, EXPR_CONST,
+  EXPR_X, EXPR_Y, EXPR_Z, EXPR_T, EXPR_NX, EXPR_NY, EXPR_NZ, EXPR_H, EXPR_PI,  // operands
+  EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_DIV, EXPR_POW, EXPR_LT, EXPR_GT, EXPR_LE, EXPR_GE,  // binary
+  EXPR_NEG, EXPR_SIN, EXPR_COS, EXPR_TAN, EXPR_EXP, EXPR_LOG, EXPR_ABS, EXPR_SQRT, EXPR_SINH, EXPR_COSH  // unary
+};
+constexpr int kExprStack = 12;
+
 struct FuncDesc {
   int kind = 0;            // MHA_FUNC_*
   double amp = 0.0;
   double freq[3] = {0, 0, 0};
   const double *ip = nullptr;  // [E][numip] device
+  const int32_t *code = nullptr;    // MHA_FUNC_EXPRESSION: postfix program (device)
+  const double *consts = nullptr;   //                      its constants (device)
+  double t = 0.0;                   //                      current time (Workset::setTime)
 };
 
 // Device view of one element block.

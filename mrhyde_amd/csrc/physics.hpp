@@ -21,17 +21,25 @@ namespace mha {
 // or a member of a small closed family evaluated at the physical integration points.
 class FunctionManager {
  public:
-  void addFunction(const std::string &name, const FuncDesc &f) { funcs_[name] = f; }
+  void addFunction(const std::string &name, const FuncDesc &f) { funcs_[name] = f; programs_.erase(name); }
+  // a deck string: compiled to a postfix program kept on the device for the life of the function (expression.hpp)
+  void addExpression(const std::string &name, const std::string &text);
   bool has(const std::string &name) const { return funcs_.count(name) != 0; }
-  const FuncDesc &evaluate(const std::string &name) const {
+  void setTime(double t) { time_ = t; }
+  FuncDesc evaluate(const std::string &name) const {
     auto it = funcs_.find(name);
     // reference: TEUCHOS_TEST_FOR_EXCEPTION "function manager could not evaluate" (functionManager.cpp:573)
     MHA_REQUIRE(it != funcs_.end(), MHA_ERR_INVALID, "function manager could not evaluate: " << name);
-    return it->second;
+    FuncDesc f = it->second;
+    f.t = time_;
+    return f;
   }
 
  private:
+  struct Program { DeviceBuffer<int32_t> code; DeviceBuffer<double> consts; };
   std::map<std::string, FuncDesc> funcs_;
+  std::map<std::string, std::shared_ptr<Program>> programs_;
+  double time_ = 0.0;
 };
 
 class PhysicsBase {

@@ -1,8 +1,26 @@
 #include "physics.hpp"
 
+#include "expression.hpp"
+
 #include <cstdlib>
 
 namespace mha {
+
+void FunctionManager::addExpression(const std::string &name, const std::string &text) {
+  std::vector<int32_t> code;
+  std::vector<double> consts;
+  compile_expression(text, code, consts);
+  auto prog = std::make_shared<Program>();
+  prog->code.upload(code);
+  if (consts.empty()) consts.push_back(0.0);
+  prog->consts.upload(consts);
+  FuncDesc f;
+  f.kind = MHA_FUNC_EXPRESSION;
+  f.code = prog->code.data();
+  f.consts = prog->consts.data();
+  funcs_[name] = f;
+  programs_[name] = prog;
+}
 
 thermal::thermal() {
   label = "thermal";

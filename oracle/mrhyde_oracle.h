@@ -208,10 +208,18 @@ int orc_physical_basis_var(int dim, int type, int order, int qdeg, int nelem, co
                            double *div, double *wts, double *ip);
 
 typedef struct orc_func {
-  int kind;              /* 0 constant amp, 1 per-ip array [E][q] (boundary: [nb][nqs]), 2 amp*prod sin(freq_d x_d) */
+  int kind;              /* 0 constant amp, 1 per-ip array [E][q] (boundary: [nb][nqs]), 2 amp*prod sin(freq_d x_d),
+                            3 deck string `expr` evaluated with orc_eval_expression at time `t`                      */
   double amp, freq[3];
   const double *ip;
+  const char *expr;
+  double t;
 } orc_func;
+/* Value of a deck function string at a point: numbers, x y z t nx ny nz h pi, + - * / ^ (right-assoc, above unary
+ * minus), < > <= >=, parentheses, sin cos tan exp log abs sqrt sinh cosh (functionManager.cpp:21-22; the reference
+ * builds a DAG with Interpreter::split, src/tools/interpreter.cpp).  Recursive descent, evaluated directly -- an
+ * implementation independent of the product's postfix compiler.  Returns 0 and sets *err on a syntax error.        */
+double orc_eval_expression(const char *expr, const double *xyz, double t, const double *nrm, double h, int *err);
 
 /* function slots: thermal {source, diffusion, specific heat, density}; porousMixed {source, Kinv_xx, Kinv_yy,
  * Kinv_zz, total_mobility}; navierstokes {source ux, source pr, source uy, source uz, density, viscosity}.

@@ -419,6 +419,10 @@ typedef struct {
 static double eval_func(const orc_func *f, int dim, size_t e, int q, int nq, const double *x) {
   if (f->kind == 0) return f->amp;
   if (f->kind == 1) return f->ip[e * nq + q];
+  if (f->kind == 3) {
+    double x3[3] = {x[0], x[1], dim > 2 ? x[2] : 0.0};
+    return orc_eval_expression(f->expr, x3, f->t, NULL, 0.0, NULL);
+  }
   double s = f->amp;
   for (int d = 0; d < dim; ++d) s *= sin(f->freq[d] * x[d]);
   return s;

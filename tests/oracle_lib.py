@@ -348,7 +348,8 @@ _sp = C.POINTER(C.c_byte)
 
 
 class Func(C.Structure):
-    _fields_ = [("kind", C.c_int), ("amp", C.c_double), ("freq", C.c_double * 3), ("ip", _dp)]
+    _fields_ = [("kind", C.c_int), ("amp", C.c_double), ("freq", C.c_double * 3), ("ip", _dp), ("expr", C.c_char_p),
+                ("t", C.c_double)]
 
 
 class BlockArgs(C.Structure):
@@ -416,8 +417,32 @@ def physical_basis_var(dim, typ, order, qdeg, nodes, orient=None):
     return out
 
 
+def eval_expression(expr, xyz, t=0.0, nrm=None, h=0.0):
+    f = lib().orc_eval_expression
+    f.restype = C.c_double
+    f.argtypes = [C.c_char_p, _dp, C.c_double, _dp, C.c_double, C.POINTER(C.c_int)]
+    x = np.zeros(3)
+    x[:len(xyz)] = xyz
+    n3 = None
+    if nrm is not None:
+        n3 = np.zeros(3)
+        n3[:len(nrm)] = nrm
+    err = C.c_int()
+    v = f(expr.encode(), _d(x), float(t), _d(n3), float(h), C.byref(err))
+    if err.value:
+        raise ValueError("bad expression: " + expr)
+    return v
+
+
 def _func(spec, keep):
     f = Func()
+    if isinstance(spec, str):  # deck string at time 0
+        spec = ("expr", spec, 0.0)
+    if isinstance(spec, tuple) and spec[0] == "expr":
+        b = spec[1].encode()
+        keep.append(b)
+        f.kind, f.expr, f.t = 3, b, float(spec[2]) if len(spec) > 2 else 0.0
+        return f
     if isinstance(spec, (int, float)):
         f.kind, f.amp = 0, float(spec)
     elif spec[0] == "const":

@@ -444,3 +444,94 @@ def test_thermal_transient_gold_end_to_end(oracle):
     for (t, e), (tg, eg) in zip(errs, _transient_golds()):
         if tg > 0.0:
             assert "%.6g" % e == "%.6g" % eg, (t, e, eg)
+
+
+def _deck(name):
+    import yaml
+    return yaml.safe_load(open(os.path.join(GOLD, name)))["ANONYMOUS"]
+
+
+def test_deck_strings_through_the_device_interpreter(oracle):
+    """MHA_FUNC_EXPRESSION: the `Functions:` strings of the mirrored decks run verbatim on the device.
+    (1) 2D_verification: 'thermal source' string -> gold L2 error; (2) expression source/diffusion on a perturbed mesh
+    against the oracle's independent evaluator, with the time variable t."""
+    torch = _torch()
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import mrhyde_amd
+    src = _deck("thermal_2D_verification.input.yaml")["Functions"]["thermal source"]
+    assert "sin(2*pi*x)" in src
+    m = oracle.mesh_structured(2, 1, (40, 40))
+    pb = oracle.physical_basis(2, 1, 2, m["nodes"])
+    blk = make_block(m, 2, 1, 2, fixed=m["boundary"])
+    blk.set_function("thermal source", src)
+    rowptr, colind = blk.get_graph()
+    u = np.zeros(m["ndof"])
+    res = torch.empty(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.empty(len(colind), dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True)
+    blk.apply_dbc_diag(vals)
+    torch.cuda.synchronize()
+    J = sp.csr_matrix((vals.cpu().numpy(), colind, rowptr), shape=(m["ndof"],) * 2)
+    u = spla.spsolve(J.tocsc(), res.cpu().numpy())
+    err = oracle.l2_error_sinprod(2, 1, 2, m["lids"], m["offsets"], pb, u, [2 * np.pi] * 2)
+    assert "%.6g" % err == "0.00102776"
+    # (2) time-dependent expression + variable diffusion on a perturbed Q2 hex mesh, general path, vs the oracle
+    mm = oracle.mesh_multi(3, (3, 2, 2), [oracle.HGRAD], [2])
+    rng = np.random.default_rng(81)
+    v = mm["verts"].copy()
+    inner = np.all((v > 1e-12) & (v < 1 - 1e-12), axis=1)
+    v[inner] += 0.04 * rng.uniform(-1, 1, (inner.sum(), 3))
+    mm["verts"], mm["nodes"] = v, np.ascontiguousarray(v[mm["cell2vert"]])
+    uu = rng.uniform(-1, 1, mm["ndof"])
+    fsrc = "(8*pi^2*sin(2*pi*t) + 2*pi*cos(2*pi*t))*sin(2*pi*x)*sin(2*pi*y)*exp(-z)"
+    fdif = "1.5 + 0.5*cos(pi*x)*(y<0.5) - z/4"
+    t = 0.37
+    ref = oracle.assemble_block(mm, oracle.PHYS_THERMAL, 4, uu,
+                                funcs={"thermal source": ("expr", fsrc, t), "thermal diffusion": ("expr", fdif, t)})
+    b2 = make_block(mm, 3, 2, 4, graph=(ref["rowptr"], ref["colind"]))
+    b2.set_function("thermal source", fsrc)
+    b2.set_function("thermal diffusion", fdif)
+    b2.set_time(t)
+    for path in (mrhyde_amd.PATH_AUTO, mrhyde_amd.PATH_ELEMENT_ATOMIC, mrhyde_amd.PATH_POINT_ENGINE):
+        r2 = torch.zeros(mm["ndof"], dtype=torch.float64, device="cuda")
+        v2 = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+        b2.assemble_jacres(torch.tensor(uu, device="cuda"), r2, v2, overwrite=True, path=path)
+        torch.cuda.synchronize()
+        assert rel_err(v2.cpu().numpy(), ref["crs_vals"]) < RTOL and rel_err(r2.cpu().numpy(), ref["res"]) < RTOL
+    with pytest.raises(mrhyde_amd.MhaError) as e:
+        b2.set_function("thermal source", "2*e + grad(e)[x]")  # solution fields are not available to expressions
+    assert e.value.code == 1
+
+
+def test_mixed_bcs_deck_strings(oracle):
+    """2D_mixed_bcs with the deck's own Neumann strings (normals-free cos/sin products) evaluated on the device."""
+    torch = _torch()
+    import scipy.sparse as sp
+    import mrhyde_amd
+    from test_oracle_golden import _gold_l2, solve_mixed_bcs
+    deck = _deck("thermal_2D_mixed_bcs.input.yaml")
+    neu = deck["Physics"]["Neumann conditions"]["e"]
+    state = {}
+
+    def assemble(m, pb, u, groups):
+        if "blk" not in state:
+            blk = make_block(m, 2, 1, 2, fixed=m["fixed"])
+            blk.set_function("thermal source", deck["Functions"]["thermal source"])
+            for name, (be, bs, _) in zip(("top", "bottom"), groups):
+                blk.add_boundary_group(name, mrhyde_amd.BC_NEUMANN, be, bs)
+                blk.set_function("Neumann e " + name, neu[name])
+            state["blk"], state["graph"] = blk, blk.get_graph()
+        blk = state["blk"]
+        rowptr, colind = state["graph"]
+        ud = torch.tensor(u, device="cuda")
+        res = torch.empty(m["ndof"], dtype=torch.float64, device="cuda")
+        vals = torch.empty(len(colind), dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(ud, res, vals, overwrite=True)
+        blk.assemble_boundary(ud, res, vals)
+        blk.apply_dbc_diag(vals)
+        torch.cuda.synchronize()
+        return sp.csr_matrix((vals.cpu().numpy(), colind, rowptr), shape=(m["ndof"],) * 2), res.cpu().numpy()
+
+    err = solve_mixed_bcs(assemble, oracle)
+    assert "%.6g" % err == "%.6g" % _gold_l2("thermal_2D_mixed_bcs.gold") == "0.00102733"
