@@ -115,16 +115,31 @@ __device__ __noinline__ double eval_expression(const FuncDesc &f, const double *
 }
 
 // Value of a named function at integration point (e,q) with physical coordinates x (nrm: unit normal on sides).
-template <int DIM>
+// EXPR: whether MHA_FUNC_EXPRESSION can occur.  The interpreter is a real call with a private stack; a kernel that
+// merely contains the call pays its register budget and scratch (the affine element kernel went from 8 to 2 waves per
+// SIMD), so kernels are instantiated both ways and the launcher picks by has_expression().
+template <int DIM, bool EXPR = false>
 __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int nq, const double *x,
                                             const double *nrm = nullptr, double h = 0.0) {
   if (f.kind == MHA_FUNC_CONSTANT) return f.amp;
   if (f.kind == MHA_FUNC_IP_ARRAY) return f.ip[(size_t)e * nq + q];
-  if (f.kind == MHA_FUNC_EXPRESSION) return eval_expression<DIM>(f, x, nrm, h);
+  if constexpr (EXPR) {
+    if (f.kind == MHA_FUNC_EXPRESSION) return eval_expression<DIM>(f, x, nrm, h);
+  }
   double s = f.amp;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) s *= sin_moderate(f.freq[d] * x[d]);
   return s;
+}
+
+inline bool has_expression(const FuncDesc &f) { return f.kind == MHA_FUNC_EXPRESSION; }
+inline bool has_expression(const ThermalDev &ph) {
+  return has_expression(ph.source) || has_expression(ph.diff) || has_expression(ph.cp) || has_expression(ph.rho);
+}
+inline bool has_expression(const PhysParamsDev &pp) {
+  for (const FuncDesc &f : pp.f)
+    if (has_expression(f)) return true;
+  return false;
 }
 
 // reference-space gradient and value of sum_j c[j] N_j at integration point q (tensor basis)

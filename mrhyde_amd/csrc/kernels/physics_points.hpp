@@ -24,11 +24,11 @@ struct PointArgs {
 };
 
 // thermal (reference: src/physics/thermal.cpp:71-165); functions {source, diffusion, specific heat, density}
-template <int DIM>
+template <int DIM, bool EXPR>
 __device__ __forceinline__ void thermal_point(const PointArgs<DIM> &a, Dual *F) {
   const PhysParamsDev &pp = *a.pp;
-  const double f = eval_func<DIM>(pp.f[0], a.e, a.q, a.nq, a.x), kap = eval_func<DIM>(pp.f[1], a.e, a.q, a.nq, a.x);
-  const double cp = eval_func<DIM>(pp.f[2], a.e, a.q, a.nq, a.x), rho = eval_func<DIM>(pp.f[3], a.e, a.q, a.nq, a.x);
+  const double f = eval_func<DIM, EXPR>(pp.f[0], a.e, a.q, a.nq, a.x), kap = eval_func<DIM, EXPR>(pp.f[1], a.e, a.q, a.nq, a.x);
+  const double cp = eval_func<DIM, EXPR>(pp.f[2], a.e, a.q, a.nq, a.x), rho = eval_func<DIM, EXPR>(pp.f[3], a.e, a.q, a.nq, a.x);
   F[0] = a.Ud[0] * (rho * cp) - f;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) F[1 + d] = a.U[1 + d] * kap;
@@ -36,15 +36,15 @@ __device__ __forceinline__ void thermal_point(const PointArgs<DIM> &a, Dual *F) 
 
 // porousMixed (reference: src/physics/porousMixed.cpp:158-338); myvars {p (HVOL), u (HDIV)};
 // functions {source, Kinv_xx, Kinv_yy, Kinv_zz, total_mobility}
-template <int DIM>
+template <int DIM, bool EXPR>
 __device__ __forceinline__ void porous_point(const PointArgs<DIM> &a, Dual *F) {
   const PhysParamsDev &pp = *a.pp;
-  const double src = eval_func<DIM>(pp.f[0], a.e, a.q, a.nq, a.x), mob = eval_func<DIM>(pp.f[4], a.e, a.q, a.nq, a.x);
+  const double src = eval_func<DIM, EXPR>(pp.f[0], a.e, a.q, a.nq, a.x), mob = eval_func<DIM, EXPR>(pp.f[4], a.e, a.q, a.nq, a.x);
   const Dual p = a.U[0], divu = a.U[1 + DIM];
   F[0] = mk(src) - divu;  // (source - div u, q)
 #pragma unroll
   for (int d = 0; d < DIM; ++d) {
-    const double Kinv = eval_func<DIM>(pp.f[1 + d], a.e, a.q, a.nq, a.x);
+    const double Kinv = eval_func<DIM, EXPR>(pp.f[1 + d], a.e, a.q, a.nq, a.x);
     F[1 + d] = a.U[1 + d] * Kinv / mob;  // ((mobility K)^-1 u, v)
   }
   F[1 + DIM] = -p;  // -(p, div v)
@@ -52,15 +52,15 @@ __device__ __forceinline__ void porous_point(const PointArgs<DIM> &a, Dual *F) {
 
 // navierstokes (reference: src/physics/navierstokes.cpp:82-849, computeTau :1054-1079); myvars {ux, pr, uy[, uz]};
 // functions {source ux, source pr, source uy, source uz, density, viscosity}; p = {useSUPG, usePSPG, fix_uz_offsets}
-template <int DIM>
+template <int DIM, bool EXPR>
 __device__ __forceinline__ void navierstokes_point(const PointArgs<DIM> &a, Dual *F) {
   constexpr int S = 1 + DIM;                 // slots per HGRAD variable
   constexpr int vnum[3] = {0, 2, 3}, prnum = 1;
   const PhysParamsDev &pp = *a.pp;
   const bool useSUPG = pp.p[0] != 0.0, usePSPG = pp.p[1] != 0.0, fix_uz = pp.p[2] != 0.0;
-  const double dens = eval_func<DIM>(pp.f[4], a.e, a.q, a.nq, a.x), visc = eval_func<DIM>(pp.f[5], a.e, a.q, a.nq, a.x);
-  const double src[3] = {eval_func<DIM>(pp.f[0], a.e, a.q, a.nq, a.x), eval_func<DIM>(pp.f[2], a.e, a.q, a.nq, a.x),
-                         DIM == 3 ? eval_func<DIM>(pp.f[3], a.e, a.q, a.nq, a.x) : 0.0};
+  const double dens = eval_func<DIM, EXPR>(pp.f[4], a.e, a.q, a.nq, a.x), visc = eval_func<DIM, EXPR>(pp.f[5], a.e, a.q, a.nq, a.x);
+  const double src[3] = {eval_func<DIM, EXPR>(pp.f[0], a.e, a.q, a.nq, a.x), eval_func<DIM, EXPR>(pp.f[2], a.e, a.q, a.nq, a.x),
+                         DIM == 3 ? eval_func<DIM, EXPR>(pp.f[3], a.e, a.q, a.nq, a.x) : 0.0};
   Dual vel[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; ++d) vel[d] = a.U[vnum[d] * S];
@@ -115,7 +115,7 @@ __device__ __forceinline__ void navierstokes_point(const PointArgs<DIM> &a, Dual
 
 // shallowwaterHybridized (reference: src/physics/shallowwaterHybridized.cpp:113-184 with computeFluxVector(false)
 // :409-480); myvars {H, Hux, Huy} (2-D); functions {source H, source Hux, source Huy}; p = {g}
-template <int DIM>
+template <int DIM, bool EXPR>
 __device__ __forceinline__ void swhdg_point(const PointArgs<DIM> &a, Dual *F) {
   static_assert(DIM >= 2, "");
   constexpr int S = 1 + DIM;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void swhdg_point(const PointArgs<DIM> &a, Dual *F) {
   Fl[2][0] = Hux * Huy / H; Fl[2][1] = Huy * Huy / H + hh;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    F[i * S] = a.Ud[i * S] - eval_func<DIM>(pp.f[i], a.e, a.q, a.nq, a.x);  // (v, dS/dt) - (v, source)
+    F[i * S] = a.Ud[i * S] - eval_func<DIM, EXPR>(pp.f[i], a.e, a.q, a.nq, a.x);  // (v, dS/dt) - (v, source)
     F[i * S + 1] = -Fl[i][0];                                               // -(dv/dx, F_x)
     F[i * S + 2] = -Fl[i][1];                                               // -(dv/dy, F_y)
   }

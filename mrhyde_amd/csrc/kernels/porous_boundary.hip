@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void porous_boundary_kernel(BlockDev b, SideTa
 #pragma unroll
       for (int d = 0; d < DIM; ++d) vdotn += J[d * DIM + c] * nrm[d];
       vdotn *= sg * phi / det;
-      r += eval_func<DIM>(bd.data, k, q, nqs, x, nrm) * w * vdotn;
+      r += eval_func<DIM, true>(bd.data, k, q, nqs, x, nrm) * w * vdotn;
     }
     const int row = b.lids[(size_t)e * n + b.offsets[u0 + dof]];
     if (out.res && !(b.fixed && b.fixed[row])) unsafeAtomicAdd(out.res + row, -r);

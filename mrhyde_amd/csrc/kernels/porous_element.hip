@@ -18,7 +18,7 @@
 namespace mha {
 namespace {
 
-template <int DIM>
+template <int DIM, bool EXPR>
 __global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm,
                                                              ElemOut out) {
   constexpr int NN = 1 << DIM, NU = 2 * DIM, N = 1 + NU;
@@ -80,10 +80,10 @@ __global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayo
 #pragma unroll
     for (int c = 0; c < DIM; ++c) xi[c] = 2.0 * Tu[c * vl.cardpad[1] + 2 * c + 1] - 1.0;
     const double w = b.ref_wts[q] * det, rdet = 1.0 / det;
-    const double src = eval_func<DIM>(pp.f[0], e, q, NQ, x), mob = eval_func<DIM>(pp.f[4], e, q, NQ, x);
+    const double src = eval_func<DIM, EXPR>(pp.f[0], e, q, NQ, x), mob = eval_func<DIM, EXPR>(pp.f[4], e, q, NQ, x);
     double kinv[DIM];
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) kinv[d] = eval_func<DIM>(pp.f[1 + d], e, q, NQ, x);
+    for (int d = 0; d < DIM; ++d) kinv[d] = eval_func<DIM, EXPR>(pp.f[1 + d], e, q, NQ, x);
     // v_i = sg_i * ph_i * J[:,c_i] / det, div_i = sg_i * (+-1/2) / det
     double ph[NU], dv[NU], uq[DIM], divu = 0.0;
 #pragma unroll
@@ -154,8 +154,9 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
   MHA_REQUIRE(out.res == nullptr && out.crs_vals == nullptr, MHA_ERR_INVALID,
               "porous element kernel writes dense element arrays only");
   const int grid = (b.e_count + 127) / 128;
-  if (b.dim == 2) hipLaunchKernelGGL(porous_element_kernel<2>, dim3(grid), dim3(128), 0, stream, b, vl, pp, tm, out);
-  else hipLaunchKernelGGL(porous_element_kernel<3>, dim3(grid), dim3(128), 0, stream, b, vl, pp, tm, out);
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(128), 0, stream, b, vl, pp, tm, out); };
+  if (has_expression(pp)) { if (b.dim == 2) go(porous_element_kernel<2, true>); else go(porous_element_kernel<3, true>); }
+  else { if (b.dim == 2) go(porous_element_kernel<2, false>); else go(porous_element_kernel<3, false>); }
   MHA_HIP(hipGetLastError());
 }
 

@@ -58,8 +58,8 @@ __global__ __launch_bounds__(64 * kSwWaves) void swhdg_boundary_kernel(BlockDev 
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      Sh[i] = eval_func<DIM>(sw.aux[i], k, lane, nqs, x, nrm);
-      Sinf[i] = eval_func<DIM>(sw.farfield[i], k, lane, nqs, x, nrm);
+      Sh[i] = eval_func<DIM, true>(sw.aux[i], k, lane, nqs, x, nrm);
+      Sinf[i] = eval_func<DIM, true>(sw.farfield[i], k, lane, nqs, x, nrm);
     }
     const bool roe = sw.roe != 0;
     double f[3];

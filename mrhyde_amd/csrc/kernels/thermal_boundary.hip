@@ -80,8 +80,8 @@ __global__ __launch_bounds__(64 * kBndWaves) void thermal_boundary_kernel(BlockD
     double Ji[DIM * DIM], nrm[DIM], w, x[DIM];
     side_point<DIM>(b.nodes + (size_t)e * NN * DIM, st, s, lane, Ji, nrm, w, x);
     s_w[wv][lane] = w;
-    s_g[wv][lane] = eval_func<DIM>(bd.data, k, lane, nqs, x, nrm);
-    s_kap[wv][lane] = eval_func<DIM>(bd.diff, k, lane, nqs, x, nrm);
+    s_g[wv][lane] = eval_func<DIM, true>(bd.data, k, lane, nqs, x, nrm);
+    s_kap[wv][lane] = eval_func<DIM, true>(bd.diff, k, lane, nqs, x, nrm);
 #pragma unroll
     for (int i = 0; i < DIM * DIM; ++i) s_Ji[wv][lane * DIM * DIM + i] = Ji[i];
 #pragma unroll

@@ -42,7 +42,7 @@ struct Shape {
   static constexpr int PER_WAVE = O_G + N * NQ * DIM;
 };
 
-template <int DIM, int P, int NQ1, int EPB>
+template <int DIM, int P, int NQ1, int EPB, bool EXPR>
 __global__ __launch_bounds__(64 * EPB) void thermal_element_kernel(BlockDev b, ThermalDev ph, ElemOut out) {
   using S = Shape<DIM, P, NQ1>;
   constexpr int N = S::N, NQ = S::NQ, NN = S::NN;
@@ -113,9 +113,9 @@ __global__ __launch_bounds__(64 * EPB) void thermal_element_kernel(BlockDev b, T
         x[d] = s;
       }
       const double w = s_w[q] * det;
-      const double kap = eval_func<DIM>(ph.diff, e, q, NQ, x);
-      const double rc = eval_func<DIM>(ph.rho, e, q, NQ, x) * eval_func<DIM>(ph.cp, e, q, NQ, x);
-      const double f = eval_func<DIM>(ph.source, e, q, NQ, x);
+      const double kap = eval_func<DIM, EXPR>(ph.diff, e, q, NQ, x);
+      const double rc = eval_func<DIM, EXPR>(ph.rho, e, q, NQ, x) * eval_func<DIM, EXPR>(ph.cp, e, q, NQ, x);
+      const double f = eval_func<DIM, EXPR>(ph.source, e, q, NQ, x);
 #pragma unroll
       for (int k = 0; k < DIM * DIM; ++k) wv[S::O_JI + q * DIM * DIM + k] = Ji[k];
       wv[S::O_KQ + q] = kap * w;
@@ -211,17 +211,16 @@ template <int DIM, int P, int NQ1, int EPB>
 void launch_one(const BlockDev &b, const ThermalDev &ph, const ElemOut &out, hipStream_t stream) {
   using S = Shape<DIM, P, NQ1>;
   const size_t lds = sizeof(double) * (S::SHARED + (size_t)EPB * S::PER_WAVE);
-  auto kern = thermal_element_kernel<DIM, P, NQ1, EPB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    attr_set = true;
-  }
   if (b.e_count <= 0) return;
   const int grid = (b.e_count + EPB - 1) / EPB;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * EPB), lds, stream, b, ph, out);
-  MHA_HIP(hipGetLastError());
+  auto go = [&](auto kern) {
+    MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * EPB), lds, stream, b, ph, out);
+    MHA_HIP(hipGetLastError());
+  };
+  if (has_expression(ph)) go(thermal_element_kernel<DIM, P, NQ1, EPB, true>);
+  else go(thermal_element_kernel<DIM, P, NQ1, EPB, false>);
 }
 
 }  // namespace

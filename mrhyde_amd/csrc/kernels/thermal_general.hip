@@ -64,7 +64,7 @@ struct GK {
   static constexpr int REC = (O_PT + KC * NP + 1) / 2 * 2;
 };
 
-template <int DIM, int P, int NQ1, bool TR>
+template <int DIM, int P, int NQ1, bool TR, bool EXPR>
 __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
                                                                        const uint8_t *__restrict__ slot8,
                                                                        const uint16_t *__restrict__ slot16, ElemOut out) {
@@ -140,9 +140,9 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
       }
       invert<DIM>(J, Ji, det);
       const double w = sh[S::S_W + q] * det;
-      const double kap = eval_func<DIM>(ph.diff, e, q, NQ, x);
-      const double rc = eval_func<DIM>(ph.rho, e, q, NQ, x) * eval_func<DIM>(ph.cp, e, q, NQ, x);
-      const double f = eval_func<DIM>(ph.source, e, q, NQ, x);
+      const double kap = eval_func<DIM, EXPR>(ph.diff, e, q, NQ, x);
+      const double rc = eval_func<DIM, EXPR>(ph.rho, e, q, NQ, x) * eval_func<DIM, EXPR>(ph.cp, e, q, NQ, x);
+      const double f = eval_func<DIM, EXPR>(ph.source, e, q, NQ, x);
       int k = 0;
 #pragma unroll
       for (int a = 0; a < DIM; ++a)
@@ -342,8 +342,13 @@ void launch_one(const BlockDev &b, const ThermalDev &ph, const AffineDev &af, co
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S0::NT), lds, stream, b, ph, af, s8, s16, out);
     MHA_HIP(hipGetLastError());
   };
-  if (tr) go(thermal_general_element_kernel<DIM, P, NQ1, true>);
-  else go(thermal_general_element_kernel<DIM, P, NQ1, false>);
+  if (has_expression(ph)) {
+    if (tr) go(thermal_general_element_kernel<DIM, P, NQ1, true, true>);
+    else go(thermal_general_element_kernel<DIM, P, NQ1, false, true>);
+  } else {
+    if (tr) go(thermal_general_element_kernel<DIM, P, NQ1, true, false>);
+    else go(thermal_general_element_kernel<DIM, P, NQ1, false, false>);
+  }
 }
 
 }  // namespace

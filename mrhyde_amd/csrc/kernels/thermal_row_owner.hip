@@ -162,7 +162,7 @@ struct EK {
 
 constexpr int kK1Threads = 256, kK1Lanes = 32, kK1Elems = kK1Threads / kK1Lanes;
 
-template <int DIM, int P, int NQ1, bool TR>
+template <int DIM, int P, int NQ1, bool TR, bool EXPR>
 __global__ __launch_bounds__(kK1Threads) void thermal_affine_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
                                                                              double *res) {
   using S = EK<DIM, P, NQ1, TR>;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kK1Threads) void thermal_affine_element_kernel(Bloc
       for (int c = 0; c < DIM; ++c) s += G[a][c] * gh[c];
       E[S::O_F + q * DIM + a] = wq * kap * s;
     }
-    const double f = eval_func<DIM>(ph.source, e, q, NQ, x);
+    const double f = eval_func<DIM, EXPR>(ph.source, e, q, NQ, x);
     E[S::O_RQ + q] = (rc * tt - f) * E[S::O_DET] * wq;
   }
   __syncthreads();
@@ -646,12 +646,15 @@ template <int DIM, int P, int NQ1>
 void launch_k1(const BlockDev &b, const ThermalDev &ph, const AffineDev &af, double *res, hipStream_t stream) {
   if (b.e_count <= 0) return;
   const int grid = (b.e_count + kK1Elems - 1) / kK1Elems;
-  if (ph.time.transient)
-    hipLaunchKernelGGL((thermal_affine_element_kernel<DIM, P, NQ1, true>), dim3(grid), dim3(kK1Threads), 0, stream, b,
-                       ph, af, res);
-  else
-    hipLaunchKernelGGL((thermal_affine_element_kernel<DIM, P, NQ1, false>), dim3(grid), dim3(kK1Threads), 0, stream, b,
-                       ph, af, res);
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1Threads), 0, stream, b, ph, af, res); };
+  const bool tr = ph.time.transient != 0;
+  if (has_expression(ph.source)) {  // the only named function K1 evaluates per point (coefficients are constants here)
+    if (tr) go(thermal_affine_element_kernel<DIM, P, NQ1, true, true>);
+    else go(thermal_affine_element_kernel<DIM, P, NQ1, false, true>);
+  } else {
+    if (tr) go(thermal_affine_element_kernel<DIM, P, NQ1, true, false>);
+    else go(thermal_affine_element_kernel<DIM, P, NQ1, false, false>);
+  }
   MHA_HIP(hipGetLastError());
 }
 
