@@ -8,8 +8,12 @@
 //   3. residual rows by quadrature -> one f64 atomic per dof into the global vector (-res.val());
 //   4. the element Jacobian as a small GEMM  K = P * Ghat^T  with
 //        P[i][(q,a)] = sum_b D_q^{ab} dhat_b N_i(q),   Ghat[j][(q,a)] = dhat_a N_j(q)
-//      (+ the mass columns sqrt-free: m_q N_i(q) against N_j(q)), 4x4 register tiles per lane, the
-//      (q,a) dimension streamed through LDS in chunks;
+//      (+ the mass columns sqrt-free: m_q N_i(q) against N_j(q)), the (q,a) dimension streamed through LDS in chunks.
+//      Elements with more than 16 dofs (Q2 hexes, Q4 quads) run the product on the matrix cores
+//      (v_mfma_f64_16x16x4_f64, 2 x 2 output tiles per wavefront): the same FMA rate as the vector unit on gfx950, but
+//      1024 FMAs per two 8-byte LDS operands instead of 16 per four 16-byte ones -- the register-tile version of this
+//      loop was bound by LDS bandwidth (4 SIMDs x 4 KB per k step against 128 B/clk).  Smaller elements keep 4x4
+//      register tiles per lane;
 //   5. scatter of the tile entries with f64 atomics into the CRS values; the position inside the row
 //      comes from a one-byte-per-entry element-major slot map (no column search), fixed rows skipped.
 // This is res(e,i).dx(j) = sum_q [ kappa w alpha_u grad N_j . grad N_i + rho cp alpha_t N_j N_i w ], the
@@ -20,11 +24,19 @@
 // compulsory traffic); the scatter adds 8 n^2 bytes of HBM atomics per element.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_math.hpp"
 #include "launch.hpp"
 
 namespace mha {
 namespace {
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 constexpr int cpowg(int b, int e) { return e == 0 ? 1 : b * cpowg(b, e - 1); }
 
@@ -40,6 +52,16 @@ struct GK {
   static constexpr int QC = NQ < 9 ? NQ : 9;      // integration points per GEMM chunk
   static constexpr int NCH = (NQ + QC - 1) / QC;
   static constexpr int KC = QC * DIM + (TR ? QC : 0);  // GEMM depth of one chunk (+ mass columns)
+#ifndef MHA_TG_MFMA
+#define MHA_TG_MFMA 1
+#endif
+#ifndef MHA_TG_STOP
+#define MHA_TG_STOP 9  // profiling aid (profiles/tg_ablate.sh): leave the kernel after phase 1, 2, 3 or the product (4)
+#endif
+  static constexpr bool MF = MHA_TG_MFMA && N > 16;  // Jacobian product on the matrix cores (2 x 2 tiles of 16 x 16)
+  static constexpr int QM = 8;                    // points per MFMA chunk: QM * DIM rows of P, a multiple of 4
+  static constexpr int PR = QM * DIM;             // rows of the MFMA P panel
+  static constexpr int PW = 32;                   // its width (dofs, zero padded)
 #ifndef MHA_TG_EPB
 #define MHA_TG_EPB 4
 #endif
@@ -61,11 +83,11 @@ struct GK {
   static constexpr int O_F = O_MQ + (TR ? NQ : 0);    // D_q grad_ref T (unscaled by alpha_u) [NQ][DIM]
   static constexpr int O_RQ = O_F + NQ * DIM;     // (rho cp T_t - f) w det [NQ]
   static constexpr int O_PT = (O_RQ + NQ + 1) / 2 * 2;  // P chunk, transposed [KC][NP] (16-byte aligned)
-  static constexpr int REC = (O_PT + KC * NP + 1) / 2 * 2;
+  static constexpr int REC = (O_PT + (MF ? PR * PW : KC * NP) + 1) / 2 * 2;
 };
 
 template <int DIM, int P, int NQ1, bool TR, bool EXPR>
-__global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
+__global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT), 2) void thermal_general_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
                                                                        const uint8_t *__restrict__ slot8,
                                                                        const uint16_t *__restrict__ slot16, ElemOut out) {
   using S = GK<DIM, P, NQ1, TR>;
@@ -76,9 +98,6 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
   double *sh = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *E = smem + S::SHARED + wave * S::REC;
-  const int el = blockIdx.x * S::EPB + wave;
-  const int e = b.e_begin + el;
-  const bool active = el < b.e_count;
   const TimeDev &tm = ph.time;
   __shared__ double tab[2 * M * NQ1];  // 1-D tables for the sum-factorised field evaluation
   __shared__ int s_offs[N];
@@ -97,11 +116,17 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
   for (int i = tid; i < NQ; i += S::NT) sh[S::S_W + i] = b.ref_wts[i];
   for (int i = tid; i < M * NQ1; i += S::NT) { tab[i] = af.phi1d[i]; tab[M * NQ1 + i] = af.dphi1d[i]; }
   for (int i = tid; i < N; i += S::NT) s_offs[i] = b.offsets[i];
-  if (active)
-    for (int i = lane; i < NN * DIM; i += 64) E[S::O_XN + i] = b.nodes[(size_t)e * NN * DIM + i];
   __syncthreads();
   const double *phi = tab, *dphi = tab + M * NQ1;
-  const int32_t *L = b.lids + (size_t)(active ? e : 0) * N;
+  // persistent over elements: the shared tables are loaded once per workgroup (they were 0.7 ms of the 2.6 ms of the
+  // one-shot version at 64^3 Q2 hexes); everything below is private to the wavefront, so no block barriers
+  for (int el = blockIdx.x * S::EPB + wave; el < b.e_count; el += gridDim.x * S::EPB) {
+  const int e = b.e_begin + el;
+  constexpr bool active = true;
+  wave_lds_sync();  // previous element consumed
+  for (int i = lane; i < NN * DIM; i += 64) E[S::O_XN + i] = b.nodes[(size_t)e * NN * DIM + i];
+  wave_lds_sync();
+  const int32_t *L = b.lids + (size_t)e * N;
 
   // ---- 1. gather + seeding values (lane = basis dof), geometry + coefficients (lane = q) ----
   if (active) {
@@ -158,7 +183,8 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
       E[S::O_F + q * DIM] = rc * w;  // parked until the fields are known
     }
   }
-  __syncthreads();
+  wave_lds_sync();  // the record is private to this wavefront
+  if (MHA_TG_STOP == 1) continue;
 
   // ---- 2. fields at the integration points, point-wise residual data (lane = q) ----
   if (active) {
@@ -186,7 +212,8 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
       E[S::O_RQ + q] += rcw * tt;
     }
   }
-  __syncthreads();
+  wave_lds_sync();
+  if (MHA_TG_STOP == 2) continue;
 
   // ---- 3. residual rows (lane = basis dof) ----
   if (active) {
@@ -208,8 +235,113 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
       }
     }
   }
-  if (out.compute_jacobian <= 0) return;  // uniform
+  if (out.compute_jacobian <= 0 || MHA_TG_STOP == 3) continue;  // uniform
 
+  const double au = tm.alpha_u, at = tm.alpha_t;
+  if constexpr (S::MF) {
+    // ---- 4m. element Jacobian on the matrix cores.  K[i][j] = sum_k Pt[k][i] * Bt[k][j], k = (q,a) then (mass) q;
+    //   Bt is the shared table Ghat^T followed by Nhat^T (contiguous), Pt is built in chunks of QM points per wave.
+    //   Operand maps (CDNA4): A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15], D reg t: row = (lane>>4) + 4t.
+    //   Rows / columns N..31 of the tiles are padding: they read finite table data and are never stored.
+    static_assert(N <= 32 && S::PR % 4 == 0, "2 x 2 tiles of 16");
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    constexpr int PW = S::PW, QM = S::QM;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][c] = v4d{0.0, 0.0, 0.0, 0.0};
+    double *Pt = E + S::O_PT;
+    if (active) {
+      auto product = [&](int krow0, int nrows) {  // nrows (multiple of 4) panel rows against table rows krow0..
+        const double *Bt = sh + S::S_GT + (size_t)krow0 * NP;
+        for (int k0 = 0; k0 < nrows; k0 += 4) {
+          const double a0 = Pt[(k0 + l4) * PW + l15], a1 = Pt[(k0 + l4) * PW + 16 + l15];
+          const double b0 = Bt[(k0 + l4) * NP + l15], b1 = Bt[(k0 + l4) * NP + 16 + l15];
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+      };
+      for (int q0 = 0; q0 < NQ; q0 += QM) {
+        wave_lds_sync();  // previous panel consumed (the record is private to this wavefront)
+        // Pt[(qq*DIM + a)][i] = alpha_u * sum_b D_q^{ab} dhat_b N_i(q); rows of points past NQ are zero
+        for (int item = lane; item < QM * PW; item += 64) {
+          const int qq = item / PW, i = item - qq * PW;
+          const int q = q0 + qq;
+          const bool ok = q < NQ && i < NP;
+          double D[DIM][DIM];
+          {
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < DIM; ++a)
+#pragma unroll
+              for (int c = a; c < DIM; ++c) { D[a][c] = ok ? E[S::O_D + q * NSYM + k] : 0.0; D[c][a] = D[a][c]; ++k; }
+          }
+          double gi[DIM];
+#pragma unroll
+          for (int c = 0; c < DIM; ++c) gi[c] = ok ? sh[S::S_GT + (q * DIM + c) * NP + i] : 0.0;
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) sacc += D[a][c] * gi[c];
+            Pt[(qq * DIM + a) * PW + i] = au * sacc;
+          }
+        }
+        wave_lds_sync();
+        const int nq = (q0 + QM <= NQ) ? QM : NQ - q0;
+        product(q0 * DIM, (nq * DIM + 3) & ~3);
+      }
+      if constexpr (TR) {
+        for (int q0 = 0; q0 < NQ; q0 += S::PR) {  // mass rows: Pt[r][i] = alpha_t m_q N_i(q)
+          wave_lds_sync();
+          for (int item = lane; item < S::PR * PW; item += 64) {
+            const int r = item / PW, i = item - r * PW;
+            const int q = q0 + r;
+            Pt[r * PW + i] = (q < NQ && i < NP) ? at * E[S::O_MQ + q] * sh[S::S_NT + q * NP + i] : 0.0;
+          }
+          wave_lds_sync();
+          const int nq = (q0 + S::PR <= NQ) ? S::PR : NQ - q0;
+          product(NQ * DIM + q0, (nq + 3) & ~3);
+        }
+      }
+      if (MHA_TG_STOP == 4) {  // keep the product alive without the stores
+        if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.678) out.local_J[0] = 1.0;
+        continue;
+      }
+      // ---- 5m. store / scatter the tiles: 16 consecutive columns per row and register ----
+#pragma unroll
+      for (int ti2 = 0; ti2 < 2; ++ti2)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = 16 * ti2 + l4 + 4 * t;
+          if (i >= N) continue;
+          const int si = s_offs[i];
+          const int row = L[si];
+          const bool fx = b.fixed && b.fixed[row];
+          const int rbase = out.crs_vals ? b.rowptr[row] : 0;
+#pragma unroll
+          for (int tj2 = 0; tj2 < 2; ++tj2) {
+            const int j = 16 * tj2 + l15;
+            if (j >= N) continue;
+            const int sj = s_offs[j];
+            const double v = acc[ti2][tj2][t];
+            if (out.local_J) {
+              double *lj = out.local_J + ((size_t)(e - out.local_base) * N + si) * N + sj;
+              *lj = out.local_store ? v : *lj + v;
+            }
+            if (out.crs_vals && !fx) {
+              const size_t sidx = ((size_t)e * N + si) * N + sj;
+              const int sl = slot8 ? (int)slot8[sidx] : (int)slot16[sidx];
+              atomicAdd(out.crs_vals + rbase + sl, v);
+            }
+          }
+        }
+    }
+  } else {
   // ---- 4. element Jacobian: K = P * Ghat^T (+ mass), 4x4 tiles per lane, chunks of QC points ----
   const int ti = lane / TI, tj = lane - ti * TI;
   const bool tile = lane < TI * TI;
@@ -218,10 +350,9 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
-  const double au = tm.alpha_u, at = tm.alpha_t;
   for (int ch = 0; ch < NCH; ++ch) {
     const int q0 = ch * QC;
-    __syncthreads();  // previous chunk consumed
+    wave_lds_sync();  // previous chunk consumed
     if (active) {
       // P chunk, transposed: Pt[(qq*DIM + a)][i] = alpha_u * sum_b D_q^{ab} dhat_b N_i(q); mass: alpha_t m_q N_i(q)
       for (int item = lane; item < QC * NP; item += 64) {
@@ -249,7 +380,7 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
         if constexpr (TR) E[S::O_PT + (QC * DIM + qq) * NP + i] = ok ? at * E[S::O_MQ + q] * sh[S::S_NT + q * NP + i] : 0.0;
       }
     }
-    __syncthreads();
+    wave_lds_sync();
     if (active && tile) {
       const int nq = (q0 + QC <= NQ) ? QC : NQ - q0;
       const double *A = E + S::O_PT + 4 * ti;
@@ -306,6 +437,8 @@ __global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT)) void thermal_general_ele
       }
     }
   }
+  }
+  }  // elements
 }
 
 template <typename SlotT>
@@ -334,7 +467,15 @@ void launch_one(const BlockDev &b, const ThermalDev &ph, const AffineDev &af, co
   using S1 = GK<DIM, P, NQ1, true>;
   const size_t lds = sizeof(double) * (tr ? S1::SHARED + (size_t)S1::EPB * S1::REC : S0::SHARED + (size_t)S0::EPB * S0::REC);
   MHA_REQUIRE(lds <= 150 * 1024, MHA_ERR_INVALID, "general element kernel needs " << lds << " B of LDS");
-  const int grid = (b.e_count + S0::EPB - 1) / S0::EPB;
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    MHA_HIP(hipGetDevice(&dev));
+    MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  // persistent workgroups: as many as are resident at once (LDS-limited), each wave strides over the elements
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
+  const int grid = std::max(1, std::min((b.e_count + S0::EPB - 1) / S0::EPB, num_cu * per_cu));
   const uint8_t *s8 = slot_bytes == 1 ? static_cast<const uint8_t *>(slot) : nullptr;
   const uint16_t *s16 = slot_bytes == 2 ? static_cast<const uint16_t *>(slot) : nullptr;
   auto go = [&](auto kern) {
