@@ -241,6 +241,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   d_colind_.upload(h_colind_);
   has_graph_ = true;
   ro_ = RowOwnerData();
+  rpat_ = RowPatternData();
   has_elem_slot_ = false;
   has_incidence_ = false;
 }
@@ -941,6 +942,62 @@ void AssemblyManager::prepareRowOwner() {
   ro.gp.upload(ref_.gauss_pts);
   MHA_HIP(hipStreamSynchronize(stream_));
   ro.ready = true;
+  prepareRowPattern();
+}
+
+// Matrix-core form of K2: group the rows by assembly pattern (row_pattern.hpp).  Requested with MHA_K2=pattern; a mesh
+// whose rows share too few patterns keeps the row-block kernel (info key "row_patterns" = 0).
+void AssemblyManager::prepareRowPattern() {
+  RowPatternData &rp = rpat_;
+  rp.tried = true;
+  rp.usable = false;
+  // opt-in for now: on config 2 the pattern kernel is at 0.51 ms against 0.47 ms of the row-block kernel
+  // (profiles/README.md, "Pattern GEMM form of K2")
+  const char *mode = std::getenv("MHA_K2");
+  if (!mode || std::string(mode) != "pattern") { rp.why = "not requested (MHA_K2=pattern)"; return; }
+  if (ro_.num_general_blocks > 0) { rp.why = "block has non-affine elements"; return; }
+  std::vector<int32_t> ptr, elem, lpos;
+  build_row_incidence(nrows_, nelem_, n_, h_lids_.data(), ptr, elem, lpos);
+  prepareElemSlots();
+  std::vector<uint8_t> slot(static_cast<size_t>(nelem_) * n_ * n_ * elem_slot_bytes_);
+  MHA_HIP(hipStreamSynchronize(stream_));
+  d_elem_slot_.download(slot.data());
+  const int nsym = dim_ * (dim_ + 1) / 2;
+  std::vector<double> khat(static_cast<size_t>(nsym + 1) * n_ * n_);
+  ro_.khat.download(khat.data());
+  int dev = 0, num_cu = 0;
+  MHA_HIP(hipGetDevice(&dev));
+  MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  int wgs_per_cu = 2;
+  if (const char *m = std::getenv("MHA_RP_WGS")) wgs_per_cu = std::max(1, std::atoi(m));
+  int chunk = 2;  // 0: contiguous cost-balanced ranges; > 0: chunks of that many super tiles dealt round-robin
+  if (const char *m = std::getenv("MHA_RP_CHUNK")) chunk = std::max(0, std::atoi(m));
+  const RowPatterns h = build_row_patterns(nrows_, n_, nsym, h_rowptr_.data(), has_fixed_ ? h_fixed_.data() : nullptr, ptr, elem, lpos, slot.data(),
+                                           elem_slot_bytes_, khat.data(), num_cu * wgs_per_cu, chunk, 4096,
+                                           size_t(256) << 20, 76 * 1024);
+  rp.why = h.why;
+  if (!h.usable) return;
+  rp.num_patterns = h.num_patterns;
+  rp.num_super_tiles = static_cast<int>(h.st_pat.size());
+  rp.w.upload(h.w);
+  rp.st_desc.upload(h.st_desc);
+  rp.st_rec.upload(h.st_rec);
+  rp.wg_ptr.upload(h.wg_ptr);
+  rp.geok.resize(static_cast<size_t>(nelem_) * h.ke);
+  launch_build_geok(nelem_, nsym, h.ke, ro_.geo.data(), rp.geok.data(), stream_);
+  RowPatternDev &d = rp.dev;
+  d.num_wgs = static_cast<int>(h.wg_ptr.size()) - 1;
+  d.ke = h.ke;
+  d.nsym = nsym;
+  d.max_w_doubles = h.max_w_doubles;
+  if (const char *m = std::getenv("MHA_RP_DBG")) d.dbg = std::atoi(m);
+  d.w = rp.w.data();
+  d.st_desc = rp.st_desc.data();
+  d.st_rec = rp.st_rec.data();
+  d.wg_ptr = rp.wg_ptr.data();
+  d.geok = rp.geok.data();
+  MHA_HIP(hipStreamSynchronize(stream_));
+  rp.usable = true;
 }
 
 bool AssemblyManager::rowOwnerUsable(std::string *why) const {
@@ -1009,6 +1066,14 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   // context's stream and K1 on a side stream, so that K1's workgroups fill the wave slots K2 leaves free
   // (0.743 -> 0.686 ms per assembly on config 2, profiles/r1_ab_k1k2_overlap.log); MHA_K1K2_OVERLAP=0 serialises them
   static const int overlap = [] { const char *m = std::getenv("MHA_K1K2_OVERLAP"); return m ? std::atoi(m) : 1; }();
+  const double su = ph.time.alpha_u * ph.diff.amp, st = ph.time.alpha_t * ph.rho.amp * ph.cp.amp;
+  auto jacobian = [&](hipStream_t s) {  // K2: pattern GEMMs on the matrix cores when the rows group, row blocks otherwise
+    if (rpat_.usable) {
+      launch_row_pattern_jacobian(rpat_.dev, out, su, st, s);
+    } else {
+      launch_row_owner_jacobian(dim_, n_, rb, af, out, su, st, s);
+    }
+  };
   if (overlap && compute_jacobian) {
     if (!side_stream_) {
       MHA_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
@@ -1018,17 +1083,14 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
     MHA_HIP(hipEventRecord(ev_fork_, stream_));
     MHA_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
     if (overlap == 2) launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, side_stream_);
-    launch_row_owner_jacobian(dim_, n_, rb, af, out, ph.time.alpha_u * ph.diff.amp,
-                              ph.time.alpha_t * ph.rho.amp * ph.cp.amp, stream_);
+    jacobian(stream_);
     if (overlap != 2) launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, side_stream_);
     MHA_HIP(hipEventRecord(ev_join_, side_stream_));
     MHA_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     return;
   }
   launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, stream_);
-  if (compute_jacobian)
-    launch_row_owner_jacobian(dim_, n_, rb, af, out, ph.time.alpha_u * ph.diff.amp,
-                              ph.time.alpha_t * ph.rho.amp * ph.cp.amp, stream_);
+  if (compute_jacobian) jacobian(stream_);
 }
 
 int64_t AssemblyManager::info(const std::string &key) const {
@@ -1040,6 +1102,8 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "last_path") return last_path_;
   if (key == "workset_size") return wkset_.maxElem;
   if (key == "row_blocks") return ro_.ready ? ro_.rb.num_blocks : 0;
+  if (key == "row_patterns") return rpat_.usable ? rpat_.num_patterns : 0;
+  if (key == "row_pattern_tiles") return rpat_.usable ? rpat_.num_super_tiles : 0;
   if (key == "num_affine_elems") return ro_.ready ? ro_.num_affine_elems : -1;
   if (key == "row_block_max_rows") return ro_.rb.max_rows;
   if (key == "row_block_max_elems") return ro_.rb.max_elems;

@@ -13,6 +13,7 @@
 #include "physics.hpp"
 #include "ref_tables.hpp"
 #include "row_blocks.hpp"
+#include "row_pattern.hpp"
 #include "workset.hpp"
 
 namespace mha {
@@ -134,6 +135,16 @@ class AssemblyManager {
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
     bool all_rows_covered = false;
   } ro_;
+  // rows grouped by assembly pattern: the matrix-core form of K2 (row_pattern.hpp); !usable -> the row-block kernel
+  struct RowPatternData {
+    bool tried = false, usable = false;
+    std::string why;
+    int num_patterns = 0, num_super_tiles = 0;
+    RowPatternDev dev;
+    DeviceBuffer<int32_t> st_desc, st_rec, wg_ptr;
+    DeviceBuffer<double> w, geok;
+  } rpat_;
+  void prepareRowPattern();
 
   // host mirror of BoundaryGroup: entries + the side views evaluated on request
   struct BoundaryGroupData {

@@ -196,6 +196,17 @@ struct SwhElementDev {
   double *blocks = nullptr;              // [E][36][36] res(r).dx(c), stored
 };
 
+// Rows grouped by assembly pattern (row_pattern.hpp) for the matrix-core row-owner Jacobian.
+struct RowPatternDev {
+  int num_wgs = 0, ke = 0, nsym = 0, max_w_doubles = 0;
+  int dbg = 0;  // profiling aid (env MHA_RP_DBG): 1 no stores, 2 no matrix products, 4 no geometry gather
+  const double *w = nullptr;        // pattern matrices
+  const int32_t *st_desc = nullptr;  // [super tile][8] descriptors (row_pattern.hpp)
+  const int32_t *st_rec = nullptr;   // row records
+  const int32_t *wg_ptr = nullptr;
+  const double *geok = nullptr;  // [E][ke]: detJ (J^-1 J^-T)_sym, detJ, zero padding
+};
+
 // Destination of the row-owner kernels.
 struct RowOut {
   double *res = nullptr;

@@ -34,6 +34,9 @@ void launch_build_block_slots(const BlockDev &b, const RowBlocksDev &rb, void *b
 bool thermal_row_owner_supported(int dim, int order, int nq1);
 size_t row_owner_jacobian_lds(const RowBlocksDev &rb, int n, int slot_bytes);
 void launch_affine_geometry(const BlockDev &b, double *geo, hipStream_t stream);
+// row_pattern.hip: packed geometry factors [E][ke] from the geometry cache; the pattern GEMM form of the row-owner Jacobian
+void launch_build_geok(int nelem, int nsym, int ke, const double *geo, double *geok, hipStream_t stream);
+void launch_row_pattern_jacobian(const RowPatternDev &rp, const RowOut &out, double su, double st, hipStream_t stream);
 void launch_build_erec(int dim, const RowBlocksDev &rb, const double *geo, double *erec, int total,
                        hipStream_t stream);
 // K1: element-wise residual (-> res with atomics)

@@ -268,10 +268,13 @@ RO_CASES = [  # dim, order, qdeg, ncell
 
 @pytest.mark.parametrize("dim,order,qdeg,ncell", RO_CASES)
 @pytest.mark.parametrize("mode", ["accumulate", "overwrite"])
-def test_row_owner_matches_oracle(oracle, dim, order, qdeg, ncell, mode):
-    """Fused row-owner kernel on affine (sheared) meshes vs the oracle: CRS values, residual, fixed rows."""
+@pytest.mark.parametrize("k2", ["blocks", "pattern"])
+def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, mode, k2):
+    """Fused row-owner kernel on affine (sheared) meshes vs the oracle: CRS values, residual, fixed rows.
+    k2 = pattern: the Jacobian rows as pattern GEMMs on the matrix cores (MHA_K2=pattern, row_pattern.hip)."""
     torch = _torch()
     import mrhyde_amd
+    monkeypatch.setenv("MHA_K2", k2)
     m = affine_mesh(oracle, dim, order, ncell)
     rng = np.random.default_rng(21)
     u = rng.uniform(-1, 1, m["ndof"])
@@ -292,6 +295,7 @@ def test_row_owner_matches_oracle(oracle, dim, order, qdeg, ncell, mode):
     blk.assemble_jacres(ud, res, vals, path=mrhyde_amd.PATH_ROW_OWNER, overwrite=(mode == "overwrite"))
     torch.cuda.synchronize()
     assert blk.info("num_affine_elems") == m["nelem"] and blk.info("last_path") == mrhyde_amd.PATH_ROW_OWNER
+    assert (blk.info("row_patterns") > 0) == (k2 == "pattern")
     assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
     assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
     v = vals.cpu().numpy()
@@ -312,9 +316,11 @@ def test_row_owner_matches_oracle(oracle, dim, order, qdeg, ncell, mode):
     assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
 
 
-def test_row_owner_transient_and_source_array(oracle):
+@pytest.mark.parametrize("k2", ["blocks", "pattern"])
+def test_row_owner_transient_and_source_array(oracle, monkeypatch, k2):
     torch = _torch()
     import mrhyde_amd
+    monkeypatch.setenv("MHA_K2", k2)
     dim, order, qdeg, ncell = 3, 2, 4, (3, 4, 3)
     m = affine_mesh(oracle, dim, order, ncell)
     rng = np.random.default_rng(23)
