@@ -936,6 +936,34 @@ void AssemblyManager::prepareRowOwner() {
       khat[static_cast<size_t>(nsym) * n_ * n_ + idx] = m;
     }
   ro.khat.upload(khat);
+  {
+    // operand tables of the matrix-core K1 (kernels/thermal_row_owner.hip): one double per lane and MFMA.
+    //   t1[(c, h)][s][lane]: A[row = point 16h + l15][k = dof 4s + l4], c < dim: d N_j / d xi_c, c = dim: N_j
+    //   t2[it][(c2, h, t)][lane]: A[row = dof 16 it + l15][k = point 16h + 4t + l4], c2 = 0: N_i, c2 = 1 + a: d N_i / d xi_a
+    const int H = (nq_ + 15) / 16, KJ = (n_ + 3) / 4, IT = (n_ + 15) / 16, K2S = (dim_ + 1) * H * 4;
+    std::vector<double> t1(static_cast<size_t>(dim_ + 1) * H * KJ * 64, 0.0), t2(static_cast<size_t>(IT) * K2S * 64, 0.0);
+    for (int c = 0; c <= dim_; ++c)
+      for (int h = 0; h < H; ++h)
+        for (int s = 0; s < KJ; ++s)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int q = 16 * h + (lane & 15), j = 4 * s + (lane >> 4);
+            if (q >= nq_ || j >= n_) continue;
+            t1[((static_cast<size_t>(c) * H + h) * KJ + s) * 64 + lane] =
+                c < dim_ ? ref_.grad[(static_cast<size_t>(j) * nq_ + q) * dim_ + c] : ref_.basis[j * nq_ + q];
+          }
+    for (int it = 0; it < IT; ++it)
+      for (int c2 = 0; c2 <= dim_; ++c2)
+        for (int h = 0; h < H; ++h)
+          for (int t = 0; t < 4; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int i = 16 * it + (lane & 15), q = 16 * h + 4 * t + (lane >> 4);
+              if (q >= nq_ || i >= n_) continue;
+              t2[(static_cast<size_t>(it) * K2S + (c2 * H + h) * 4 + t) * 64 + lane] =
+                  c2 == 0 ? ref_.basis[i * nq_ + q] : ref_.grad[(static_cast<size_t>(i) * nq_ + q) * dim_ + c2 - 1];
+            }
+    ro.k1_t1.upload(t1);
+    ro.k1_t2.upload(t2);
+  }
   ro.phi.upload(ref_.phi1d);
   ro.dphi.upload(ref_.dphi1d);
   ro.gw.upload(ref_.gauss_wts);
@@ -1052,6 +1080,9 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   af.erec = ro_.erec.data();
   af.pair_off16 = ro_.pair_off16.data();
   af.slot_pair = ro_.slot_pair.data();
+  af.k1_t1 = ro_.k1_t1.data();
+  af.k1_t2 = ro_.k1_t2.data();
+  if (const char *m = std::getenv("MHA_K1_DBG")) af.k1_dbg = std::atoi(m);
   RowOut out;
   out.res = res;
   out.vals = crs_vals;

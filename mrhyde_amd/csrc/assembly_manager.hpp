@@ -130,7 +130,7 @@ class AssemblyManager {
     DeviceBuffer<int> slot_pair;  // LID slots paired by co-ownership (K2 lane layout)
     DeviceBuffer<uint32_t> pairs;
     DeviceBuffer<uint8_t> slot, flags;
-    DeviceBuffer<double> khat, phi, dphi, gw, gp;
+    DeviceBuffer<double> khat, phi, dphi, gw, gp, k1_t1, k1_t2;
     int slot_bytes = 1;
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
     bool all_rows_covered = false;

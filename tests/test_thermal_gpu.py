@@ -271,10 +271,12 @@ RO_CASES = [  # dim, order, qdeg, ncell
 @pytest.mark.parametrize("k2", ["blocks", "pattern"])
 def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, mode, k2):
     """Fused row-owner kernel on affine (sheared) meshes vs the oracle: CRS values, residual, fixed rows.
-    k2 = pattern: the Jacobian rows as pattern GEMMs on the matrix cores (MHA_K2=pattern, row_pattern.hip)."""
+    k2 = pattern: the Jacobian rows as pattern GEMMs on the matrix cores (MHA_K2=pattern, row_pattern.hip) and the
+    element residual kernel in its matrix-core form (MHA_K1=mfma)."""
     torch = _torch()
     import mrhyde_amd
     monkeypatch.setenv("MHA_K2", k2)
+    monkeypatch.setenv("MHA_K1", "mfma" if k2 == "pattern" else "lanes")
     m = affine_mesh(oracle, dim, order, ncell)
     rng = np.random.default_rng(21)
     u = rng.uniform(-1, 1, m["ndof"])
@@ -321,6 +323,7 @@ def test_row_owner_transient_and_source_array(oracle, monkeypatch, k2):
     torch = _torch()
     import mrhyde_amd
     monkeypatch.setenv("MHA_K2", k2)
+    monkeypatch.setenv("MHA_K1", "mfma" if k2 == "pattern" else "lanes")
     dim, order, qdeg, ncell = 3, 2, 4, (3, 4, 3)
     m = affine_mesh(oracle, dim, order, ncell)
     rng = np.random.default_rng(23)
