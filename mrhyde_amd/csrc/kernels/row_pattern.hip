@@ -17,6 +17,7 @@
 
 #include "device_math.hpp"
 #include "launch.hpp"
+#include "../row_pattern.hpp"
 
 namespace mha {
 namespace {
@@ -32,10 +33,13 @@ __global__ __launch_bounds__(256) void build_geok_kernel(int nelem, int nsym, in
 
 constexpr int kMaxKSteps = 16;  // GEMM depth held in registers: 64 = 8 hexes x 8 or 16 quads x 4 (host: kMaxDepth)
 constexpr int kMaxColTiles = 9;  // 144 columns: a Q2-hex vertex row (125) at any alignment (host checks)
-constexpr int kRpThreads = 512;
+constexpr int kRpThreads = kRowsPerSuperTile * 4;  // one wavefront per 16 rows of the super tile
+#ifndef MHA_RP_ORDER
+#define MHA_RP_ORDER 0  // 0: stores interleaved with the products; 1: products, next gather, wait, stores (spills: 2.4x slower)
+#endif
 #ifndef MHA_RP_MINW
 #define MHA_RP_MINW 4  // waves per SIMD the register budget is cut for: 4 = two workgroups of 8 waves per CU
-#endif  // 8 wavefronts x 16 rows = one super tile (host: kRowsPerSuperTile)
+#endif
 
 template <int KE>
 __global__ __launch_bounds__(kRpThreads, MHA_RP_MINW) void row_pattern_jacobian_kernel(RowPatternDev rp, RowOut out, double su,
@@ -211,13 +215,32 @@ __global__ __launch_bounds__(kRpThreads, MHA_RP_MINW) void row_pattern_jacobian_
       for (int ct = 0; ct < kMaxColTiles; ++ct)
         if (ct < nct) store_tile(ct, acc[ct]);
     } else {
+#if MHA_RP_ORDER == 1
+      // products of every column tile -> gather of the next tile into the (now dead) operand registers -> wait for it
+      // -> stores.  gfx950 counts loads and stores in one in-order vmcnt: with the stores last, the only thing a wave
+      // ever waits for is loads, and its stores drain under the next tile's products.
+      v4d acc[kMaxColTiles];
+#pragma unroll
+      for (int ct = 0; ct < kMaxColTiles; ++ct)
+        if (ct < nct) acc[ct] = product(ct);
+      gather(d1, r1, A_cur);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+      for (int q = 0; q < kMaxKSteps; ++q) asm volatile("" : "+v"(A_cur[q]));
+#pragma unroll
+      for (int ct = 0; ct < kMaxColTiles; ++ct)
+        if (ct < nct) store_tile(ct, acc[ct]);
+#else
       for (int ct = 0; ct < nct; ++ct) store_tile(ct, product(ct));
+#endif
     }
     if constexpr (kPrefetchA) {
 #pragma unroll
       for (int q = 0; q < kMaxKSteps; ++q) A_cur[q] = A_nxt[q];
     } else {
+#if MHA_RP_ORDER != 1
       gather(d1, r1, A_cur);
+#endif
     }
     d0 = d1; d1 = d2; d2 = uniform(raw3);
     r0 = r1; r1 = r2;

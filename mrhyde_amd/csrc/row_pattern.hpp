@@ -46,7 +46,7 @@ struct RowPatterns {
 
 // slot: element-major map [e][si][sj] -> position of column lids[e][sj] inside CRS row lids[e][si] (slot_bytes 1 or 2);
 // khat: [nsym + 1][n*n] reference matrices in LID-slot space (last = mass).
-constexpr int kRowsPerSuperTile = 128;
+constexpr int kRowsPerSuperTile = 128;  // 8 wavefronts x 16 rows per workgroup pass
 
 RowPatterns build_row_patterns(int nrows, int n, int nsym, const int32_t *rowptr, const uint8_t *fixed,
                                const std::vector<int32_t> &inc_ptr, const std::vector<int32_t> &inc_elem,
