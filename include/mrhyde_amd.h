@@ -323,7 +323,9 @@ void mha_row_partition_destroy(mha_row_partition *p);
 /* ---- introspection for bench / tests ---------------------------------------------
  * keys: "num_elems","num_rows","nnz","dofs_per_elem","num_ip","workset_size","last_path",
  *       "row_blocks","num_affine_elems","row_block_max_rows","row_block_max_elems",
- *       "row_block_max_acc","row_owner_lds_bytes"                                      */
+ *       "row_block_max_acc","row_owner_lds_bytes","row_patterns","row_pattern_tiles"
+ * (the last two are 0 unless the pattern form of the row-owner Jacobian was requested with MHA_K2=pattern
+ * and the mesh's rows group into few enough patterns)                                   */
 int mha_get_info(mha_context *ctx, const char *key, int64_t *value);
 /* average device time (ms) of the last assembly's kernels, measured with HIP events on the
  * context's stream; valid after mha_set_timing(ctx,1).                                  */
