@@ -10,7 +10,12 @@
 // discretizationInterface.cpp:1019,1053; s_i the orientation sign), phihat_{2c+h} = (1 -/+ x_c)/2 e_c.
 // Output: dense local_J / local_res in LID-position order (updateJac / updateRes convention), from which
 // kernels/row_gather.hip builds the CRS rows.  Same gather / seeding conventions as the point engine.
+// A thread's 24 vertex coordinates and 56 results are contiguous per ELEMENT, i.e. 192 / 392 bytes apart between
+// lanes: read and written directly, every memory instruction touched 64 cache lines.  The workgroup's 128 elements are
+// therefore staged through LDS and move to and from memory as flat, fully coalesced arrays.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -18,13 +23,22 @@
 namespace mha {
 namespace {
 
+constexpr int kPorousThreads = 128;
+
 template <int DIM, bool EXPR>
-__global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm,
+__global__ __launch_bounds__(kPorousThreads) void porous_element_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm,
                                                              ElemOut out) {
   constexpr int NN = 1 << DIM, NU = 2 * DIM, N = 1 + NU;
-  const int el = blockIdx.x * blockDim.x + threadIdx.x;
-  if (el >= b.e_count) return;
-  const int e = b.e_begin + el, NQ = vl.nq;
+  extern __shared__ double sm[];  // in: [128][NN*DIM] vertices; out: [128][N*N] element matrices + [128][N] residuals
+  const int tid = threadIdx.x, e0 = blockIdx.x * kPorousThreads;
+  const int cnt = min(kPorousThreads, b.e_count - e0);
+  {
+    const double *src = b.nodes + (size_t)(b.e_begin + e0) * NN * DIM;
+    for (int i = tid; i < cnt * NN * DIM; i += kPorousThreads) sm[i] = src[i];
+  }
+  __syncthreads();
+  const bool active = tid < cnt;
+  const int e = b.e_begin + e0 + (active ? tid : 0), NQ = vl.nq;
   const int32_t *L = b.lids + (size_t)e * N;
   // gather + seeding values; positions: p at offsets[0], u_i at offsets[1 + i]
   int pos[N];
@@ -48,7 +62,8 @@ __global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayo
 #pragma unroll
   for (int k = 0; k < NN; ++k)
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) xn[k][d] = b.nodes[((size_t)e * NN + k) * DIM + d];
+    for (int d = 0; d < DIM; ++d) xn[k][d] = sm[((active ? tid : 0) * NN + k) * DIM + d];
+  __syncthreads();  // vertices are in registers: the buffer is reused for the results
   double A[NU][NU], Bv[NU], rp = 0.0, ru[NU];
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
@@ -81,6 +96,7 @@ __global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayo
     for (int c = 0; c < DIM; ++c) xi[c] = 2.0 * Tu[c * vl.cardpad[1] + 2 * c + 1] - 1.0;
     const double w = b.ref_wts[q] * det, rdet = 1.0 / det;
     const double src = eval_func<DIM, EXPR>(pp.f[0], e, q, NQ, x), mob = eval_func<DIM, EXPR>(pp.f[4], e, q, NQ, x);
+    const double rmob = 1.0 / mob;  // one division per point instead of fifteen
     double kinv[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) kinv[d] = eval_func<DIM, EXPR>(pp.f[1 + d], e, q, NQ, x);
@@ -107,7 +123,7 @@ __global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayo
         double s = 0.0;
 #pragma unroll
         for (int d = 0; d < DIM; ++d) s += J[d * DIM + c] * kinv[d] * J[d * DIM + c2];
-        M[c][c2] = s / mob;
+        M[c][c2] = s * rmob;
       }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
@@ -115,34 +131,37 @@ __global__ __launch_bounds__(128) void porous_element_kernel(BlockDev b, VarLayo
       double kuv = 0.0;
 #pragma unroll
       for (int d = 0; d < DIM; ++d) kuv += kinv[d] * uq[d] * J[d * DIM + c];
-      ru[i] += (kuv * ph[i] / mob - u[0] * dv[i]) * w;
+      ru[i] += (kuv * ph[i] * rmob - u[0] * dv[i]) * w;
       Bv[i] -= dv[i] * w;
 #pragma unroll
       for (int j = 0; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1] * w;
     }
   }
-  // dense output, LID-position order
+  // dense output, LID-position order: into LDS per thread, then flat and coalesced to memory
   const double au = tm.alpha_u;
-  if (out.local_res) {
-    double *lr = out.local_res + (size_t)(e - out.local_base) * N;
-    lr[pos[0]] = out.local_store ? -rp : lr[pos[0]] - rp;
+  double *sJ = sm + (size_t)tid * N * N, *sR = sm + (size_t)kPorousThreads * N * N + (size_t)tid * N;
+  if (active) {
+    sR[pos[0]] = -rp;
 #pragma unroll
-    for (int i = 0; i < NU; ++i) lr[pos[1 + i]] = out.local_store ? -ru[i] : lr[pos[1 + i]] - ru[i];
-  }
-  if (out.local_J && out.compute_jacobian) {
-    double *lj = out.local_J + (size_t)(e - out.local_base) * N * N;
-    auto put = [&](int pi, int pj, double v) {
-      double *d = lj + pi * N + pj;
-      *d = out.local_store ? v : *d + v;
-    };
-    put(pos[0], pos[0], 0.0);
+    for (int i = 0; i < NU; ++i) sR[pos[1 + i]] = -ru[i];
+    sJ[pos[0] * N + pos[0]] = 0.0;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      put(pos[0], pos[1 + i], au * Bv[i]);
-      put(pos[1 + i], pos[0], au * Bv[i]);
+      sJ[pos[0] * N + pos[1 + i]] = au * Bv[i];
+      sJ[pos[1 + i] * N + pos[0]] = au * Bv[i];
 #pragma unroll
-      for (int j = 0; j < NU; ++j) put(pos[1 + i], pos[1 + j], au * A[i][j]);
+      for (int j = 0; j < NU; ++j) sJ[pos[1 + i] * N + pos[1 + j]] = au * A[i][j];
     }
+  }
+  __syncthreads();
+  if (out.local_res) {
+    double *lr = out.local_res + (size_t)(b.e_begin + e0 - out.local_base) * N;
+    const double *srcr = sm + (size_t)kPorousThreads * N * N;
+    for (int i = tid; i < cnt * N; i += kPorousThreads) lr[i] = out.local_store ? srcr[i] : lr[i] + srcr[i];
+  }
+  if (out.local_J && out.compute_jacobian) {
+    double *lj = out.local_J + (size_t)(b.e_begin + e0 - out.local_base) * N * N;
+    for (int i = tid; i < cnt * N * N; i += kPorousThreads) lj[i] = out.local_store ? sm[i] : lj[i] + sm[i];
   }
 }
 
@@ -153,8 +172,10 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
   if (b.e_count <= 0) return;
   MHA_REQUIRE(out.res == nullptr && out.crs_vals == nullptr, MHA_ERR_INVALID,
               "porous element kernel writes dense element arrays only");
-  const int grid = (b.e_count + 127) / 128;
-  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(128), 0, stream, b, vl, pp, tm, out); };
+  const int grid = (b.e_count + kPorousThreads - 1) / kPorousThreads;
+  const int n = 1 + 2 * b.dim;
+  const size_t lds = sizeof(double) * kPorousThreads * std::max<size_t>((size_t)(1 << b.dim) * b.dim, (size_t)n * n + n);
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kPorousThreads), lds, stream, b, vl, pp, tm, out); };
   if (has_expression(pp)) { if (b.dim == 2) go(porous_element_kernel<2, true>); else go(porous_element_kernel<3, true>); }
   else { if (b.dim == 2) go(porous_element_kernel<2, false>); else go(porous_element_kernel<3, false>); }
   MHA_HIP(hipGetLastError());
