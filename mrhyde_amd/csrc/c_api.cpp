@@ -1,4 +1,5 @@
 // c_api.cpp -- extern "C" boundary (include/mrhyde_amd.h) over the C++ host layer.
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -6,6 +7,7 @@
 #include "expression.hpp"
 #include "mesh.hpp"
 #include "row_blocks.hpp"
+#include "row_pattern.hpp"
 
 struct mha_row_partition {
   mha::RowBlocks rb;
@@ -308,6 +310,66 @@ int mha_row_partition_build(int dim, int num_elems, int n, int num_rows, const d
       throw;
     }
     *out = p;
+  });
+}
+
+int mha_row_patterns_host_apply(int num_rows, int num_elems, int n, int nsym, const int32_t *lids,
+                                const int32_t *rowptr, const int32_t *colind, const uint8_t *fixed,
+                                const double *khat, const double *factors, double *vals, int *num_patterns,
+                                int *num_super_tiles) {
+  return guarded([&] {
+    MHA_REQUIRE(lids && rowptr && colind && khat && factors && vals && num_patterns && num_super_tiles, MHA_ERR_INVALID,
+                "null argument");
+    MHA_REQUIRE(num_rows > 0 && num_elems > 0 && n > 0 && n <= 255 && nsym > 0, MHA_ERR_INVALID, "bad sizes");
+    std::vector<int32_t> ptr, elem, lpos;
+    mha::build_row_incidence(num_rows, num_elems, n, lids, ptr, elem, lpos);
+    // element-major slot map by column search (the device builds the same map in build_elem_slot_map_kernel)
+    int max_row = 0;
+    for (int r = 0; r < num_rows; ++r) max_row = std::max(max_row, rowptr[r + 1] - rowptr[r]);
+    const int sb = max_row <= 256 ? 1 : 2;
+    std::vector<uint8_t> slot(static_cast<size_t>(num_elems) * n * n * sb);
+    for (int e = 0; e < num_elems; ++e)
+      for (int si = 0; si < n; ++si) {
+        const int row = lids[static_cast<size_t>(e) * n + si];
+        const int32_t *lo = colind + rowptr[row], *hi = colind + rowptr[row + 1];
+        for (int sj = 0; sj < n; ++sj) {
+          const int32_t *it = std::lower_bound(lo, hi, lids[static_cast<size_t>(e) * n + sj]);
+          MHA_REQUIRE(it != hi && *it == lids[static_cast<size_t>(e) * n + sj], MHA_ERR_INVALID, "graph misses an element coupling");
+          const size_t idx = (static_cast<size_t>(e) * n + si) * n + sj;
+          if (sb == 1) slot[idx] = static_cast<uint8_t>(it - lo);
+          else reinterpret_cast<uint16_t *>(slot.data())[idx] = static_cast<uint16_t>(it - lo);
+        }
+      }
+    const mha::RowPatterns rp = mha::build_row_patterns(num_rows, n, nsym, rowptr, fixed, ptr, elem, lpos, slot.data(),
+                                                        sb, khat, 8, 2, 4096, size_t(256) << 20, 76 * 1024);
+    MHA_REQUIRE(rp.usable, MHA_ERR_INVALID, "rows do not group: " << rp.why);
+    *num_patterns = rp.num_patterns;
+    *num_super_tiles = static_cast<int>(rp.st_pat.size());
+    const int ke = rp.ke, nst = *num_super_tiles;
+    MHA_REQUIRE(rp.wg_ptr.back() == nst, MHA_ERR_STATE, "workgroup ranges do not cover the tiles");
+    for (size_t w = 0; w + 1 < rp.wg_ptr.size(); ++w)
+      for (int s = rp.wg_ptr[w]; s < rp.wg_ptr[w + 1]; ++s) {
+        const int32_t *d = &rp.st_desc[static_cast<size_t>(s) * 8];
+        const int ni = d[1] & 0xff, len = d[1] >> 16, gstride = d[3] >> 16;
+        const int64_t rec = (static_cast<int64_t>(d[5]) << 32) | static_cast<uint32_t>(d[4]);
+        const int64_t woff = (static_cast<int64_t>(d[7]) << 32) | static_cast<uint32_t>(d[6]);
+        for (int wv = 0; wv < mha::kRowsPerSuperTile / 16; ++wv)
+          for (int l = 0; l < 16; ++l) {
+            const int32_t *p = &rp.st_rec[static_cast<size_t>(rec) + static_cast<size_t>(wv) * (2 + ni) * 16 + l];
+            const int base = p[0], meta = p[16], rlen = meta & 0x3fffffff;
+            if (rlen == 0) continue;
+            MHA_REQUIRE(rlen == len, MHA_ERR_STATE, "row length differs from its pattern");
+            for (int c = 0; c < rlen; ++c) {
+              double v = 0.0;
+              if (!(meta >> 30))
+                for (int k = 0; k < ni; ++k)
+                  for (int cc = 0; cc < ke; ++cc)
+                    v += factors[static_cast<size_t>(p[(2 + k) * 16]) * ke + cc] *
+                         rp.w[static_cast<size_t>(woff) + static_cast<size_t>(k * ke + cc) * gstride + c];
+              vals[base + c] = v;
+            }
+          }
+      }
   });
 }
 

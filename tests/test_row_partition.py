@@ -67,3 +67,60 @@ def test_partition_rejects_impossible_caps(oracle):
     with pytest.raises(mrhyde_amd.MhaError) as ei:
         mrhyde_amd.row_partition(2, m["nodes"], m["lids"], m["ndof"], rowptr, caps=[4, 4, 8, 8])
     assert ei.value.code == 1 and "exceeds" in str(ei.value)
+
+
+# ---- pattern grouping behind MHA_K2=pattern (csrc/row_pattern.{hpp,cpp}), walked on the host as the kernel walks it ----
+
+def _pattern_reference(m, rowptr, colind, khat, factors, fixed=None):
+    """vals[row(e,si)][col(e,sj)] += sum_c factors[e][c] * khat[c][si][sj], fixed rows zero: plain element loop."""
+    n = m["lids"].shape[1]
+    vals = np.zeros(len(colind))
+    ncomp = khat.shape[0]
+    for e, L in enumerate(m["lids"]):
+        K = np.tensordot(factors[e, :ncomp], khat, axes=(0, 0)).reshape(n, n)
+        for si in range(n):
+            r = L[si]
+            if fixed is not None and fixed[r]:
+                continue
+            lo, hi = rowptr[r], rowptr[r + 1]
+            vals[lo + np.searchsorted(colind[lo:hi], L)] += K[si]
+    return vals
+
+
+@pytest.mark.parametrize("dim,order,ncell", [(3, 2, (4, 3, 3)), (3, 1, (4, 4, 3)), (2, 1, (7, 5)), (2, 2, (5, 4)),
+                                              (2, 4, (3, 3))])
+def test_row_patterns_reproduce_the_element_scatter(oracle, dim, order, ncell):
+    m = mrhyde_amd.mesh_structured(dim, order, ncell)
+    nrows = m["ndof"]
+    rowptr, colind = oracle.build_graph(nrows, m["lids"])
+    n = m["lids"].shape[1]
+    nsym = dim * (dim + 1) // 2
+    depth = (nsym + 1 + 3) // 4 * 4
+    rng = np.random.default_rng(31)
+    khat = rng.uniform(-1, 1, (nsym + 1, n * n))      # any tables: the grouping does not look at their values
+    factors = np.zeros((m["nelem"], depth))
+    factors[:, :nsym + 1] = rng.uniform(0.5, 2.0, (m["nelem"], nsym + 1))
+    fixed = (rng.uniform(size=nrows) < 0.1).astype(np.uint8)
+    vals, npat, nst = mrhyde_amd.row_patterns_host_apply(m["lids"], nrows, rowptr, colind, khat, factors, fixed)
+    ref = _pattern_reference(m, rowptr, colind, khat, factors, fixed)
+    assert not np.any(np.isnan(vals)), "every CRS entry written exactly once"
+    assert np.max(np.abs(vals - ref)) <= 1e-12 * np.max(np.abs(ref))
+    # a tensor mesh has few patterns: per direction a dof is a vertex (left end, interior, right end) or lies inside
+    # one cell (order - 1 positions, each possibly in the first / an interior / the last cell)
+    assert 0 < npat <= (3 + 3 * (order - 1)) ** dim
+    assert nst >= npat
+
+
+def test_row_patterns_reject_unstructured_numbering(oracle):
+    """A random renumbering of the dofs gives (nearly) every row its own slot pattern: the grouping must refuse
+    (the caller then keeps the row-block kernel) rather than build one matrix per row."""
+    m = mrhyde_amd.mesh_structured(3, 2, (8, 8, 8))  # 4913 rows > the 4096 patterns the grouping accepts
+    rng = np.random.default_rng(32)
+    perm = rng.permutation(m["ndof"]).astype(np.int32)
+    lids = perm[m["lids"]]
+    rowptr, colind = oracle.build_graph(m["ndof"], lids)
+    n = lids.shape[1]
+    khat = rng.uniform(-1, 1, (7, n * n))
+    factors = rng.uniform(0.5, 2.0, (lids.shape[0], 8))
+    with pytest.raises(mrhyde_amd.MhaError, match="patterns"):
+        mrhyde_amd.row_patterns_host_apply(lids, m["ndof"], rowptr, colind, khat, factors)
