@@ -1,0 +1,181 @@
+"""Parity at BASELINE.json's full sizes, through properties that need no oracle run of that size.
+
+Config 2 (64^3 Q2 hexes, 2.1e6 rows, 1.4e8 CRS entries), affine and perturbed meshes:
+  * the affine fast path (row-owner kernels) and the general path (element matrices + row gather) are independent
+    implementations: their CRS values and residuals must agree to 1e-12 on the same affine mesh;
+  * thermal with constant coefficients is linear: scattered residual(u1) - residual(u2) = -J (u1 - u2) on free rows,
+    which ties the Jacobian to the residual at full size (the vector receives -res.val(), the matrix +dres/du:
+    src/managers/assemblyManager.cpp:4094, 4138);
+  * pure diffusion annihilates constants: free rows of J sum to zero and a constant state with no source has zero residual;
+  * J is symmetric (x'Jy = y'Jx on random vectors supported on free rows);
+  * the CRS rows of an interior vertex dof equal the oracle's on a 4^3 mesh of the same element size (an interior
+    stencil does not know how large the mesh is): pins full-size VALUES, not only relations, to the oracle.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _rel(a, b):
+    torch = _torch()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+def _spmv(torch, rowptr, colind, vals, x):
+    """y = A x for a CRS matrix, with plain tensor ops (no sparse library in the loop)."""
+    nrows = len(rowptr) - 1
+    counts = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(nrows, device=x.device), counts)
+    y = torch.zeros(nrows, dtype=x.dtype, device=x.device)
+    y.index_add_(0, rows, vals * x[colind.to(torch.int64)])
+    return y
+
+
+@pytest.fixture(scope="module")
+def config2():
+    """64^3 Q2-hex thermal block on the unit cube, Dirichlet rows on the boundary, graph on the device."""
+    torch = _torch()
+    import mrhyde_amd
+    nc, order = 64, 2
+    m = mrhyde_amd.mesh_structured(3, order, (nc,) * 3)
+    blk = mrhyde_amd.Block(3, order, quadrature=2 * order, workset_size=100)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"], m["boundary"])
+    blk.set_graph()
+    rowptr, colind = blk.get_graph()
+    dev = torch.device("cuda")
+    return dict(m=m, blk=blk, nc=nc, rowptr=torch.tensor(rowptr, device=dev), colind=torch.tensor(colind, device=dev),
+                free=torch.tensor(m["boundary"] == 0, device=dev), nrows=m["ndof"], nnz=len(colind))
+
+
+def _assemble(torch, c, u, path, source=None):
+    import mrhyde_amd
+    blk = c["blk"]
+    blk.set_function("thermal source", source if source is not None else ("sinprod", 12 * np.pi ** 2, [2 * np.pi] * 3))
+    blk.set_function("thermal diffusion", 1.0)
+    res = torch.full((c["nrows"],), 3.0, dtype=torch.float64, device="cuda")
+    vals = torch.full((c["nnz"],), -2.0, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(u, res, vals, path=path, overwrite=True)
+    torch.cuda.synchronize()
+    assert blk.info("last_path") == path
+    return res, vals
+
+
+def test_config2_fast_path_equals_general_path(config2):
+    torch = _torch()
+    import mrhyde_amd
+    c = config2
+    u = torch.rand(c["nrows"], dtype=torch.float64, device="cuda", generator=torch.Generator("cuda").manual_seed(2)) * 2 - 1
+    r_fast, v_fast = _assemble(torch, c, u, mrhyde_amd.PATH_ROW_OWNER)
+    assert c["blk"].info("num_affine_elems") == c["m"]["nelem"]
+    r_gen, v_gen = _assemble(torch, c, u, mrhyde_amd.PATH_ROW_GATHER)
+    assert _rel(v_fast, v_gen) < RTOL
+    assert _rel(r_fast, r_gen) < RTOL
+    c["vals"], c["u"], c["res"] = v_fast, u, r_fast  # reused below
+
+
+def test_config2_linearity_row_sums_symmetry(config2):
+    torch = _torch()
+    import mrhyde_amd
+    c = config2
+    if "vals" not in c:
+        test_config2_fast_path_equals_general_path(c)
+    vals, u1, r1 = c["vals"], c["u"], c["res"]
+    free = c["free"]
+    g = torch.Generator("cuda").manual_seed(3)
+    u2 = torch.rand(c["nrows"], dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    r2, _ = _assemble(torch, c, u2, mrhyde_amd.PATH_ROW_OWNER)
+    Jd = _spmv(torch, c["rowptr"], c["colind"], vals, u1 - u2)
+    lhs = (r1 - r2)[free]
+    assert float((lhs + Jd[free]).abs().max() / lhs.abs().max()) < 1e-11  # 125-term sums of O(1) entries
+    # fixed rows: zero matrix rows and zero residual entries
+    assert float(Jd[~free].abs().max()) == 0.0 and float(r1[~free].abs().max()) == 0.0
+    # constants are in the kernel of the diffusion operator
+    ones = torch.ones(c["nrows"], dtype=torch.float64, device="cuda")
+    rs = _spmv(torch, c["rowptr"], c["colind"], vals, ones)
+    assert float(rs.abs().max() / vals.abs().max()) < 1e-12
+    r0, _ = _assemble(torch, c, 0.7 * ones, mrhyde_amd.PATH_ROW_OWNER, source=0.0)
+    assert float(r0.abs().max()) < 1e-12 * float(vals.abs().max())
+    # symmetry on the free rows / columns
+    x = torch.rand(c["nrows"], dtype=torch.float64, device="cuda", generator=g) * free
+    y = torch.rand(c["nrows"], dtype=torch.float64, device="cuda", generator=g) * free
+    a = float(torch.dot(x, _spmv(torch, c["rowptr"], c["colind"], vals, y)))
+    b = float(torch.dot(y, _spmv(torch, c["rowptr"], c["colind"], vals, x)))
+    assert abs(a - b) < 1e-11 * abs(a)
+
+
+def test_config2_interior_rows_equal_the_oracle_stencil(config2, oracle):
+    """Rows of dofs around the centre of the 64^3 mesh against the oracle on a 4^3 mesh with the same element size."""
+    torch = _torch()
+    import mrhyde_amd
+    c = config2
+    if "vals" not in c:
+        test_config2_fast_path_equals_general_path(c)
+    nc, order, h = c["nc"], 2, 1.0 / c["nc"]
+    small = oracle.mesh_structured(3, order, (4, 4, 4))
+    small["verts"] = small["verts"] * (4 * h)
+    small["nodes"] = np.ascontiguousarray(small["verts"][small["cell2vert"]])
+    us = np.zeros(small["ndof"])
+    ref = oracle.assemble_thermal(3, order, 2 * order, small["nodes"], small["lids"], small["offsets"], us,
+                                  source=("sinprod", 0.0, [1.0, 1.0, 1.0]), diff=1.0)
+    P, Ps = order * nc + 1, order * 4 + 1          # dofs per direction (lexicographic numbering, x fastest)
+    vals = c["vals"]
+    rowptr = c["rowptr"].cpu().numpy()
+    for off in [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)]:  # vertex, edge, face and cell-interior dofs
+        i, j, k = (order * nc // 2 + off[0], order * nc // 2 + off[1], order * nc // 2 + off[2])
+        r = (k * P + j) * P + i
+        i_s, j_s, k_s = (4 + off[0], 4 + off[1], 4 + off[2])  # centre vertex of the small mesh
+        r_s = (k_s * Ps + j_s) * Ps + i_s
+        big = vals[rowptr[r]:rowptr[r + 1]].cpu().numpy()
+        sm = ref["crs_vals"][ref["rowptr"][r_s]:ref["rowptr"][r_s + 1]]
+        assert len(big) == len(sm)
+        assert np.abs(big - sm).max() < RTOL * np.abs(sm).max()  # same stencil order: both graphs are lexicographic
+
+
+def test_config2_perturbed_general_paths_agree():
+    """Perturbed 64^3 mesh (seed 3): matrix-core element kernel + row gather against the same kernel with
+    the atomic CRS scatter, and the linearity relation."""
+    torch = _torch()
+    import mrhyde_amd
+    nc, order = 64, 2
+    m = mrhyde_amd.mesh_structured(3, order, (nc,) * 3)
+    rng = np.random.default_rng(3)
+    v = m["verts"]
+    interior = np.all((v > 1e-9) & (1 - v > 1e-9), axis=1)
+    v[interior] += 0.15 / nc * rng.uniform(-1, 1, (int(interior.sum()), 3))
+    m["nodes"] = np.ascontiguousarray(v[m["cell2vert"]])
+    blk = mrhyde_amd.Block(3, order, quadrature=2 * order, workset_size=100)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"], m["boundary"])
+    blk.set_graph()
+    rowptr, colind = blk.get_graph()
+    blk.set_function("thermal source", ("sinprod", 12 * np.pi ** 2, [2 * np.pi] * 3))
+    blk.set_function("thermal diffusion", 1.0)
+    n, nnz = m["ndof"], len(colind)
+    g = torch.Generator("cuda").manual_seed(5)
+    u1 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    u2 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    out = {}
+    for path in (mrhyde_amd.PATH_ROW_GATHER, mrhyde_amd.PATH_ELEMENT_ATOMIC):
+        res = torch.zeros(n, dtype=torch.float64, device="cuda")
+        vals = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(u1, res, vals, path=path, overwrite=(path == mrhyde_amd.PATH_ROW_GATHER))
+        torch.cuda.synchronize()
+        out[path] = (res, vals)
+    (r_g, v_g), (r_a, v_a) = out[mrhyde_amd.PATH_ROW_GATHER], out[mrhyde_amd.PATH_ELEMENT_ATOMIC]
+    assert _rel(v_a, v_g) < RTOL and _rel(r_a, r_g) < RTOL
+    res2 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(u2, res2, None, compute_jacobian=False, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    torch.cuda.synchronize()
+    dev = torch.device("cuda")
+    Jd = _spmv(torch, torch.tensor(rowptr, device=dev), torch.tensor(colind, device=dev), v_g, u1 - u2)
+    free = torch.tensor(m["boundary"] == 0, device=dev)
+    lhs = (r_g - res2)[free]
+    assert float((lhs + Jd[free]).abs().max() / lhs.abs().max()) < 1e-11
