@@ -179,3 +179,95 @@ def test_config2_perturbed_general_paths_agree():
     free = torch.tensor(m["boundary"] == 0, device=dev)
     lhs = (r_g - res2)[free]
     assert float((lhs + Jd[free]).abs().max() / lhs.abs().max()) < 1e-11
+
+
+def _warp(m):
+    v = m["verts"].copy()
+    w = v.copy()
+    w[:, 0] += 0.06 * np.sin(1.3 * v[:, 1] + 0.4) + 0.04 * v[:, 2] ** 2
+    w[:, 1] += 0.05 * np.cos(1.1 * v[:, 0]) * (1 + 0.5 * v[:, 1])
+    w[:, 2] += 0.05 * v[:, 0] * v[:, 1] + 0.03 * np.sin(2.0 * v[:, 2])
+    m["verts"] = w
+    m["nodes"] = np.ascontiguousarray(w[m["cell2vert"]])
+    return m
+
+
+def _multi_block(m, physics, qdeg, fixed=None):
+    import mrhyde_amd
+    blk = mrhyde_amd.Block(m["dim"], quadrature=qdeg, physics=physics,
+                           variables=list(zip(m["types"].tolist(), m["orders"].tolist())))
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"], fixed)
+    blk.set_orientation(m["orient"])
+    blk.set_graph()
+    return blk
+
+
+def test_config3_porous_mixed_128_cubed(oracle):
+    """porousMixed at BASELINE config 3 (128^3 hexes, p in HVOL + u in HDIV-I1, 8.4e6 rows) on a warped mesh:
+    the dedicated element kernel + row gather against the generic point engine with the atomic scatter (independent
+    implementations), the linearity relation residual(u1) - residual(u2) = -J (u1 - u2), saddle-point symmetry."""
+    torch = _torch()
+    import mrhyde_amd
+    m = _warp(oracle.mesh_multi(3, (128, 128, 128), [oracle.HVOL, oracle.HDIV], [0, 1]))
+    blk = _multi_block(m, "porousMixed", 2)
+    for k, v in {"source": ("sinprod", 2.0, [np.pi, 2 * np.pi, np.pi]), "Kinv_xx": 1.3, "Kinv_yy": 0.7, "Kinv_zz": 2.1,
+                 "total_mobility": 1.9}.items():
+        blk.set_function(k, v)
+    rowptr, colind = blk.get_graph()
+    n, nnz = m["ndof"], len(colind)
+    dev = torch.device("cuda")
+    g = torch.Generator("cuda").manual_seed(4)
+    u1 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    u2 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    r_g = torch.full((n,), 5.0, dtype=torch.float64, device="cuda")
+    v_g = torch.full((nnz,), 5.0, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(u1, r_g, v_g, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    r_e = torch.zeros(n, dtype=torch.float64, device="cuda")
+    v_e = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(u1, r_e, v_e, path=mrhyde_amd.PATH_POINT_ENGINE)
+    torch.cuda.synchronize()
+    assert _rel(v_g, v_e) < RTOL and _rel(r_g, r_e) < RTOL
+    r2 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(u2, r2, None, compute_jacobian=False, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    torch.cuda.synchronize()
+    rp, ci = torch.tensor(rowptr, device=dev), torch.tensor(colind, device=dev)
+    Jd = _spmv(torch, rp, ci, v_g, u1 - u2)
+    d = r_g - r2
+    assert float((d + Jd).abs().max() / d.abs().max()) < 1e-11
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    a, b = float(torch.dot(x, _spmv(torch, rp, ci, v_g, y))), float(torch.dot(y, _spmv(torch, rp, ci, v_g, x)))
+    assert abs(a - b) < 1e-11 * max(abs(a), float(v_g.abs().max()))
+
+
+def test_navierstokes_32_cubed_jacobian_is_the_derivative_of_the_residual(oracle):
+    """navierstokes (Q2 velocity / Q1 pressure, 89 dofs per element, the config-4 element at 32^3): the assembled
+    Jacobian against a central difference of the assembled residual along a random direction -- the module is
+    nonlinear, so this is the full-size stand-in for the Sacado derivative array.  Second-order accurate: the error
+    scales with eps^2 ~ 1e-10 relative, far above round-off at this size but far below any wrong entry."""
+    torch = _torch()
+    import mrhyde_amd
+    H = oracle.HGRAD
+    m = _warp(oracle.mesh_multi(3, (32, 32, 32), [H] * 4, [2, 1, 2, 2]))
+    blk = _multi_block(m, "navierstokes", 4)
+    for k, v in {"source ux": 0.3, "source uy": ("sinprod", 1.0, [1.0, 2.0, 0.5]), "source uz": -0.2, "viscosity": 0.05,
+                 "density": 1.3}.items():
+        blk.set_function(k, v)
+    blk.set_physics_parameter("fix_uz_offsets", 1)
+    rowptr, colind = blk.get_graph()
+    n, nnz = m["ndof"], len(colind)
+    dev = torch.device("cuda")
+    g = torch.Generator("cuda").manual_seed(5)
+    u = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    dlt = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    res = torch.zeros(n, dtype=torch.float64, device="cuda")
+    vals = torch.zeros(nnz, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(u, res, vals, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    eps = 1e-5
+    rp_, rm_ = torch.zeros_like(res), torch.zeros_like(res)
+    blk.assemble_jacres(u + eps * dlt, rp_, None, compute_jacobian=False, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    blk.assemble_jacres(u - eps * dlt, rm_, None, compute_jacobian=False, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    torch.cuda.synchronize()
+    Jd = _spmv(torch, torch.tensor(rowptr, device=dev), torch.tensor(colind, device=dev), vals, dlt)
+    fd = -(rp_ - rm_) / (2 * eps)  # the vector holds -res.val()
+    assert float((fd - Jd).abs().max() / Jd.abs().max()) < 1e-7
