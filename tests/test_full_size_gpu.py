@@ -271,3 +271,47 @@ def test_navierstokes_32_cubed_jacobian_is_the_derivative_of_the_residual(oracle
     Jd = _spmv(torch, torch.tensor(rowptr, device=dev), torch.tensor(colind, device=dev), vals, dlt)
     fd = -(rp_ - rm_) / (2 * eps)  # the vector holds -res.val()
     assert float((fd - Jd).abs().max() / Jd.abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize("roe", [1, 0])
+def test_config5_hdg_256_squared_blocks_are_the_derivative_of_the_residual(oracle, roe):
+    """shallowwaterHybridized HDG element at BASELINE config 5 (256^2 quads, Q1 interior + HFACE-1 traces, 36 unknowns
+    per element): the side blocks [E][36][36] against a central difference of the side residual [E][36] along a random
+    direction in (u, lambda), element by element -- Roe-like and max-EV stabilisation."""
+    torch = _torch()
+    import mrhyde_amd
+    H = oracle.HGRAD
+    nc = 256
+    m = oracle.mesh_multi(2, (nc, nc), [H, H, H], [1, 1, 1])
+    blk = mrhyde_amd.Block(2, quadrature=2, physics="shallowwaterHybridized", variables=[(0, 1)] * 3)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+    blk.set_graph()
+    blk.set_physics_parameter("g", 1.0)
+    blk.set_physics_parameter("Roe-like stabilization", roe)
+    blk.set_physics_parameter("max EV stabilization", 1 - roe)
+    rng = np.random.default_rng(6)
+    E, n = m["nelem"], m["ndof"]
+    # momenta 0.3 +- 0.05 in both directions: the normal velocity on the axis-aligned sides stays away from zero, where
+    # the |eigenvalue| of the stabilisation has a kink and a central difference across it means nothing
+    u = 0.3 + 0.05 * rng.uniform(-1, 1, n)
+    hd = m["dof_var"] == 0
+    u[hd] = 1.0 + 0.2 * rng.uniform(0, 1, hd.sum())          # depth stays well above zero
+    lam = 0.3 + 0.05 * rng.uniform(-1, 1, (E, 3, 4, 2))
+    lam[:, 0] = 1.0 + 0.2 * rng.uniform(0, 1, (E, 4, 2))
+    du, dl = rng.uniform(-1, 1, n), rng.uniform(-1, 1, (E, 24))
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+    res = torch.zeros((E, 36), dtype=torch.float64, device="cuda")
+    blocks = torch.zeros((E, 36, 36), dtype=torch.float64, device="cuda")
+    blk.swhdg_element_blocks(t(u), t(lam.reshape(E, 24)), res, blocks)
+    eps = 1e-6
+    rp_, rm_ = torch.zeros_like(res), torch.zeros_like(res)
+    blk.swhdg_element_blocks(t(u + eps * du), t(lam.reshape(E, 24) + eps * dl), rp_, None)
+    blk.swhdg_element_blocks(t(u - eps * du), t(lam.reshape(E, 24) - eps * dl), rm_, None)
+    torch.cuda.synchronize()
+    # element direction: 12 interior unknowns flattened (variable, dof), then the 24 traces
+    idx = np.stack([m["lids"][:, m["offsets"][m["varptr"][v] + d]] for v in range(3) for d in range(4)], axis=1)
+    de = torch.cat([t(du[idx]), t(dl)], dim=1)                 # [E][36]
+    Jd = torch.einsum("erc,ec->er", blocks, de)
+    fd = -(rp_ - rm_) / (2 * eps)                              # the residual arrays hold -res.val()
+    assert float((fd - Jd).abs().max() / Jd.abs().max()) < 1e-6
+    assert float(blocks.abs().max()) > 0.0 and bool(torch.isfinite(blocks).all())
