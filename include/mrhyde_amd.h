@@ -292,6 +292,24 @@ int mha_swhdg_element_blocks(mha_context *ctx, const double *u_dev, const double
  * if given, MHA_ERR_INVALID otherwise.  Stateless; synchronises the stream.                                  */
 int mha_batched_condense(int n_int, int n_trace, int64_t num_elems, const double *blocks_dev, const double *res_dev,
                          double *schur_dev, double *gvec_dev, double *du_dev, int *num_singular_host, void *hip_stream);
+/* Scatter of dense element blocks through an arbitrary LID map: the flux -> trace scatter of the HDG caller (condensed
+ * blocks [E][24][24] and flux vectors [E][24] of mha_batched_condense into the macro trace system).
+ * replaces: SubGridDtN_Solver::updateFlux's scatter and the macro assembly's sumIntoValues for those blocks
+ * (src/subgrid/subgridDtN_solver.cpp:1542-1616, src/managers/assemblyManager.cpp:4031-4145).
+ * create: lids_host[E][n] = global row of unknown t of element e; the CRS graph of the target (colind ascending inside a
+ * row), or NULL/NULL to have the every-dof-of-an-element-couples graph built (read it back with _graph); fixed_host
+ * [num_rows] or NULL.  apply: vals[rowptr[r] + slot] (+)= sum blocks[e][t][s], res[r] (+)= sum vec[e][t], one wavefront
+ * per CRS row, no global atomics, results independent of scheduling; overwrite = 1 stores (fixed rows: zeros),
+ * 0 accumulates (fixed rows untouched).  blocks+vals or vec+res may be NULL.                                    */
+typedef struct mha_scatter_plan mha_scatter_plan;
+int mha_scatter_plan_create(int n, int64_t num_elems, int64_t num_rows, const int32_t *lids_host,
+                            const int32_t *rowptr_host, const int32_t *colind_host, const uint8_t *fixed_host,
+                            mha_scatter_plan **out);
+int mha_scatter_plan_nnz(const mha_scatter_plan *p, int64_t *nnz);
+int mha_scatter_plan_graph(const mha_scatter_plan *p, int32_t *rowptr_host, int32_t *colind_host);
+int mha_scatter_plan_apply(const mha_scatter_plan *p, const double *blocks_dev, const double *vec_dev, double *res_dev,
+                           double *vals_dev, int overwrite, void *hip_stream);
+void mha_scatter_plan_destroy(mha_scatter_plan *p);
 /* L[npts][3][3], lam[npts][3], R[npts][3][3] (row-major) of the normal flux Jacobian at Shat */
 int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat_dev, const double *normals_dev,
                           double *L_dev, double *lam_dev, double *R_dev, void *hip_stream);

@@ -21,7 +21,8 @@ EXPORTS = [
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
     "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_get_info", "mha_set_timing",
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
-    "mha_row_partition_destroy", "mha_row_patterns_host_apply", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
+    "mha_row_partition_destroy", "mha_row_patterns_host_apply", "mha_scatter_plan_create", "mha_scatter_plan_nnz",
+    "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
     "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense", "mha_set_function_expression", "mha_set_time", "mha_check_expression",
 ]
@@ -157,6 +158,55 @@ def batched_condense(n_int, n_trace, blocks, res, want_du=True):
     _check(load_library().mha_batched_condense(n_int, n_trace, E, _ptr(blocks), _ptr(res), _ptr(schur), _ptr(gvec), _ptr(du),
                                                C.byref(ns), None))
     return schur, gvec, du, ns.value
+
+
+class ScatterPlan:
+    """Scatter of dense element blocks through an arbitrary LID map (mha_scatter_plan_*): the flux -> trace scatter of
+    the HDG caller.  lids [E][n] int32 (host); graph given or built (every dof of an element couples)."""
+
+    def __init__(self, lids, nrows, rowptr=None, colind=None, fixed=None):
+        lib = load_library()
+        lids = _np(lids, np.int32)
+        self.n, self.nrows = lids.shape[1], int(nrows)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        rp = None if rowptr is None else _np(rowptr, np.int32)
+        ci = None if colind is None else _np(colind, np.int32)
+        fx = None if fixed is None else _np(fixed, np.uint8)
+        self._h = C.c_void_p()
+        lib.mha_scatter_plan_create.argtypes = [C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 5
+        _check(lib.mha_scatter_plan_create(self.n, lids.shape[0], self.nrows, vp(lids), vp(rp), vp(ci), vp(fx),
+                                           C.byref(self._h)))
+        nnz = C.c_int64()
+        lib.mha_scatter_plan_nnz.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib.mha_scatter_plan_nnz(self._h, C.byref(nnz)))
+        self.nnz = nnz.value
+
+    def graph(self):
+        lib = load_library()
+        rowptr, colind = np.zeros(self.nrows + 1, np.int32), np.zeros(self.nnz, np.int32)
+        lib.mha_scatter_plan_graph.argtypes = [C.c_void_p] * 3
+        _check(lib.mha_scatter_plan_graph(self._h, rowptr.ctypes.data_as(C.c_void_p), colind.ctypes.data_as(C.c_void_p)))
+        return rowptr, colind
+
+    def apply(self, blocks=None, vec=None, res=None, vals=None, overwrite=False, stream=None):
+        lib = load_library()
+        lib.mha_scatter_plan_apply.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        _check(lib.mha_scatter_plan_apply(self._h, _ptr(blocks), _ptr(vec), _ptr(res), _ptr(vals), int(overwrite),
+                                          None if stream is None else C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib = load_library()
+            lib.mha_scatter_plan_destroy.argtypes = [C.c_void_p]
+            lib.mha_scatter_plan_destroy.restype = None
+            lib.mha_scatter_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def check_expression(text):

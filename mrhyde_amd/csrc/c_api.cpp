@@ -1,6 +1,7 @@
 // c_api.cpp -- extern "C" boundary (include/mrhyde_amd.h) over the C++ host layer.
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include "assembly_manager.hpp"
@@ -8,6 +9,7 @@
 #include "mesh.hpp"
 #include "row_blocks.hpp"
 #include "row_pattern.hpp"
+#include "scatter_plan.hpp"
 
 struct mha_row_partition {
   mha::RowBlocks rb;
@@ -312,6 +314,50 @@ int mha_row_partition_build(int dim, int num_elems, int n, int num_rows, const d
     *out = p;
   });
 }
+
+struct mha_scatter_plan {
+  std::unique_ptr<mha::ScatterPlan> plan;
+};
+
+int mha_scatter_plan_create(int n, int64_t num_elems, int64_t num_rows, const int32_t *lids_host,
+                            const int32_t *rowptr_host, const int32_t *colind_host, const uint8_t *fixed_host,
+                            mha_scatter_plan **out) {
+  return guarded([&] {
+    MHA_REQUIRE(out && lids_host, MHA_ERR_INVALID, "null argument");
+    MHA_REQUIRE((rowptr_host != nullptr) == (colind_host != nullptr), MHA_ERR_INVALID, "rowptr and colind go together");
+    MHA_REQUIRE(num_elems > 0 && num_elems < (int64_t(1) << 31) && num_rows > 0 && num_rows < (int64_t(1) << 31),
+                MHA_ERR_INVALID, "bad sizes");
+    *out = nullptr;
+    auto p = std::make_unique<mha_scatter_plan>();
+    p->plan = std::make_unique<mha::ScatterPlan>(n, static_cast<int>(num_elems), static_cast<int>(num_rows), lids_host,
+                                                  rowptr_host, colind_host, fixed_host);
+    *out = p.release();
+  });
+}
+
+int mha_scatter_plan_nnz(const mha_scatter_plan *p, int64_t *nnz) {
+  return guarded([&] {
+    MHA_REQUIRE(p && nnz, MHA_ERR_INVALID, "null argument");
+    *nnz = p->plan->nnz();
+  });
+}
+
+int mha_scatter_plan_graph(const mha_scatter_plan *p, int32_t *rowptr_host, int32_t *colind_host) {
+  return guarded([&] {
+    MHA_REQUIRE(p && rowptr_host && colind_host, MHA_ERR_INVALID, "null argument");
+    p->plan->graph(rowptr_host, colind_host);
+  });
+}
+
+int mha_scatter_plan_apply(const mha_scatter_plan *p, const double *blocks_dev, const double *vec_dev, double *res_dev,
+                           double *vals_dev, int overwrite, void *hip_stream) {
+  return guarded([&] {
+    MHA_REQUIRE(p, MHA_ERR_INVALID, "null plan");
+    p->plan->apply(blocks_dev, vec_dev, res_dev, vals_dev, overwrite != 0, static_cast<hipStream_t>(hip_stream));
+  });
+}
+
+void mha_scatter_plan_destroy(mha_scatter_plan *p) { delete p; }
 
 int mha_row_patterns_host_apply(int num_rows, int num_elems, int n, int nsym, const int32_t *lids,
                                 const int32_t *rowptr, const int32_t *colind, const uint8_t *fixed,

@@ -252,3 +252,79 @@ def test_batched_condensation(oracle):
     bad[1] = np.eye(3)
     _, _, _, ns = mrhyde_amd.batched_condense(2, 1, torch.tensor(bad, device="cuda"), torch.zeros((2, 3), dtype=torch.float64, device="cuda"))
     assert ns == 1
+
+
+def trace_lids(nx, ny):
+    """Global trace numbering of an nx x ny macro mesh of HDG quads: 24 unknowns per element = (variable, edge, function)
+    with HFACE edges left, bottom, right, top and two linear functions per edge along the edge's coordinate (the same
+    direction for the two elements that share it: Basis_HFACE needs no orientation).  -> lids [E][24], number of rows."""
+    nvert, nhor = (nx + 1) * ny, nx * (ny + 1)            # vertical edges (x = const), horizontal edges (y = const)
+    vert = lambda i, j: j * (nx + 1) + i                   # edge at x_i between y_j and y_j+1
+    hor = lambda i, j: nvert + j * nx + i                  # edge at y_j between x_i and x_i+1
+    lids = np.zeros((nx * ny, 24), np.int32)
+    for j in range(ny):
+        for i in range(nx):
+            e = j * nx + i
+            edges = [vert(i, j), hor(i, j), vert(i + 1, j), hor(i, j + 1)]
+            for v in range(3):
+                for k, edge in enumerate(edges):
+                    for f in range(2):
+                        lids[e, (v * 4 + k) * 2 + f] = (edge * 3 + v) * 2 + f
+    return lids, (nvert + nhor) * 6
+
+
+@pytest.mark.parametrize("ncell", [(7, 5), (64, 48)])
+def test_flux_to_trace_scatter(ncell):
+    """The condensed trace blocks [E][24][24] and flux vectors [E][24] into the macro trace system through
+    mha_scatter_plan_* (one wavefront per CRS row, no atomics) against a plain COO accumulation; store and accumulate
+    semantics, fixed rows (the macro boundary), matrix-only and vector-only calls."""
+    torch = _torch()
+    import mrhyde_amd
+    import scipy.sparse as sp
+    nx, ny = ncell
+    lids, nrows = trace_lids(nx, ny)
+    E = nx * ny
+    rng = np.random.default_rng(41)
+    S = rng.uniform(-1, 1, (E, 24, 24))
+    gv = rng.uniform(-1, 1, (E, 24))
+    fixed = np.zeros(nrows, np.uint8)
+    cnt = np.bincount(lids.ravel(), minlength=nrows)
+    fixed[cnt == 1] = 1                                   # traces on the macro boundary belong to one element only
+    plan = mrhyde_amd.ScatterPlan(lids, nrows, fixed=fixed)
+    rowptr, colind = plan.graph()
+    assert plan.nnz == len(colind) and np.all(np.diff(rowptr) >= 0)
+    # reference: COO sum, fixed rows zero
+    rows = np.repeat(lids, 24, axis=1).ravel()
+    cols = np.tile(lids, (1, 24)).ravel()
+    keep = fixed[rows] == 0
+    A = sp.coo_matrix((S.ravel()[keep], (rows[keep], cols[keep])), shape=(nrows, nrows)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    ref_vals = np.zeros(len(colind))
+    for r in range(nrows):                                # same graph by construction; place by column
+        lo, hi = rowptr[r], rowptr[r + 1]
+        a_lo, a_hi = A.indptr[r], A.indptr[r + 1]
+        ref_vals[lo + np.searchsorted(colind[lo:hi], A.indices[a_lo:a_hi])] = A.data[a_lo:a_hi]
+    ref_res = np.zeros(nrows)
+    np.add.at(ref_res, lids.ravel(), gv.ravel())
+    ref_res[fixed == 1] = 0.0
+    Sd, gd = torch.tensor(S, device="cuda"), torch.tensor(gv, device="cuda")
+    vals = torch.full((plan.nnz,), 9.0, dtype=torch.float64, device="cuda")
+    res = torch.full((nrows,), -4.0, dtype=torch.float64, device="cuda")
+    plan.apply(Sd, gd, res, vals, overwrite=True)
+    torch.cuda.synchronize()
+    assert np.abs(vals.cpu().numpy() - ref_vals).max() < 1e-13 * np.abs(ref_vals).max()
+    assert np.abs(res.cpu().numpy() - ref_res).max() < 1e-13 * np.abs(ref_res).max()
+    plan.apply(Sd, gd, res, vals)                          # accumulate on top
+    plan.apply(None, gd, res, None)                        # vector only
+    plan.apply(Sd, None, None, vals)                       # matrix only
+    torch.cuda.synchronize()
+    assert np.abs(vals.cpu().numpy() - 3 * ref_vals).max() < 1e-13 * np.abs(ref_vals).max()
+    assert np.abs(res.cpu().numpy() - 3 * ref_res).max() < 1e-13 * np.abs(ref_res).max()
+    with pytest.raises(mrhyde_amd.MhaError):
+        plan.apply(Sd, None, None, None)
+    bad = lids.copy()
+    bad[0, 0] = nrows
+    with pytest.raises(mrhyde_amd.MhaError, match="out of range"):
+        mrhyde_amd.ScatterPlan(bad, nrows)
+    plan.close()
