@@ -102,6 +102,27 @@ def run_hdg(nc):
         t1.record()
         torch.cuda.synchronize()
         print("hdg %d^2: condensation %.3f ms (incl. output allocation), singular %d" % (nc, t0.elapsed_time(t1), ns), flush=True)
+    # flux -> trace scatter of the condensed blocks into the macro trace system (HFACE edge numbering of the nc x nc mesh)
+    nvert = (nc + 1) * nc
+    ii, jj = np.meshgrid(np.arange(nc), np.arange(nc), indexing="xy")
+    ii, jj = ii.ravel(), jj.ravel()
+    edges = np.stack([jj * (nc + 1) + ii, nvert + jj * nc + ii, jj * (nc + 1) + ii + 1, nvert + (jj + 1) * nc + ii], axis=1)
+    lids = np.zeros((E, 24), np.int32)
+    for v in range(3):
+        for k in range(4):
+            for f in range(2):
+                lids[:, (v * 4 + k) * 2 + f] = (edges[:, k] * 3 + v) * 2 + f
+    nrows_t = (nvert + nc * (nc + 1)) * 6
+    plan = mrhyde_amd.ScatterPlan(lids, nrows_t)
+    tv = torch.zeros(plan.nnz, dtype=torch.float64, device="cuda")
+    tr_ = torch.zeros(nrows_t, dtype=torch.float64, device="cuda")
+    for it in range(3):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        plan.apply(S, gv, tr_, tv, overwrite=True, stream=torch.cuda.current_stream().cuda_stream)
+        t1.record()
+        torch.cuda.synchronize()
+        print("hdg %d^2: flux->trace scatter %.3f ms (%d trace rows, %d CRS entries)" % (nc, t0.elapsed_time(t1), nrows_t, plan.nnz), flush=True)
 
 
 def cpu_baseline(kind, sample_nc):
