@@ -8,6 +8,9 @@
 // the same information is  X = A_uu^{-1} [A_ul | r_u],  S = A_ll - A_lu X_ul,  g = r_l - A_lu x_r,  du0 = x_r.
 // One wavefront per element: lane c owns column c of the augmented matrix [A_uu | A_ul | r_u] in registers and the
 // wave runs Gauss-Jordan with partial pivoting on it (pivot column broadcast by shuffles); then lanes own columns of S.
+// The trace rows [A_lu | A_ll | r_l] are requested before the elimination starts (one coalesced row per register, so
+// their latency hides behind it) and the multipliers A_lu[a][i] of the Schur update come out of those registers by
+// shuffle: one pass over the element's block, no wave-uniform reloads.
 // n_int <= 32 and n_int + n_trace + 1 <= 64 (12 + 24 + 1 for the shallow-water HDG element).
 #include <hip/hip_runtime.h>
 
@@ -19,6 +22,15 @@ namespace mha {
 namespace {
 
 constexpr int kCondMaxInt = 32, kCondWaves = 4;
+
+// Value of lane `src` (wave-uniform index) for every lane: v_readlane_b32 x2 into scalar registers.  The generic
+// __shfl goes through the LDS crossbar (ds_bpermute); the elimination does ~1500 of these per element.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int kCondMaxTrace = 32;  // trace rows held in registers (more: read row by row in the Schur loop)
 
 template <int MAXI>
 __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int nt, int64_t nelem,
@@ -38,6 +50,15 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
     if (i < ni && lane < ncol) v = lane < n ? B[(size_t)i * n + lane] : r[i];
     col[i] = v;
   }
+  // row ni + a of [A_lu | A_ll | r_l], entry `lane`
+  const bool regs = nt <= kCondMaxTrace;
+  double low[kCondMaxTrace];
+#pragma unroll
+  for (int a = 0; a < kCondMaxTrace; ++a) {
+    double v = 0.0;
+    if (regs && a < nt && lane < ncol) v = lane < n ? B[(size_t)(ni + a) * n + lane] : r[ni + a];
+    low[a] = v;
+  }
   bool bad = false;
   for (int k = 0; k < ni; ++k) {
     // partial pivoting on column k (held by lane k): the pivot row is the same for every lane
@@ -45,7 +66,7 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
     int piv = k;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-      const double a = fabs(__shfl(col[i], k));
+      const double a = fabs(readlane_f64(col[i], k));
       if (i >= k && i < ni && a > best) { best = a; piv = i; }
     }
     if (!(best > 0.0)) { bad = true; break; }
@@ -59,11 +80,11 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
     double pk = 0.0;
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) if (i == k) pk = col[i];
-    const double akk = __shfl(pk, k);
+    const double akk = readlane_f64(pk, k);
     const double rk = pk / akk;  // this lane's entry of the normalised pivot row
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-      const double aik = __shfl(col[i], k);  // multiplier source: column k before the update
+      const double aik = readlane_f64(col[i], k);  // multiplier source: column k before the update
       if (i < ni) col[i] = (i == k) ? rk : col[i] - aik * rk;
     }
   }
@@ -72,7 +93,23 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
   if (du && lane == n)
     for (int i = 0; i < ni; ++i) du[e * ni + i] = col[i];
   // S[:, b] for trace column b = lane - ni; g through the last lane
-  if (lane >= ni && lane < ncol) {
+  if (regs) {
+    const int b = lane - ni;
+#pragma unroll
+    for (int a = 0; a < kCondMaxTrace; ++a) {
+      if (a < nt) {  // uniform
+        const double rowv = low[a];
+        double sacc = rowv;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+          const double m = readlane_f64(rowv, i);  // A_lu[a][i], executed by every lane
+          if (i < ni) sacc -= m * col[i];
+        }
+        if (lane >= ni && lane < n) { if (schur) schur[(e * nt + a) * nt + b] = sacc; }
+        else if (lane == n && gvec) gvec[e * nt + a] = sacc;
+      }
+    }
+  } else if (lane >= ni && lane < ncol) {
     const int b = lane - ni;
     for (int a = 0; a < nt; ++a) {
       const double *Alu = B + (size_t)(ni + a) * n;  // row a of [A_lu | A_ll]
