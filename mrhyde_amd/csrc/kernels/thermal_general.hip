@@ -59,7 +59,10 @@ struct GK {
 #define MHA_TG_STOP 9  // profiling aid (profiles/tg_ablate.sh): leave the kernel after phase 1, 2, 3 or the product (4)
 #endif
   static constexpr bool MF = MHA_TG_MFMA && N > 16;  // Jacobian product on the matrix cores (2 x 2 tiles of 16 x 16)
-  static constexpr int QM = 8;                    // points per MFMA chunk: QM * DIM rows of P, a multiple of 4
+#ifndef MHA_TG_QM
+#define MHA_TG_QM 8
+#endif
+  static constexpr int QM = MHA_TG_QM;            // points per MFMA chunk: QM * DIM rows of P, a multiple of 4
   static constexpr int PR = QM * DIM;             // rows of the MFMA P panel
   static constexpr int PW = 32;                   // its width (dofs, zero padded)
 #ifndef MHA_TG_EPB
@@ -86,8 +89,11 @@ struct GK {
   static constexpr int REC = (O_PT + (MF ? PR * PW : KC * NP) + 1) / 2 * 2;
 };
 
+#ifndef MHA_TG_MINW
+#define MHA_TG_MINW 2
+#endif
 template <int DIM, int P, int NQ1, bool TR, bool EXPR>
-__global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT), 2) void thermal_general_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
+__global__ __launch_bounds__((GK<DIM, P, NQ1, TR>::NT), MHA_TG_MINW) void thermal_general_element_kernel(BlockDev b, ThermalDev ph, AffineDev af,
                                                                        const uint8_t *__restrict__ slot8,
                                                                        const uint16_t *__restrict__ slot16, ElemOut out) {
   using S = GK<DIM, P, NQ1, TR>;
