@@ -834,7 +834,9 @@ void launch_k1(const BlockDev &b, const ThermalDev &ph, const AffineDev &af, dou
     return;
   }
   const int grid = (b.e_count + kK1Elems - 1) / kK1Elems;
-  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1Threads), 0, stream, b, ph, af, res); };
+  // MHA_K1_LDS_PAD: unused dynamic LDS per workgroup -- throttles how many K1 workgroups share a CU with K2 (experiment)
+  static const size_t pad = [] { const char *m = std::getenv("MHA_K1_LDS_PAD"); return m ? (size_t)std::atoi(m) : (size_t)0; }();
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1Threads), pad, stream, b, ph, af, res); };
   if (has_expression(ph.source)) {  // the only named function K1 evaluates per point (coefficients are constants here)
     if (tr) go(thermal_affine_element_kernel<DIM, P, NQ1, true, true>);
     else go(thermal_affine_element_kernel<DIM, P, NQ1, false, true>);
