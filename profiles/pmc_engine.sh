@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_engine
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $OUT
 run() { local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python $GRAFT_REPO_ROOT/profiles/engine_bench.py $MOD $NC gather > $OUT.$name.log 2>&1 || echo "pass $name failed"; }
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python $GRAFT_REPO_ROOT/tests/engine_bench.py $MOD $NC gather > $OUT.$name.log 2>&1 || echo "pass $name failed"; }
 MOD=${1:-thermal}; NC=${2:-32}
 run inst SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES
 run wait SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE

@@ -1,6 +1,8 @@
-"""Timing of the multi-variable point engine at the sizes of BASELINE.json configs 2-4 (not a bench.py line: those
-configs are parity cases; this script records where the first implementation stands).  Usage:
-  python profiles/engine_bench.py [thermal|porous|ns] [ncell]"""
+"""Timing of the multi-variable paths at the sizes of BASELINE.json configs 2-5 (not a bench.py line: those configs are
+parity cases; this script records where the implementation stands).  It lives under tests/ because it builds its
+inputs with the oracle's mesh generator and can time the oracle as a CPU baseline -- test infrastructure, like the
+parity tests.  Usage:
+  python tests/engine_bench.py [thermal|porous|ns|hdg] [ncell] [full|gather|res|local] [cpu]"""
 import sys
 import time
 
@@ -10,7 +12,7 @@ import torch
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # oracle_lib
 import mrhyde_amd  # noqa: E402
 import oracle_lib as orc  # noqa: E402  (mesh generator only: test infrastructure building the input)
 
