@@ -143,6 +143,29 @@ __global__ __launch_bounds__(256) void affine_geometry_kernel(BlockDev b, double
 // K1: element-wise residual
 // ---------------------------------------------------------------------------------------------
 
+#ifndef MHA_K1_DPP
+#define MHA_K1_DPP 0  // 1: residual contraction transposed (lane = point), DPP row reductions instead of LDS broadcasts;
+                      // parity-tested, same speed alone and beside K2 (profiles/r1_ab_k1_dpp.log), so the simpler form stays
+#endif
+
+// x + (x moved across lanes by the DPP control CTRL), lanes of rows outside ROWMASK add zero.  v_mov_b32_dpp x2 + v_add_f64:
+// data movement inside the vector ALU, no LDS.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xF, false);
+  return x + __hiloint2double(hi, lo);
+}
+// sum over the 32 lanes of a half wave; complete in lanes 16..31 (and 48..63)
+[[maybe_unused]] __device__ __forceinline__ double half_wave_sum(double x) {
+  x = dpp_add<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add<0x141, 0xF>(x);  // row_half_mirror
+  x = dpp_add<0x140, 0xF>(x);  // row_mirror: every lane of a 16-lane row holds the row's sum
+  x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  return x;
+}
+
 template <int DIM, int P, int NQ1, bool TR>
 struct EK {
   static constexpr int M = P + 1;
@@ -208,6 +231,9 @@ __global__ __launch_bounds__(kK1Threads) void thermal_affine_element_kernel(Bloc
   __syncthreads();
 
   // B. fields at the integration points (e, e_t, grad(e)) and the point-wise residual data (l = q)
+  double my_rq = 0.0, my_F[DIM];
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) my_F[a] = 0.0;
   if (active && l < NQ) {
     const int q = l;
     double gh[DIM], tv, gd[DIM], tt;
@@ -241,11 +267,57 @@ __global__ __launch_bounds__(kK1Threads) void thermal_affine_element_kernel(Bloc
       double s = 0.0;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) s += G[a][c] * gh[c];
-      E[S::O_F + q * DIM + a] = wq * kap * s;
+      my_F[a] = wq * kap * s;
+      if (!MHA_K1_DPP) E[S::O_F + q * DIM + a] = my_F[a];
     }
     const double f = eval_func<DIM, EXPR>(ph.source, e, q, NQ, x);
-    E[S::O_RQ + q] = (rc * tt - f) * E[S::O_DET] * wq;
+    my_rq = (rc * tt - f) * E[S::O_DET] * wq;
+    if (!MHA_K1_DPP) E[S::O_RQ + q] = my_rq;
   }
+#if MHA_K1_DPP
+  // C'. residual rows, transposed: this lane keeps ITS point's data in registers and walks the dofs; the sum over the
+  //     points is a DPP reduction over the half wave (the LDS broadcasts of the other form kept the LDS pipe busy for
+  //     78 % of the kernel and collided with K2's accumulator traffic).  Result of dof ib lands in lane 16 + (ib & 15).
+  {
+    int qq = (l < NQ) ? l : 0;
+    double Pt[DIM][M], Dt[DIM][M];  // 1-D basis values / derivatives at this lane's point, per direction
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      const int qd = qq % NQ1;
+      qq /= NQ1;
+#pragma unroll
+      for (int a = 0; a < M; ++a) { Pt[d][a] = phi[a * NQ1 + qd]; Dt[d][a] = dphi[a * NQ1 + qd]; }
+    }
+    double mine[(N + 15) / 16];
+#pragma unroll
+    for (int k = 0; k < (N + 15) / 16; ++k) mine[k] = 0.0;
+#pragma unroll
+    for (int ib = 0; ib < N; ++ib) {
+      const int i0 = ib % M, i1 = (ib / M) % M, i2 = ib / (M * M);
+      double c;
+      if constexpr (DIM == 2) {
+        (void)i2;
+        c = my_rq * Pt[0][i0] * Pt[1][i1] + my_F[0] * Dt[0][i0] * Pt[1][i1] + my_F[1] * Pt[0][i0] * Dt[1][i1];
+      } else {
+        const double a12 = Pt[1][i1] * Pt[DIM - 1][i2];
+        c = (my_rq * Pt[0][i0] + my_F[0] * Dt[0][i0]) * a12 +
+            Pt[0][i0] * (my_F[1] * Dt[1][i1] * Pt[DIM - 1][i2] + my_F[DIM - 1] * Pt[1][i1] * Dt[DIM - 1][i2]);
+      }
+      const double sum = half_wave_sum(c);
+      if (l >= 16 && (l & 15) == (ib & 15)) mine[ib >> 4] = sum;
+    }
+    if (active && l >= 16) {
+#pragma unroll
+      for (int k = 0; k < (N + 15) / 16; ++k) {
+        const int ib = (l & 15) + 16 * k;
+        if (ib >= N) continue;
+        const int row = b.lids[(size_t)e * N + s_offs[ib]];
+        if (!(b.fixed && b.fixed[row])) atomicAdd(res + row, -mine[k]);  // -res.val(), fixed rows skipped
+      }
+    }
+  }
+  return;
+#endif
   __syncthreads();
 
   // C. residual rows by quadrature (l = LID slot): r_i = sum_q rq N_i + F . grad_ref N_i
