@@ -338,25 +338,13 @@ int mha_row_partition_get(const mha_row_partition *p, int32_t *row_ptr, int32_t 
                           int32_t *elems);
 void mha_row_partition_destroy(mha_row_partition *p);
 
-/* Host-only check of the pattern grouping behind MHA_K2=pattern (csrc/row_pattern.hpp): groups the rows of the block
- * (lids [num_elems][n], CRS graph rowptr/colind, fixed [num_rows] or NULL) by assembly pattern, then walks the tile
- * descriptors and row records exactly as kernels/row_pattern.hip does and evaluates
- *   vals[rowptr[r] + slot] = sum_(e incident to r) sum_c factors[e][c] * khat[c][si(e,r)][sj -> slot]
- * on the host (khat [nsym+1][n*n] in LID-slot space, factors [num_elems][depth], depth = nsym + 1 rounded up to a
- * multiple of 4; fixed rows give zeros).  Replaces nothing in the reference: test infrastructure for the
- * matrix-core form of the scatter (src/managers/assemblyManager.cpp:4031-4145).
- * Returns MHA_ERR_INVALID with a reason when the rows do not group (too many patterns).                         */
-int mha_row_patterns_host_apply(int num_rows, int num_elems, int n, int nsym, const int32_t *lids,
-                                const int32_t *rowptr, const int32_t *colind, const uint8_t *fixed,
-                                const double *khat, const double *factors, double *vals, int *num_patterns,
-                                int *num_super_tiles);
-
 /* ---- introspection for bench / tests ---------------------------------------------
  * keys: "num_elems","num_rows","nnz","dofs_per_elem","num_ip","workset_size","last_path",
  *       "row_blocks","num_affine_elems","row_block_max_rows","row_block_max_elems",
- *       "row_block_max_acc","row_owner_lds_bytes","row_patterns","row_pattern_tiles"
- * (the last two are 0 unless the pattern form of the row-owner Jacobian was requested with MHA_K2=pattern
- * and the mesh's rows group into few enough patterns)                                   */
+ *       "row_block_max_acc","row_owner_lds_bytes","block_patterns","block_pattern_roles",
+ *       "block_pattern_blocks","block_pattern_mfma"
+ * (the block_pattern keys are 0 when the matrix-core form of the row-owner Jacobian is not in use: MHA_K2=blocks,
+ * or a mesh whose row blocks share too few assembly patterns)                            */
 int mha_get_info(mha_context *ctx, const char *key, int64_t *value);
 /* average device time (ms) of the last assembly's kernels, measured with HIP events on the
  * context's stream; valid after mha_set_timing(ctx,1).                                  */

@@ -21,7 +21,7 @@ EXPORTS = [
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
     "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_get_info", "mha_set_timing",
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
-    "mha_row_partition_destroy", "mha_row_patterns_host_apply", "mha_scatter_plan_create", "mha_scatter_plan_nnz",
+    "mha_row_partition_destroy", "mha_scatter_plan_create", "mha_scatter_plan_nnz",
     "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
     "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense", "mha_set_function_expression", "mha_set_time", "mha_check_expression",
@@ -245,22 +245,24 @@ def mesh_structured(dim, order, ncell, lo=None, hi=None):
     return m
 
 
-def row_patterns_host_apply(lids, nrows, rowptr, colind, khat, factors, fixed=None):
-    """Host-only: the pattern grouping behind MHA_K2=pattern, walked as the kernel walks it
-    (mha_row_patterns_host_apply).  -> (vals [nnz], num_patterns, num_super_tiles)."""
+def block_patterns_host_apply(dim, nodes, lids, nrows, rowptr, colind, khat, factors, fixed=None, scale_u=1.0,
+                              scale_t=1.0, chunk_elems=16, num_cus=8, max_patterns=256):
+    """Host-only test hook (csrc/test_hooks.h, not part of the boundary): the block-pattern plan of the matrix-core
+    row-owner Jacobian, walked as the kernel walks it.  -> (vals [nnz], (patterns, roles, workgroups, parts))."""
     lib = load_library()
-    lids, rowptr, colind = _np(lids, np.int32), _np(rowptr, np.int32), _np(colind, np.int32)
+    nodes, lids, rowptr, colind = _np(nodes, np.float64), _np(lids, np.int32), _np(rowptr, np.int32), _np(colind, np.int32)
     khat, factors = _np(khat, np.float64), _np(factors, np.float64)
     fx = None if fixed is None else _np(fixed, np.uint8)
     vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     nsym = khat.shape[0] - 1
     vals = np.full(len(colind), np.nan)
-    npat, nst = C.c_int(), C.c_int()
-    lib.mha_row_patterns_host_apply.argtypes = [C.c_int] * 4 + [C.c_void_p] * 9
-    _check(lib.mha_row_patterns_host_apply(int(nrows), lids.shape[0], lids.shape[1], nsym, vp(lids), vp(rowptr),
-                                           vp(colind), vp(fx), vp(khat), vp(factors), vp(vals), C.byref(npat),
-                                           C.byref(nst)))
-    return vals, npat.value, nst.value
+    counts = (C.c_int * 4)()
+    f = lib.mha_test_block_patterns_host_apply
+    f.argtypes = [C.c_int] * 6 + [C.c_void_p] * 7 + [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    _check(f(int(dim), int(nrows), lids.shape[0], nodes.shape[1], lids.shape[1], nsym, vp(nodes), vp(lids), vp(rowptr),
+             vp(colind), vp(fx), vp(khat), vp(factors), float(scale_u), float(scale_t), int(chunk_elems), int(num_cus),
+             int(max_patterns), vp(vals), counts))
+    return vals, tuple(counts)
 
 
 def row_partition(dim, nodes, lids, nrows, rowptr, caps=None):

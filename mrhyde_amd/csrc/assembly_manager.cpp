@@ -1,6 +1,8 @@
 #include "assembly_manager.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -241,7 +243,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   d_colind_.upload(h_colind_);
   has_graph_ = true;
   ro_ = RowOwnerData();
-  rpat_ = RowPatternData();
+  bpat_ = BlockPatternData();
   has_elem_slot_ = false;
   has_incidence_ = false;
 }
@@ -964,28 +966,80 @@ void AssemblyManager::prepareRowOwner() {
     ro.k1_t1.upload(t1);
     ro.k1_t2.upload(t2);
   }
+  // thread-per-element K1: 1-D tables by value; the collocation derivative D = Phi'^T Phi^-T (Gauss-Jordan on the
+  // small, well-conditioned point-value matrix)
+  ro.k1_thread = false;
+  if (thermal_affine_residual_supported(dim_, order_, ref_.nq1)) {
+    const int m = order_ + 1;
+    AffineTables1D &t = ro.tab1d;
+    t = AffineTables1D();
+    for (int i = 0; i < m * m; ++i) t.phi[i] = ref_.phi1d[i];
+    for (int q = 0; q < m; ++q) { t.gw[q] = ref_.gauss_wts[q]; t.gp[q] = ref_.gauss_pts[q]; }
+    // inv = Phi^-1 with Phi[i][q] = phi_i(xi_q)
+    std::vector<double> a(ref_.phi1d.begin(), ref_.phi1d.begin() + m * m), inv(m * m, 0.0);
+    for (int i = 0; i < m; ++i) inv[i * m + i] = 1.0;
+    for (int c = 0; c < m; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < m; ++r)
+        if (std::fabs(a[r * m + c]) > std::fabs(a[piv * m + c])) piv = r;
+      for (int k = 0; k < m; ++k) { std::swap(a[c * m + k], a[piv * m + k]); std::swap(inv[c * m + k], inv[piv * m + k]); }
+      const double d = 1.0 / a[c * m + c];
+      for (int k = 0; k < m; ++k) { a[c * m + k] *= d; inv[c * m + k] *= d; }
+      for (int r = 0; r < m; ++r) {
+        if (r == c) continue;
+        const double f = a[r * m + c];
+        for (int k = 0; k < m; ++k) { a[r * m + k] -= f * a[c * m + k]; inv[r * m + k] -= f * inv[c * m + k]; }
+      }
+    }
+    for (int q = 0; q < m; ++q)
+      for (int qp = 0; qp < m; ++qp) {
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += ref_.dphi1d[i * m + q] * inv[qp * m + i];
+        t.dcol[q * m + qp] = s;
+      }
+    const char *k1 = std::getenv("MHA_K1");
+    ro.k1_thread = !(k1 && std::string(k1) == "lanes");
+  }
   ro.phi.upload(ref_.phi1d);
   ro.dphi.upload(ref_.dphi1d);
   ro.gw.upload(ref_.gauss_wts);
   ro.gp.upload(ref_.gauss_pts);
   MHA_HIP(hipStreamSynchronize(stream_));
   ro.ready = true;
-  prepareRowPattern();
+  prepareBlockPattern();
 }
 
-// Matrix-core form of K2: group the rows by assembly pattern (row_pattern.hpp).  Requested with MHA_K2=pattern; a mesh
-// whose rows share too few patterns keeps the row-block kernel (info key "row_patterns" = 0).
-void AssemblyManager::prepareRowPattern() {
-  RowPatternData &rp = rpat_;
-  rp.tried = true;
-  rp.usable = false;
-  // opt-in for now: on config 2 the pattern kernel is at 0.51 ms against 0.47 ms of the row-block kernel
-  // (profiles/README.md, "Pattern GEMM form of K2")
+// Matrix-core form of K2: row blocks keyed by assembly pattern (block_pattern.hpp).  Default; MHA_K2=blocks keeps the
+// LDS-accumulator row-block kernel, as does a mesh whose blocks share too few patterns (info key "block_patterns" = 0).
+void AssemblyManager::prepareBlockPattern() {
+  BlockPatternData &bp = bpat_;
+  bp.tried = true;
+  bp.usable = false;
+  // opt-in while it is being tuned (profiles/README.md, round 2): parity-green, 0.53 ms against 0.47 ms for the row blocks
   const char *mode = std::getenv("MHA_K2");
-  if (!mode || std::string(mode) != "pattern") { rp.why = "not requested (MHA_K2=pattern)"; return; }
-  if (ro_.num_general_blocks > 0) { rp.why = "block has non-affine elements"; return; }
-  std::vector<int32_t> ptr, elem, lpos;
-  build_row_incidence(nrows_, nelem_, n_, h_lids_.data(), ptr, elem, lpos);
+  if (!mode || std::string(mode) != "pattern") { bp.why = "not requested (MHA_K2=pattern)"; return; }
+  if (ro_.num_general_blocks > 0) { bp.why = "block has non-affine elements"; return; }
+  if (static_cast<long long>(h_rowptr_[nrows_]) >= (1ll << 28)) { bp.why = "more than 2^28 CRS entries (32-bit byte offsets)"; return; }
+  // its own partition: larger Morton chunks (16 elements = 16 rows of every class of a Q2 hex block: whole MFMA panels),
+  // no LDS accumulator to fit
+  RowBlockCaps caps = default_caps(dim_, n_);
+  caps.chunk_elems = 16;
+  if (const char *e = std::getenv("MHA_BP_CHUNK")) caps.chunk_elems = std::max(1, std::atoi(e));
+  caps.max_rows = 4096;
+  caps.max_elems = 255;
+  caps.max_pairs = 1 << 20;
+  caps.max_acc = 1 << 30;
+  std::vector<double> nodes(static_cast<size_t>(nelem_) * nnodes_ * dim_);
+  d_nodes_.download(nodes.data());
+  RowBlocks rb;
+  try {
+    rb = build_row_blocks(dim_, nnodes_, nelem_, n_, nrows_, nodes.data(), h_lids_.data(), h_rowptr_.data(), caps,
+                          has_fixed_ ? h_fixed_.data() : nullptr, 1);
+  } catch (const Error &e) {
+    bp.why = e.what();
+    return;
+  }
+  if (static_cast<int>(rb.rows.size()) != nrows_ && !ro_.all_rows_covered) { /* rows without elements stay untouched on both paths */ }
   prepareElemSlots();
   std::vector<uint8_t> slot(static_cast<size_t>(nelem_) * n_ * n_ * elem_slot_bytes_);
   MHA_HIP(hipStreamSynchronize(stream_));
@@ -996,36 +1050,49 @@ void AssemblyManager::prepareRowPattern() {
   int dev = 0, num_cu = 0;
   MHA_HIP(hipGetDevice(&dev));
   MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  int wgs_per_cu = 2;
-  if (const char *m = std::getenv("MHA_RP_WGS")) wgs_per_cu = std::max(1, std::atoi(m));
-  int chunk = 2;  // 0: contiguous cost-balanced ranges; > 0: chunks of that many super tiles dealt round-robin
-  if (const char *m = std::getenv("MHA_RP_CHUNK")) chunk = std::max(0, std::atoi(m));
-  const RowPatterns h = build_row_patterns(nrows_, n_, nsym, h_rowptr_.data(), has_fixed_ ? h_fixed_.data() : nullptr, ptr, elem, lpos, slot.data(),
-                                           elem_slot_bytes_, khat.data(), num_cu * wgs_per_cu, chunk, 4096,
-                                           size_t(256) << 20, 76 * 1024);
-  rp.why = h.why;
+  if (const char *m = std::getenv("MHA_BP_WGS")) num_cu = std::max(1, std::atoi(m));
+  const BlockPatternPlan h = build_block_patterns(rb, n_, nsym, h_rowptr_.data(), has_fixed_ ? h_fixed_.data() : nullptr,
+                                                  slot.data(), elem_slot_bytes_, khat.data(), num_cu, size_t(150) * 1024, 256,
+                                                  std::getenv("MHA_BP_SEGBLOCKS") ? std::atoi(std::getenv("MHA_BP_SEGBLOCKS")) : 0);
+  bp.why = h.why;
+  if (std::getenv("MHA_VERBOSE"))
+    fprintf(stderr, "[mrhyde_amd] block patterns: usable %d (%s), %d patterns, %d roles, %d parts, %d workgroups, %lld MFMAs per assembly\n",
+            int(h.usable), h.why.c_str(), h.num_patterns, h.num_roles, h.num_parts, h.num_wgs, (long long)h.mfma_per_assembly);
   if (!h.usable) return;
-  rp.num_patterns = h.num_patterns;
-  rp.num_super_tiles = static_cast<int>(h.st_pat.size());
-  rp.w.upload(h.w);
-  rp.st_desc.upload(h.st_desc);
-  rp.st_rec.upload(h.st_rec);
-  rp.wg_ptr.upload(h.wg_ptr);
-  rp.geok.resize(static_cast<size_t>(nelem_) * h.ke);
-  launch_build_geok(nelem_, nsym, h.ke, ro_.geo.data(), rp.geok.data(), stream_);
-  RowPatternDev &d = rp.dev;
-  d.num_wgs = static_cast<int>(h.wg_ptr.size()) - 1;
-  d.ke = h.ke;
-  d.nsym = nsym;
+  bp.num_patterns = h.num_patterns;
+  bp.num_roles = h.num_roles;
+  bp.num_blocks = rb.num_blocks;
+  bp.mfma_per_assembly = h.mfma_per_assembly;
+  bp.role.upload(h.role);
+  bp.seg.upload(h.seg);
+  bp.wg_seg_ptr.upload(h.wg_seg_ptr);
+  bp.part_ptr.upload(h.part_ptr);
+  bp.part_hdr.upload(h.part_hdr);
+  bp.part_lane.upload(h.part_lane);
+  bp.rowbase.upload(h.rowbase);
+  bp.erec_elem.upload(h.erec_elem);
+  bp.w.upload(h.w);
+  bp.erec2.resize(h.erec_elem.size() * kBpRecDoubles);
+  launch_build_erec2(static_cast<int64_t>(h.erec_elem.size()), nsym, bp.erec_elem.data(), ro_.geo.data(), bp.erec2.data(), stream_);
+  if (std::getenv("MHA_BP_TIMING")) bp.timing.resize(static_cast<size_t>(h.num_wgs) * kBpWaves * 8);
+  BlockPatternDev &d = bp.dev;
+  d.num_wgs = h.num_wgs;
   d.max_w_doubles = h.max_w_doubles;
-  if (const char *m = std::getenv("MHA_RP_DBG")) d.dbg = std::atoi(m);
-  d.w = rp.w.data();
-  d.st_desc = rp.st_desc.data();
-  d.st_rec = rp.st_rec.data();
-  d.wg_ptr = rp.wg_ptr.data();
-  d.geok = rp.geok.data();
+  d.dbg = 0;
+  if (const char *m = std::getenv("MHA_BP_DBG")) d.dbg = std::atoi(m);
+  d.erec2 = bp.erec2.data();
+  d.rowbase = bp.rowbase.data();
+  d.w = bp.w.data();
+  d.role = bp.role.data();
+  d.seg = bp.seg.data();
+  d.wg_seg_ptr = bp.wg_seg_ptr.data();
+  d.part_ptr = bp.part_ptr.data();
+  d.part_hdr = bp.part_hdr.data();
+  d.part_lane = bp.part_lane.data();
+  d.nnz = h_rowptr_[nrows_];
+  d.timing = bp.timing.empty() ? nullptr : bp.timing.data();
   MHA_HIP(hipStreamSynchronize(stream_));
-  rp.usable = true;
+  bp.usable = true;
 }
 
 bool AssemblyManager::rowOwnerUsable(std::string *why) const {
@@ -1098,9 +1165,19 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   // (0.743 -> 0.686 ms per assembly on config 2, profiles/r1_ab_k1k2_overlap.log); MHA_K1K2_OVERLAP=0 serialises them
   static const int overlap = [] { const char *m = std::getenv("MHA_K1K2_OVERLAP"); return m ? std::atoi(m) : 1; }();
   const double su = ph.time.alpha_u * ph.diff.amp, st = ph.time.alpha_t * ph.rho.amp * ph.cp.amp;
+  auto residual = [&](hipStream_t s) {  // K1: one thread per element (default) or the 32-lanes-per-element form (MHA_K1=lanes)
+    if (ro_.k1_thread) launch_thermal_affine_residual(dim_, order_, blockDev(), ph, ro_.geo.data(), ro_.tab1d, res, s);
+    else launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, s);
+  };
   auto jacobian = [&](hipStream_t s) {  // K2: pattern GEMMs on the matrix cores when the rows group, row blocks otherwise
-    if (rpat_.usable) {
-      launch_row_pattern_jacobian(rpat_.dev, out, su, st, s);
+    if (bpat_.usable) {
+      launch_block_pattern_jacobian(bpat_.dev, out, su, st, s);
+      if (bpat_.dev.timing) {  // profiling aid: wall-clock stamps of every wavefront of the last launch -> $MHA_BP_TIMING
+        MHA_HIP(hipStreamSynchronize(s));
+        std::vector<long long> t(bpat_.timing.size());
+        bpat_.timing.download(t.data());
+        if (FILE *f = fopen(std::getenv("MHA_BP_TIMING"), "wb")) { fwrite(t.data(), sizeof(long long), t.size(), f); fclose(f); }
+      }
     } else {
       launch_row_owner_jacobian(dim_, n_, rb, af, out, su, st, s);
     }
@@ -1113,14 +1190,14 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
     }
     MHA_HIP(hipEventRecord(ev_fork_, stream_));
     MHA_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
-    if (overlap == 2) launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, side_stream_);
+    if (overlap == 2) residual(side_stream_);
     jacobian(stream_);
-    if (overlap != 2) launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, side_stream_);
+    if (overlap != 2) residual(side_stream_);
     MHA_HIP(hipEventRecord(ev_join_, side_stream_));
     MHA_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     return;
   }
-  launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, stream_);
+  residual(stream_);
   if (compute_jacobian) jacobian(stream_);
 }
 
@@ -1133,8 +1210,10 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "last_path") return last_path_;
   if (key == "workset_size") return wkset_.maxElem;
   if (key == "row_blocks") return ro_.ready ? ro_.rb.num_blocks : 0;
-  if (key == "row_patterns") return rpat_.usable ? rpat_.num_patterns : 0;
-  if (key == "row_pattern_tiles") return rpat_.usable ? rpat_.num_super_tiles : 0;
+  if (key == "block_patterns") return bpat_.usable ? bpat_.num_patterns : 0;
+  if (key == "block_pattern_roles") return bpat_.usable ? bpat_.num_roles : 0;
+  if (key == "block_pattern_blocks") return bpat_.usable ? bpat_.num_blocks : 0;
+  if (key == "block_pattern_mfma") return bpat_.usable ? bpat_.mfma_per_assembly : 0;
   if (key == "num_affine_elems") return ro_.ready ? ro_.num_affine_elems : -1;
   if (key == "row_block_max_rows") return ro_.rb.max_rows;
   if (key == "row_block_max_elems") return ro_.rb.max_elems;

@@ -13,7 +13,7 @@
 #include "physics.hpp"
 #include "ref_tables.hpp"
 #include "row_blocks.hpp"
-#include "row_pattern.hpp"
+#include "block_pattern.hpp"
 #include "workset.hpp"
 
 namespace mha {
@@ -131,20 +131,24 @@ class AssemblyManager {
     DeviceBuffer<uint32_t> pairs;
     DeviceBuffer<uint8_t> slot, flags;
     DeviceBuffer<double> khat, phi, dphi, gw, gp, k1_t1, k1_t2;
+    AffineTables1D tab1d;  // thread-per-element K1
+    bool k1_thread = false;
     int slot_bytes = 1;
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
     bool all_rows_covered = false;
   } ro_;
-  // rows grouped by assembly pattern: the matrix-core form of K2 (row_pattern.hpp); !usable -> the row-block kernel
-  struct RowPatternData {
+  // row blocks keyed by assembly pattern: the matrix-core form of K2 (block_pattern.hpp); !usable -> the row-block kernel
+  struct BlockPatternData {
     bool tried = false, usable = false;
     std::string why;
-    int num_patterns = 0, num_super_tiles = 0;
-    RowPatternDev dev;
-    DeviceBuffer<int32_t> st_desc, st_rec, wg_ptr;
-    DeviceBuffer<double> w, geok;
-  } rpat_;
-  void prepareRowPattern();
+    int num_patterns = 0, num_roles = 0, num_blocks = 0;
+    int64_t mfma_per_assembly = 0;
+    BlockPatternDev dev;
+    DeviceBuffer<int32_t> role, seg, wg_seg_ptr, part_ptr, part_hdr, part_lane, rowbase, erec_elem;
+    DeviceBuffer<double> w, erec2;
+    DeviceBuffer<long long> timing;
+  } bpat_;
+  void prepareBlockPattern();
 
   // host mirror of BoundaryGroup: entries + the side views evaluated on request
   struct BoundaryGroupData {

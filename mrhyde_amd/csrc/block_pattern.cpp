@@ -1,0 +1,485 @@
+// block_pattern.cpp -- see block_pattern.hpp.
+#include "block_pattern.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <numeric>
+#include <unordered_map>
+
+#include "common.hpp"
+
+namespace mha {
+namespace {
+
+// role record (kBpRoleInts ints)
+enum { R_EREC_LO = 0, R_EREC_HI, R_ESTRIDE, R_ROWB_LO, R_ROWB_HI, R_NRUNS, R_NBLOCKS, R_COST, R_WOFF_LO, R_WOFF_HI,
+       R_WDOUBLES, R_PATTERN, R_NELEMS };
+// part header (kBpHdrInts ints)
+enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_PHASE, H_NPHASE, H_FLAGS, H_CLASS };
+
+uint64_t fnv1a(const std::vector<uint8_t> &b) {
+  uint64_t h = 1469598103934665603ull;
+  for (uint8_t c : b) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+inline void put16(std::vector<uint8_t> &o, int v) { o.push_back(v & 0xff); o.push_back((v >> 8) & 0xff); }
+inline void put24(std::vector<uint8_t> &o, int v) { put16(o, v); o.push_back((v >> 16) & 0xff); }
+
+// Everything the kernel's static tables depend on, as bytes: rows (length, fixed), touched elements (count) and per
+// contribution pair the owned row, the element, the local dof and the slot of every column of that element.
+void block_signature(const RowBlocks &rb, int b, int n, const int32_t *rowptr, const uint8_t *fixed, const uint8_t *slot,
+                     int slot_bytes, std::vector<uint8_t> &out) {
+  out.clear();
+  const int r0 = rb.row_ptr[b], R = rb.row_ptr[b + 1] - r0;
+  const int t0 = rb.elem_ptr[b], T = rb.elem_ptr[b + 1] - t0;
+  put16(out, R);
+  put16(out, T);
+  for (int o = 0; o < R; ++o) {
+    const int r = rb.rows[r0 + o];
+    put24(out, rowptr[r + 1] - rowptr[r]);
+    out.push_back((fixed && fixed[r]) ? 1 : 0);
+    out.push_back((o > 0 && rb.rows[r0 + o - 1] + 1 == r) ? 0 : 1);  // 1: the row starts a new run of consecutive rows
+  }
+  for (int p = rb.pair_ptr[b]; p < rb.pair_ptr[b + 1]; ++p) {
+    const uint32_t pk = rb.pairs[p];
+    const int o = pk >> 16, t = (pk >> 8) & 0xff, si = pk & 0xff;
+    put16(out, o);
+    out.push_back(static_cast<uint8_t>(t));
+    out.push_back(static_cast<uint8_t>(si));
+    const uint8_t *s = slot + (static_cast<size_t>(rb.elems[t0 + t]) * n + si) * n * slot_bytes;
+    out.insert(out.end(), s, s + static_cast<size_t>(n) * slot_bytes);
+  }
+}
+
+struct Inc { int si, t; const uint8_t *slots; };
+
+struct RowClass {
+  int len = 0, ni = 0;
+  bool fixed = false;
+  std::vector<int> inst_row;             // block-local rows of the instances
+  std::vector<std::vector<int>> inst_t;  // per instance: block-local element of incidence k
+  std::vector<int> si;                   // local dof of incidence k
+  std::vector<std::vector<int>> slots;   // per incidence k: slot of every column of that element
+  int ks = 0, nct = 0, stride = 0, w_doubles = 0;
+  int bin = 0, w_off = 0;                // role (LDS bin) and offset inside it
+};
+
+inline int stride_for(int nct) { return (nct % 2 == 1) ? 16 * nct : 16 * nct + 16; }
+
+}  // namespace
+
+BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, const int32_t *rowptr, const uint8_t *fixed,
+                                      const void *elem_slot, int slot_bytes, const double *khat, int num_cus,
+                                      size_t lds_budget_bytes, int max_patterns, int seg_blocks) {
+  BlockPatternPlan pl;
+  pl.nsym = nsym;
+  pl.ke = nsym + 1;
+  const int ke = pl.ke;
+  const uint8_t *slot = static_cast<const uint8_t *>(elem_slot);
+  auto fail = [&](const std::string &m) { pl.usable = false; pl.why = m; return pl; };
+  if (rb.num_blocks == 0) return fail("no row blocks");
+  if (ke > kBpRecDoubles) return fail("more geometry components than an element record holds");
+  const size_t nn = static_cast<size_t>(n) * n;
+
+  // ---- 1. pattern of every block ----
+  std::unordered_map<uint64_t, std::vector<int32_t>> by_hash;  // hash -> pattern ids (collisions resolved by comparing bytes)
+  std::vector<int32_t> rep;                                    // representative block of each pattern
+  std::vector<std::vector<int32_t>> members;
+  std::vector<uint8_t> cur, other;
+  for (int b = 0; b < rb.num_blocks; ++b) {
+    block_signature(rb, b, n, rowptr, fixed, slot, slot_bytes, cur);
+    std::vector<int32_t> &ids = by_hash[fnv1a(cur)];
+    int found = -1;
+    for (int id : ids) {
+      block_signature(rb, rep[id], n, rowptr, fixed, slot, slot_bytes, other);
+      if (other == cur) { found = id; break; }
+    }
+    if (found < 0) {
+      found = static_cast<int>(rep.size());
+      if (found >= max_patterns) return fail("row blocks share too few assembly patterns (unstructured numbering)");
+      rep.push_back(b);
+      members.emplace_back();
+      ids.push_back(found);
+    }
+    members[found].push_back(b);
+  }
+  pl.num_patterns = static_cast<int>(rep.size());
+
+  // ---- 2. per pattern: classes, tiles, parts, roles ----
+  struct RoleBuild {
+    int pattern, bin, R, T, nruns;
+    int w_doubles = 0;
+    int64_t w_off = 0;             // start of the role's LDS image inside pl.w
+    int64_t cost = 0;              // per block
+    std::vector<std::vector<int32_t>> wave_parts;  // [kBpWaves] -> part indices (global)
+  };
+  std::vector<RoleBuild> roles;
+  const int budget_doubles = static_cast<int>(lds_budget_bytes / sizeof(double));
+
+  for (int pat = 0; pat < pl.num_patterns; ++pat) {
+    const int b = rep[pat];
+    const int r0 = rb.row_ptr[b], R = rb.row_ptr[b + 1] - r0;
+    const int t0 = rb.elem_ptr[b], T = rb.elem_ptr[b + 1] - t0;
+    if ((T + 1) * kBpRecDoubles >= 65536) return fail("a block touches too many elements");
+    // runs of consecutive rows: contiguous in the CRS value array, so one offset per (block, run) locates every row
+    std::vector<int> run_of(R), run_first;
+    for (int o = 0; o < R; ++o) {
+      if (o == 0 || rb.rows[r0 + o - 1] + 1 != rb.rows[r0 + o]) run_first.push_back(o);
+      run_of[o] = static_cast<int>(run_first.size()) - 1;
+      if (rowptr[rb.rows[r0 + o]] - rowptr[rb.rows[r0 + run_first.back()]] >= (1 << 20)) return fail("a run of rows is longer than 2^20 entries");
+    }
+    const int nruns = static_cast<int>(run_first.size());
+    if (nruns > kBpSegInts || nruns >= 2048) return fail("the rows of a block form too many runs");
+    // incidences of every owned row
+    std::vector<std::vector<Inc>> inc(R);
+    for (int p = rb.pair_ptr[b]; p < rb.pair_ptr[b + 1]; ++p) {
+      const uint32_t pk = rb.pairs[p];
+      const int o = pk >> 16, t = (pk >> 8) & 0xff, si = pk & 0xff;
+      inc[o].push_back({si, t, slot + (static_cast<size_t>(rb.elems[t0 + t]) * n + si) * n * slot_bytes});
+    }
+    std::map<std::vector<uint8_t>, int> class_of;
+    std::vector<RowClass> classes;
+    std::vector<uint8_t> key;
+    for (int o = 0; o < R; ++o) {
+      const int r = rb.rows[r0 + o];
+      const int len = rowptr[r + 1] - rowptr[r];
+      const bool fx = fixed && fixed[r];
+      std::vector<Inc> &v = inc[o];
+      const size_t sb = static_cast<size_t>(n) * slot_bytes;
+      std::sort(v.begin(), v.end(), [&](const Inc &a, const Inc &c) {
+        if (a.si != c.si) return a.si < c.si;
+        return std::memcmp(a.slots, c.slots, sb) < 0;
+      });
+      key.clear();
+      put24(key, len);
+      key.push_back(fx ? 1 : 0);
+      if (!fx)
+        for (const Inc &i : v) { key.push_back(static_cast<uint8_t>(i.si)); key.insert(key.end(), i.slots, i.slots + sb); }
+      auto it = class_of.find(key);
+      int c;
+      if (it == class_of.end()) {
+        c = static_cast<int>(classes.size());
+        class_of[key] = c;
+        RowClass rc;
+        rc.len = len;
+        rc.fixed = fx;
+        rc.ni = fx ? 0 : static_cast<int>(v.size());
+        if (!fx)
+          for (const Inc &i : v) {
+            rc.si.push_back(i.si);
+            std::vector<int> s(n);
+            for (int sj = 0; sj < n; ++sj)
+              s[sj] = slot_bytes == 1 ? i.slots[sj] : reinterpret_cast<const uint16_t *>(i.slots)[sj];
+            rc.slots.push_back(std::move(s));
+          }
+        rc.nct = (len + 15) / 16;
+        rc.stride = stride_for(rc.nct);
+        rc.ks = (rc.ni * ke + 3) / 4;
+        if (rc.ks > kBpMaxKSteps) return fail("a dof is shared by more elements than the pattern kernel holds");
+        rc.w_doubles = rc.ks * 4 * rc.stride;
+        if (rc.w_doubles > budget_doubles) return fail("a pattern matrix does not fit the LDS");
+        classes.push_back(std::move(rc));
+      } else {
+        c = it->second;
+      }
+      classes[c].inst_row.push_back(o);
+      std::vector<int> ts;
+      if (!fx)
+        for (const Inc &i : v) ts.push_back(i.t);
+      classes[c].inst_t.push_back(std::move(ts));
+    }
+    // LDS bins: first fit, largest W first
+    std::vector<int> order(classes.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return classes[a].w_doubles > classes[c].w_doubles; });
+    std::vector<int> bin_fill;
+    for (int c : order) {
+      RowClass &rc = classes[c];
+      int bin = -1;
+      for (size_t k = 0; k < bin_fill.size(); ++k)
+        if (bin_fill[k] + rc.w_doubles <= budget_doubles) { bin = static_cast<int>(k); break; }
+      if (bin < 0) { bin = static_cast<int>(bin_fill.size()); bin_fill.push_back(0); }
+      rc.bin = bin;
+      rc.w_off = bin_fill[bin];
+      bin_fill[bin] += rc.w_doubles;
+    }
+    if (bin_fill.empty()) bin_fill.push_back(0);
+    const int first_role = static_cast<int>(roles.size());
+    std::vector<size_t> role_woff(bin_fill.size());
+    for (size_t k = 0; k < bin_fill.size(); ++k) {
+      role_woff[k] = pl.w.size();
+      pl.w.resize(pl.w.size() + 2 * static_cast<size_t>(bin_fill[k]), 0.0);  // stiffness rows | mass rows
+      pl.max_w_doubles = std::max(pl.max_w_doubles, bin_fill[k]);
+      RoleBuild rbld;
+      rbld.pattern = pat;
+      rbld.bin = static_cast<int>(k);
+      rbld.R = R;
+      rbld.T = T;
+      rbld.nruns = nruns;
+      rbld.w_doubles = bin_fill[k];
+      rbld.w_off = static_cast<int64_t>(role_woff[k]);
+      rbld.wave_parts.assign(kBpWaves, {});
+      roles.push_back(std::move(rbld));
+    }
+    // W images
+    for (RowClass &rc : classes) {
+      if (rc.fixed) continue;
+      double *W = pl.w.data() + role_woff[rc.bin] + rc.w_off;
+      const size_t mass = static_cast<size_t>(bin_fill[rc.bin]);  // offset of the mass half of the role's image
+      for (int k = 0; k < rc.ni; ++k)
+        for (int sj = 0; sj < n; ++sj)
+          for (int m = 0; m < ke; ++m)
+            W[(m == nsym ? mass : 0) + static_cast<size_t>(k * ke + m) * rc.stride + rc.slots[k][sj]] +=
+                khat[m * nn + static_cast<size_t>(rc.si[k]) * n + sj];
+    }
+    // tiles of 16 instances, split into parts by phase so that all wavefronts carry a similar load
+    struct Tile { int cls, tile; int64_t cost; };
+    std::vector<std::vector<Tile>> tiles(bin_fill.size());
+    for (size_t c = 0; c < classes.size(); ++c) {
+      const RowClass &rc = classes[c];
+      const int ntile = (static_cast<int>(rc.inst_row.size()) + 15) / 16;
+      for (int t = 0; t < ntile; ++t)
+        tiles[rc.bin].push_back({static_cast<int>(c), t, static_cast<int64_t>(rc.nct) * (rc.ks + 4)});
+    }
+    for (size_t k = 0; k < bin_fill.size(); ++k) {
+      RoleBuild &role = roles[first_role + k];
+      int64_t total = 0;
+      for (const Tile &t : tiles[k]) total += t.cost;
+      role.cost = total;
+      const double target = std::max(1.0, static_cast<double>(total) / kBpWaves);
+      struct PartBuild { int cls, tile, phase, nphase; double cost; };
+      std::vector<PartBuild> parts;
+      for (const Tile &t : tiles[k]) {
+        const int ns = std::max(1, std::min(kBpWaves, static_cast<int>(std::lround(t.cost / target))));
+        for (int ph = 0; ph < ns; ++ph) parts.push_back({t.cls, t.tile, ph, ns, static_cast<double>(t.cost) / ns});
+      }
+      std::stable_sort(parts.begin(), parts.end(), [](const PartBuild &a, const PartBuild &c) { return a.cost > c.cost; });
+      std::vector<double> load(kBpWaves, 0.0);
+      for (const PartBuild &pb : parts) {
+        const int wv = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+        load[wv] += pb.cost;
+        const RowClass &rc = classes[pb.cls];
+        const int pidx = pl.num_parts++;
+        role.wave_parts[wv].push_back(pidx);
+        int32_t hdr[kBpHdrInts] = {0};
+        hdr[H_WOFF] = rc.w_off;
+        hdr[H_KS] = rc.ks;
+        hdr[H_NCT] = rc.nct;
+        hdr[H_LEN] = rc.len;
+        hdr[H_PHASE] = pb.phase;
+        hdr[H_NPHASE] = pb.nphase;
+        hdr[H_FLAGS] = rc.fixed ? 1 : 0;
+        hdr[H_CLASS] = pl.num_classes + pb.cls;
+        pl.part_hdr.insert(pl.part_hdr.end(), hdr, hdr + kBpHdrInts);
+        const size_t base = pl.part_lane.size();
+        pl.part_lane.resize(base + static_cast<size_t>(kBpLaneRows) * 64, 0);
+        int32_t *L = pl.part_lane.data() + base;
+        const int ninst = static_cast<int>(rc.inst_row.size());
+        const int zero_off = T * kBpRecDoubles;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, kk = lane >> 4;
+          const int inst = pb.tile * 16 + i;
+          for (int s = 0; s < kBpMaxKSteps; ++s) {
+            const int kidx = 4 * s + kk;
+            int off = zero_off;
+            if (inst < ninst && !rc.fixed && kidx < rc.ni * ke) {
+              const int kel = kidx / ke, m = kidx % ke;
+              off = rc.inst_t[inst][kel] * kBpRecDoubles + m;
+            }
+            L[s * 64 + lane] = off;
+          }
+          for (int t = 0; t < 4; ++t) {
+            const int r = kk + 4 * t;  // result register t of this lane belongs to tile row (lane >> 4) + 4 t
+            const int instr = pb.tile * 16 + r;
+            // run of consecutive rows the result row lies in and its CRS offset relative to the run's first row
+            // (both part of the pattern), -1 = no row
+            int packed = -1;
+            if (instr < ninst) {
+              const int o = rc.inst_row[instr];
+              packed = (run_of[o] << 20) | (rowptr[rb.rows[r0 + o]] - rowptr[rb.rows[r0 + run_first[run_of[o]]]]);
+            }
+            L[(16 + t) * 64 + lane] = packed;
+          }
+          {  // the same for tile row (lane & 15): what the row-contiguous stores of the kernel consult
+            const int instr = pb.tile * 16 + i;
+            int packed = -1;
+            if (instr < ninst) {
+              const int o = rc.inst_row[instr];
+              packed = (run_of[o] << 20) | (rowptr[rb.rows[r0 + o]] - rowptr[rb.rows[r0 + run_first[run_of[o]]]]);
+            }
+            L[20 * 64 + lane] = packed;
+          }
+        }
+      }
+    }
+    pl.num_classes += static_cast<int>(classes.size());
+  }
+
+  // ---- 3. (workgroups are cut after the block tables: step 5) ----
+  pl.num_roles = static_cast<int>(roles.size());
+
+  // ---- 4. role records, block-major tables ----
+  pl.role.assign(static_cast<size_t>(pl.num_roles) * kBpRoleInts, 0);
+  pl.part_ptr.assign(static_cast<size_t>(pl.num_roles) * (kBpWaves + 1), 0);
+  // parts must be contiguous per (role, wave): renumber
+  {
+    std::vector<int32_t> new_hdr, new_lane;
+    new_hdr.reserve(pl.part_hdr.size());
+    new_lane.reserve(pl.part_lane.size());
+    int next = 0;
+    for (int k = 0; k < pl.num_roles; ++k)
+      for (int wv = 0; wv <= kBpWaves; ++wv) {
+        pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv] = next;
+        if (wv == kBpWaves) break;
+        for (int pidx : roles[k].wave_parts[wv]) {
+          new_hdr.insert(new_hdr.end(), pl.part_hdr.begin() + static_cast<size_t>(pidx) * kBpHdrInts,
+                         pl.part_hdr.begin() + static_cast<size_t>(pidx + 1) * kBpHdrInts);
+          new_lane.insert(new_lane.end(), pl.part_lane.begin() + static_cast<size_t>(pidx) * kBpLaneRows * 64,
+                          pl.part_lane.begin() + static_cast<size_t>(pidx + 1) * kBpLaneRows * 64);
+          ++next;
+        }
+      }
+    pl.part_hdr.swap(new_hdr);
+    pl.part_lane.swap(new_lane);
+  }
+  for (int k = 0; k < pl.num_roles; ++k) {
+    const RoleBuild &r = roles[k];
+    const std::vector<int32_t> &blocks = members[r.pattern];
+    int32_t *ro = &pl.role[static_cast<size_t>(k) * kBpRoleInts];
+    const int64_t erec_base = static_cast<int64_t>(pl.erec_elem.size());
+    const int64_t row_base = static_cast<int64_t>(pl.rowbase.size());
+    ro[R_EREC_LO] = static_cast<int32_t>(erec_base & 0xffffffffll);
+    ro[R_EREC_HI] = static_cast<int32_t>(erec_base >> 32);
+    ro[R_ESTRIDE] = r.T + 1;
+    ro[R_ROWB_LO] = static_cast<int32_t>(row_base & 0xffffffffll);
+    ro[R_ROWB_HI] = static_cast<int32_t>(row_base >> 32);
+    ro[R_NRUNS] = r.nruns;
+    ro[R_NBLOCKS] = static_cast<int32_t>(blocks.size());
+    ro[R_COST] = static_cast<int32_t>(std::min<int64_t>(r.cost, 0x7fffffff));
+    ro[R_WOFF_LO] = static_cast<int32_t>(r.w_off & 0xffffffffll);
+    ro[R_WOFF_HI] = static_cast<int32_t>(r.w_off >> 32);
+    ro[R_WDOUBLES] = r.w_doubles;
+    ro[R_PATTERN] = r.pattern;
+    ro[R_NELEMS] = r.T;
+    for (int32_t b : blocks) {
+      for (int t = rb.elem_ptr[b]; t < rb.elem_ptr[b + 1]; ++t) pl.erec_elem.push_back(rb.elems[t]);
+      pl.erec_elem.push_back(-1);
+      for (int o = rb.row_ptr[b]; o < rb.row_ptr[b + 1]; ++o)  // CRS offset of the first row of every run
+        if (o == rb.row_ptr[b] || rb.rows[o - 1] + 1 != rb.rows[o]) pl.rowbase.push_back(rb.row_base[o]);
+    }
+    int64_t mf = 0;
+    for (int wv = 0; wv < kBpWaves; ++wv)
+      for (int p = pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv]; p < pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv + 1]; ++p) {
+        const int32_t *h = &pl.part_hdr[static_cast<size_t>(p) * kBpHdrInts];
+        mf += static_cast<int64_t>(h[H_KS]) * h[H_NCT] * ((static_cast<int64_t>(blocks.size()) + h[H_NPHASE] - 1 - h[H_PHASE]) / h[H_NPHASE]);  // as if one segment
+      }
+    pl.mfma_per_assembly += mf;
+  }
+  // ---- 5. persistent workgroups, exactly one per CU: the role-major block sequence is cut into num_cus contiguous
+  //         pieces of equal cost; a piece that crosses a role boundary becomes several SEGMENTS (the workgroup reloads
+  //         the LDS image between them), so small roles cost no extra workgroup and nobody waits for a free CU ----
+  {
+    double total_cost = 0.0;
+    for (const RoleBuild &r : roles) total_cost += static_cast<double>(members[r.pattern].size()) * std::max<int64_t>(1, r.cost);
+    const int nwg = std::max(1, num_cus);
+    pl.wg_seg_ptr.assign(1, 0);
+    double done = 0.0;
+    int wg = 0;
+    for (int k = 0; k < pl.num_roles; ++k) {
+      const double c = static_cast<double>(std::max<int64_t>(1, roles[k].cost));
+      const int nb = static_cast<int>(members[roles[k].pattern].size());
+      int first = 0;
+      while (first < nb) {
+        // blocks of this role the current workgroup still takes: up to its share boundary
+        const double bound = total_cost * (wg + 1) / nwg;
+        int take = static_cast<int>(std::floor((bound - done) / c + 0.5));
+        if (wg == nwg - 1) take = nb - first;
+        int seg_cap = std::max(1, kBpSegInts / roles[k].nruns);
+        if (seg_blocks > 0) seg_cap = std::min(seg_cap, seg_blocks);
+        const bool capped = take > seg_cap;
+        take = std::max(0, std::min(take, nb - first));
+        take = std::min(take, seg_cap);  // the kernel keeps a segment's run offsets in LDS
+        if (take > 0) {
+          pl.seg.push_back(k);
+          pl.seg.push_back(first);
+          pl.seg.push_back(take);
+          pl.seg.push_back(0);
+          first += take;
+          done += take * c;
+        }
+        if ((first < nb && !capped) || (first >= nb && done >= bound - 0.5 * c)) {
+          if (wg < nwg - 1) {
+            pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
+            ++wg;
+          }
+        }
+      }
+    }
+    while (static_cast<int>(pl.wg_seg_ptr.size()) < nwg + 1) pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
+    pl.wg_seg_ptr.back() = static_cast<int32_t>(pl.seg.size() / 4);
+    pl.num_wgs = nwg;
+  }
+  pl.usable = true;
+  return pl;
+}
+
+void block_patterns_host_apply(const BlockPatternPlan &pl, const double *factors, double su, double st, bool overwrite,
+                               double *vals) {
+  MHA_REQUIRE(pl.usable, MHA_ERR_STATE, "block patterns not usable: " << pl.why);
+  const int ke = pl.ke;
+  std::vector<double> rec;
+  for (int wg = 0; wg < pl.num_wgs; ++wg)
+  for (int sg = pl.wg_seg_ptr[wg]; sg < pl.wg_seg_ptr[wg + 1]; ++sg) {
+    const int role = pl.seg[4 * sg], first = pl.seg[4 * sg + 1], nseg = pl.seg[4 * sg + 2];
+    const int32_t *ro = &pl.role[static_cast<size_t>(role) * kBpRoleInts];
+    const int64_t erec_base = (static_cast<int64_t>(ro[R_EREC_HI]) << 32) | static_cast<uint32_t>(ro[R_EREC_LO]);
+    const int64_t row_base = (static_cast<int64_t>(ro[R_ROWB_HI]) << 32) | static_cast<uint32_t>(ro[R_ROWB_LO]);
+    const int estride = ro[R_ESTRIDE], nruns = ro[R_NRUNS];
+    MHA_REQUIRE(first >= 0 && first + nseg <= ro[R_NBLOCKS], MHA_ERR_STATE, "segment outside its role");
+    const double *Wrole = pl.w.data() + ((static_cast<int64_t>(ro[R_WOFF_HI]) << 32) | static_cast<uint32_t>(ro[R_WOFF_LO]));
+    for (int wv = 0; wv < kBpWaves; ++wv)
+      for (int p = pl.part_ptr[static_cast<size_t>(role) * (kBpWaves + 1) + wv]; p < pl.part_ptr[static_cast<size_t>(role) * (kBpWaves + 1) + wv + 1]; ++p) {
+        const int32_t *h = &pl.part_hdr[static_cast<size_t>(p) * kBpHdrInts];
+        const int32_t *L = &pl.part_lane[static_cast<size_t>(p) * kBpLaneRows * 64];
+        const int ks = h[H_KS], nct = h[H_NCT], len = h[H_LEN], stride = stride_for(nct);
+        const bool fixed_class = h[H_FLAGS] & 1;
+        if (fixed_class && !overwrite) continue;
+        const double *W = Wrole + h[H_WOFF], *Wm = W + ro[R_WDOUBLES];
+        for (int i = h[H_PHASE];; i += h[H_NPHASE]) {
+          if (i >= nseg) break;
+          const int64_t j = first + i;
+          // the block's element records, as build_erec2_kernel lays them out
+          rec.assign(static_cast<size_t>(estride) * kBpRecDoubles, 0.0);
+          for (int t = 0; t < estride; ++t) {
+            const int e = pl.erec_elem[static_cast<size_t>(erec_base + j * estride + t)];
+            if (e >= 0)
+              for (int m = 0; m < ke; ++m) rec[static_cast<size_t>(t) * kBpRecDoubles + m] = factors[static_cast<size_t>(e) * ke + m];
+          }
+          for (int row = 0; row < 16; ++row) {
+            // result rows live in lanes (row & 3) << 4 .. with register t = row >> 2
+            const int packed = L[(16 + (row >> 2)) * 64 + ((row & 3) << 4)];
+            MHA_REQUIRE(packed == L[20 * 64 + row] && packed == L[20 * 64 + 48 + row], MHA_ERR_STATE, "row tables of a part disagree");
+            if (packed < 0) continue;
+            const int base = pl.rowbase[static_cast<size_t>(row_base + j * nruns + (packed >> 20))] + (packed & 0xfffff);
+            for (int c = 0; c < len; ++c) {
+              double v = 0.0;
+              for (int s = 0; s < ks; ++s)
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int lane = kk * 16 + row;  // A operand: row = lane & 15, k = 4 s + (lane >> 4)
+                  const size_t wi = static_cast<size_t>(4 * s + kk) * stride + c;
+                  v += rec[L[s * 64 + lane]] * (su * W[wi] + st * Wm[wi]);
+                }
+              if (overwrite) vals[base + c] = fixed_class ? 0.0 : v;
+              else vals[base + c] += v;
+            }
+          }
+        }
+      }
+  }
+}
+
+}  // namespace mha

@@ -8,7 +8,8 @@
 #include "expression.hpp"
 #include "mesh.hpp"
 #include "row_blocks.hpp"
-#include "row_pattern.hpp"
+#include "block_pattern.hpp"
+#include "test_hooks.h"
 #include "scatter_plan.hpp"
 
 struct mha_row_partition {
@@ -359,16 +360,14 @@ int mha_scatter_plan_apply(const mha_scatter_plan *p, const double *blocks_dev, 
 
 void mha_scatter_plan_destroy(mha_scatter_plan *p) { delete p; }
 
-int mha_row_patterns_host_apply(int num_rows, int num_elems, int n, int nsym, const int32_t *lids,
-                                const int32_t *rowptr, const int32_t *colind, const uint8_t *fixed,
-                                const double *khat, const double *factors, double *vals, int *num_patterns,
-                                int *num_super_tiles) {
+int mha_test_block_patterns_host_apply(int dim, int num_rows, int num_elems, int nnodes, int n, int nsym,
+                                       const double *nodes, const int32_t *lids, const int32_t *rowptr,
+                                       const int32_t *colind, const uint8_t *fixed, const double *khat,
+                                       const double *factors, double scale_u, double scale_t, int chunk_elems,
+                                       int num_cus, int max_patterns, double *vals, int *counts) {
   return guarded([&] {
-    MHA_REQUIRE(lids && rowptr && colind && khat && factors && vals && num_patterns && num_super_tiles, MHA_ERR_INVALID,
-                "null argument");
+    MHA_REQUIRE(nodes && lids && rowptr && colind && khat && factors && vals && counts, MHA_ERR_INVALID, "null argument");
     MHA_REQUIRE(num_rows > 0 && num_elems > 0 && n > 0 && n <= 255 && nsym > 0, MHA_ERR_INVALID, "bad sizes");
-    std::vector<int32_t> ptr, elem, lpos;
-    mha::build_row_incidence(num_rows, num_elems, n, lids, ptr, elem, lpos);
     // element-major slot map by column search (the device builds the same map in build_elem_slot_map_kernel)
     int max_row = 0;
     for (int r = 0; r < num_rows; ++r) max_row = std::max(max_row, rowptr[r + 1] - rowptr[r]);
@@ -386,36 +385,22 @@ int mha_row_patterns_host_apply(int num_rows, int num_elems, int n, int nsym, co
           else reinterpret_cast<uint16_t *>(slot.data())[idx] = static_cast<uint16_t>(it - lo);
         }
       }
-    const mha::RowPatterns rp = mha::build_row_patterns(num_rows, n, nsym, rowptr, fixed, ptr, elem, lpos, slot.data(),
-                                                        sb, khat, 8, 2, 4096, size_t(256) << 20, 76 * 1024);
-    MHA_REQUIRE(rp.usable, MHA_ERR_INVALID, "rows do not group: " << rp.why);
-    *num_patterns = rp.num_patterns;
-    *num_super_tiles = static_cast<int>(rp.st_pat.size());
-    const int ke = rp.ke, nst = *num_super_tiles;
-    MHA_REQUIRE(rp.wg_ptr.back() == nst, MHA_ERR_STATE, "workgroup ranges do not cover the tiles");
-    for (size_t w = 0; w + 1 < rp.wg_ptr.size(); ++w)
-      for (int s = rp.wg_ptr[w]; s < rp.wg_ptr[w + 1]; ++s) {
-        const int32_t *d = &rp.st_desc[static_cast<size_t>(s) * 8];
-        const int ni = d[1] & 0xff, len = d[1] >> 16, gstride = d[3] >> 16;
-        const int64_t rec = (static_cast<int64_t>(d[5]) << 32) | static_cast<uint32_t>(d[4]);
-        const int64_t woff = (static_cast<int64_t>(d[7]) << 32) | static_cast<uint32_t>(d[6]);
-        for (int wv = 0; wv < mha::kRowsPerSuperTile / 16; ++wv)
-          for (int l = 0; l < 16; ++l) {
-            const int32_t *p = &rp.st_rec[static_cast<size_t>(rec) + static_cast<size_t>(wv) * (2 + ni) * 16 + l];
-            const int base = p[0], meta = p[16], rlen = meta & 0x3fffffff;
-            if (rlen == 0) continue;
-            MHA_REQUIRE(rlen == len, MHA_ERR_STATE, "row length differs from its pattern");
-            for (int c = 0; c < rlen; ++c) {
-              double v = 0.0;
-              if (!(meta >> 30))
-                for (int k = 0; k < ni; ++k)
-                  for (int cc = 0; cc < ke; ++cc)
-                    v += factors[static_cast<size_t>(p[(2 + k) * 16]) * ke + cc] *
-                         rp.w[static_cast<size_t>(woff) + static_cast<size_t>(k * ke + cc) * gstride + c];
-              vals[base + c] = v;
-            }
-          }
-      }
+    mha::RowBlockCaps caps = mha::default_caps(dim, n);
+    caps.chunk_elems = chunk_elems > 0 ? chunk_elems : 16;
+    caps.max_rows = 4096;
+    caps.max_elems = 255;
+    caps.max_pairs = 1 << 20;
+    caps.max_acc = 1 << 30;
+    const mha::RowBlocks rb = mha::build_row_blocks(dim, nnodes, num_elems, n, num_rows, nodes, lids, rowptr, caps, fixed, 1);
+    const mha::BlockPatternPlan pl = mha::build_block_patterns(rb, n, nsym, rowptr, fixed, slot.data(), sb, khat,
+                                                               num_cus > 0 ? num_cus : 8, size_t(150) * 1024,
+                                                               max_patterns > 0 ? max_patterns : 256);
+    MHA_REQUIRE(pl.usable, MHA_ERR_INVALID, "row blocks do not group: " << pl.why);
+    counts[0] = pl.num_patterns;
+    counts[1] = pl.num_roles;
+    counts[2] = pl.num_wgs;
+    counts[3] = pl.num_parts;
+    mha::block_patterns_host_apply(pl, factors, scale_u, scale_t, true, vals);
   });
 }
 

@@ -111,6 +111,14 @@ struct AffineDev {
   int k1_dbg = 0;  // profiling aid (env MHA_K1_DBG): 1 no residual atomics, 2 no source evaluation, 4 no gather
 };
 
+// 1-D tables of the thread-per-element residual kernel (kernels/thermal_affine_residual.hip), passed by value: as many
+// integration points per direction as dofs (m = order + 1 <= 5).
+struct AffineTables1D {
+  double phi[25] = {0};   // [m][m]  phi_i(xi_q)
+  double dcol[25] = {0};  // [m][m]  collocation derivative: f'(xi_q) = sum_q' dcol[q][q'] f(xi_q')
+  double gw[5] = {0}, gp[5] = {0};
+};
+
 // Side reference tables on the device (ref_tables.hpp: SideTables).
 struct SideTablesDev {
   int nsides = 0, nqs = 0;
@@ -200,15 +208,16 @@ struct SwhElementDev {
   double *blocks = nullptr;              // [E][36][36] res(r).dx(c), stored
 };
 
-// Rows grouped by assembly pattern (row_pattern.hpp) for the matrix-core row-owner Jacobian.
-struct RowPatternDev {
-  int num_wgs = 0, ke = 0, nsym = 0, max_w_doubles = 0;
-  int dbg = 0;  // profiling aid (env MHA_RP_DBG): 1 no stores, 2 no matrix products, 4 no geometry gather
-  const double *w = nullptr;        // pattern matrices
-  const int32_t *st_desc = nullptr;  // [super tile][8] descriptors (row_pattern.hpp)
-  const int32_t *st_rec = nullptr;   // row records
-  const int32_t *wg_ptr = nullptr;
-  const double *geok = nullptr;  // [E][ke]: detJ (J^-1 J^-T)_sym, detJ, zero padding
+// Row blocks keyed by assembly pattern (block_pattern.hpp) for the matrix-core row-owner Jacobian.
+struct BlockPatternDev {
+  int num_wgs = 0, max_w_doubles = 0;
+  int dbg = 0;                         // profiling / cross-check aid (env MHA_BP_DBG): 1 plain-load form of every part, 2 no stores, 4 no products
+  const double *erec2 = nullptr;       // role-major, block-major element records [T + 1][8]
+  const int32_t *rowbase = nullptr;    // role-major, block-major CRS offsets of the owned rows [R]
+  const double *w = nullptr;           // LDS images of the roles
+  const int32_t *role = nullptr, *seg = nullptr, *wg_seg_ptr = nullptr, *part_ptr = nullptr, *part_hdr = nullptr, *part_lane = nullptr;
+  long long nnz = 0;                   // CRS entries (the kernel addresses them with 32-bit byte offsets: nnz < 2^28)
+  long long *timing = nullptr;         // profiling aid (env MHA_BP_TIMING): [num_wgs][16 waves][8] wall-clock stamps (10 ns)
 };
 
 // Destination of the row-owner kernels.

@@ -34,14 +34,19 @@ void launch_build_block_slots(const BlockDev &b, const RowBlocksDev &rb, void *b
 bool thermal_row_owner_supported(int dim, int order, int nq1);
 size_t row_owner_jacobian_lds(const RowBlocksDev &rb, int n, int slot_bytes);
 void launch_affine_geometry(const BlockDev &b, double *geo, hipStream_t stream);
-// row_pattern.hip: packed geometry factors [E][ke] from the geometry cache; the pattern GEMM form of the row-owner Jacobian
-void launch_build_geok(int nelem, int nsym, int ke, const double *geo, double *geok, hipStream_t stream);
-void launch_row_pattern_jacobian(const RowPatternDev &rp, const RowOut &out, double su, double st, hipStream_t stream);
+// block_pattern.hip: block-major element records from the geometry cache; the matrix-core form of the row-owner Jacobian
+void launch_build_erec2(int64_t total_records, int nsym, const int32_t *erec_elem, const double *geo, double *erec2,
+                        hipStream_t stream);
+void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, double su, double st, hipStream_t stream);
 void launch_build_erec(int dim, const RowBlocksDev &rb, const double *geo, double *erec, int total,
                        hipStream_t stream);
 // K1: element-wise residual (-> res with atomics)
 void launch_thermal_affine_element(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph,
                                    const AffineDev &af, double *res, hipStream_t stream);
+// thermal_affine_residual.hip: the same residual, one thread per element (sum-factorised through the point values)
+bool thermal_affine_residual_supported(int dim, int order, int nq1);
+void launch_thermal_affine_residual(int dim, int order, const BlockDev &b, const ThermalDev &ph, const double *geo,
+                                    const AffineTables1D &tab, double *res, hipStream_t stream);
 // K2: row-owner Jacobian; scale_u = alpha_u*kappa, scale_t = alpha_t*rho*cp
 void launch_row_owner_jacobian(int dim, int n, const RowBlocksDev &rb, const AffineDev &af, const RowOut &out,
                                double scale_u, double scale_t, hipStream_t stream);

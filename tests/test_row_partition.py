@@ -69,15 +69,17 @@ def test_partition_rejects_impossible_caps(oracle):
     assert ei.value.code == 1 and "exceeds" in str(ei.value)
 
 
-# ---- pattern grouping behind MHA_K2=pattern (csrc/row_pattern.{hpp,cpp}), walked on the host as the kernel walks it ----
+# ---- block patterns of the matrix-core row-owner Jacobian (csrc/block_pattern.{hpp,cpp}), walked on the host as the
+# ---- kernel walks them (workgroup -> wavefront -> part -> block -> MFMA panel)
 
-def _pattern_reference(m, rowptr, colind, khat, factors, fixed=None):
-    """vals[row(e,si)][col(e,sj)] += sum_c factors[e][c] * khat[c][si][sj], fixed rows zero: plain element loop."""
+def _pattern_reference(m, rowptr, colind, khat, factors, fixed=None, scale=None):
+    """vals[row(e,si)][col(e,sj)] += sum_c scale_c factors[e][c] * khat[c][si][sj], fixed rows zero: plain element loop."""
     n = m["lids"].shape[1]
     vals = np.zeros(len(colind))
     ncomp = khat.shape[0]
+    sc = np.ones(ncomp) if scale is None else np.asarray(scale)
     for e, L in enumerate(m["lids"]):
-        K = np.tensordot(factors[e, :ncomp], khat, axes=(0, 0)).reshape(n, n)
+        K = np.tensordot(factors[e, :ncomp] * sc, khat, axes=(0, 0)).reshape(n, n)
         for si in range(n):
             r = L[si]
             if fixed is not None and fixed[r]:
@@ -87,40 +89,55 @@ def _pattern_reference(m, rowptr, colind, khat, factors, fixed=None):
     return vals
 
 
-@pytest.mark.parametrize("dim,order,ncell", [(3, 2, (4, 3, 3)), (3, 1, (4, 4, 3)), (2, 1, (7, 5)), (2, 2, (5, 4)),
-                                              (2, 4, (3, 3))])
-def test_row_patterns_reproduce_the_element_scatter(oracle, dim, order, ncell):
+@pytest.mark.parametrize("dim,order,ncell,chunk", [(3, 2, (8, 4, 4), 16), (3, 2, (4, 3, 3), 16), (3, 1, (4, 4, 3), 16),
+                                                    (2, 1, (7, 5), 16), (2, 2, (8, 8), 16), (2, 4, (3, 3), 4),
+                                                    (3, 2, (4, 4, 4), 8)])
+def test_block_patterns_reproduce_the_element_scatter(oracle, dim, order, ncell, chunk):
     m = mrhyde_amd.mesh_structured(dim, order, ncell)
     nrows = m["ndof"]
     rowptr, colind = oracle.build_graph(nrows, m["lids"])
     n = m["lids"].shape[1]
     nsym = dim * (dim + 1) // 2
-    depth = (nsym + 1 + 3) // 4 * 4
     rng = np.random.default_rng(31)
     khat = rng.uniform(-1, 1, (nsym + 1, n * n))      # any tables: the grouping does not look at their values
-    factors = np.zeros((m["nelem"], depth))
-    factors[:, :nsym + 1] = rng.uniform(0.5, 2.0, (m["nelem"], nsym + 1))
+    factors = rng.uniform(0.5, 2.0, (m["nelem"], nsym + 1))
     fixed = (rng.uniform(size=nrows) < 0.1).astype(np.uint8)
-    vals, npat, nst = mrhyde_amd.row_patterns_host_apply(m["lids"], nrows, rowptr, colind, khat, factors, fixed)
-    ref = _pattern_reference(m, rowptr, colind, khat, factors, fixed)
+    su, st = 1.7, -0.3
+    vals, counts = mrhyde_amd.block_patterns_host_apply(dim, m["nodes"], m["lids"], nrows, rowptr, colind, khat, factors,
+                                                        fixed, scale_u=su, scale_t=st, chunk_elems=chunk,
+                                                        max_patterns=4096)
+    ref = _pattern_reference(m, rowptr, colind, khat, factors, fixed, scale=[su] * nsym + [st])
     assert not np.any(np.isnan(vals)), "every CRS entry written exactly once"
     assert np.max(np.abs(vals - ref)) <= 1e-12 * np.max(np.abs(ref))
-    # a tensor mesh has few patterns: per direction a dof is a vertex (left end, interior, right end) or lies inside
-    # one cell (order - 1 positions, each possibly in the first / an interior / the last cell)
-    assert 0 < npat <= (3 + 3 * (order - 1)) ** dim
-    assert nst >= npat
+    assert counts[0] >= 1 and counts[1] >= counts[0] and counts[2] == 8 and counts[3] >= counts[1]  # one workgroup per CU
 
 
-def test_row_patterns_reject_unstructured_numbering(oracle):
-    """A random renumbering of the dofs gives (nearly) every row its own slot pattern: the grouping must refuse
-    (the caller then keeps the row-block kernel) rather than build one matrix per row."""
-    m = mrhyde_amd.mesh_structured(3, 2, (8, 8, 8))  # 4913 rows > the 4096 patterns the grouping accepts
+def test_block_patterns_of_a_structured_mesh_are_few(oracle):
+    """64^3-style case in small: 4x2x2-element chunks; per direction a chunk is first / interior / last."""
+    m = mrhyde_amd.mesh_structured(3, 2, (16, 8, 8))
+    nrows = m["ndof"]
+    rowptr, colind = oracle.build_graph(nrows, m["lids"])
+    n = m["lids"].shape[1]
+    rng = np.random.default_rng(33)
+    khat = rng.uniform(-1, 1, (7, n * n))
+    factors = rng.uniform(0.5, 2.0, (m["nelem"], 7))
+    vals, counts = mrhyde_amd.block_patterns_host_apply(3, m["nodes"], m["lids"], nrows, rowptr, colind, khat, factors,
+                                                        m["boundary"], num_cus=32)
+    ref = _pattern_reference(m, rowptr, colind, khat, factors, m["boundary"])
+    assert np.max(np.abs(vals - ref)) <= 1e-12 * np.max(np.abs(ref))
+    assert counts[0] == 27 and counts[1] == 27
+
+
+def test_block_patterns_reject_unstructured_numbering(oracle):
+    """A random renumbering of the dofs gives (nearly) every block its own pattern: the grouping must refuse
+    (the caller then keeps the row-block kernel) rather than build one set of tables per block."""
+    m = mrhyde_amd.mesh_structured(3, 2, (8, 8, 8))
     rng = np.random.default_rng(32)
     perm = rng.permutation(m["ndof"]).astype(np.int32)
     lids = perm[m["lids"]]
     rowptr, colind = oracle.build_graph(m["ndof"], lids)
     n = lids.shape[1]
     khat = rng.uniform(-1, 1, (7, n * n))
-    factors = rng.uniform(0.5, 2.0, (lids.shape[0], 8))
+    factors = rng.uniform(0.5, 2.0, (lids.shape[0], 7))
     with pytest.raises(mrhyde_amd.MhaError, match="patterns"):
-        mrhyde_amd.row_patterns_host_apply(lids, m["ndof"], rowptr, colind, khat, factors)
+        mrhyde_amd.block_patterns_host_apply(3, m["nodes"], lids, m["ndof"], rowptr, colind, khat, factors, max_patterns=16)

@@ -271,8 +271,8 @@ RO_CASES = [  # dim, order, qdeg, ncell
 @pytest.mark.parametrize("k2", ["blocks", "pattern"])
 def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, mode, k2):
     """Fused row-owner kernel on affine (sheared) meshes vs the oracle: CRS values, residual, fixed rows.
-    k2 = pattern: the Jacobian rows as pattern GEMMs on the matrix cores (MHA_K2=pattern, row_pattern.hip) and the
-    element residual kernel in its matrix-core form (MHA_K1=mfma)."""
+    k2 = pattern (the default): the Jacobian rows as block-pattern GEMMs on the matrix cores (block_pattern.hip);
+    k2 = blocks: the LDS-accumulator row-block kernel (the fallback for meshes whose blocks do not group)."""
     torch = _torch()
     import mrhyde_amd
     monkeypatch.setenv("MHA_K2", k2)
@@ -297,7 +297,7 @@ def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, 
     blk.assemble_jacres(ud, res, vals, path=mrhyde_amd.PATH_ROW_OWNER, overwrite=(mode == "overwrite"))
     torch.cuda.synchronize()
     assert blk.info("num_affine_elems") == m["nelem"] and blk.info("last_path") == mrhyde_amd.PATH_ROW_OWNER
-    assert (blk.info("row_patterns") > 0) == (k2 == "pattern")
+    assert (blk.info("block_patterns") > 0) == (k2 == "pattern")
     assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
     assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
     v = vals.cpu().numpy()
