@@ -1015,9 +1015,8 @@ void AssemblyManager::prepareBlockPattern() {
   BlockPatternData &bp = bpat_;
   bp.tried = true;
   bp.usable = false;
-  // opt-in while it is being tuned (profiles/README.md, round 2): parity-green, 0.53 ms against 0.47 ms for the row blocks
   const char *mode = std::getenv("MHA_K2");
-  if (!mode || std::string(mode) != "pattern") { bp.why = "not requested (MHA_K2=pattern)"; return; }
+  if (mode && std::string(mode) == "blocks") { bp.why = "row-block kernel requested (MHA_K2=blocks)"; return; }
   if (ro_.num_general_blocks > 0) { bp.why = "block has non-affine elements"; return; }
   if (static_cast<long long>(h_rowptr_[nrows_]) >= (1ll << 28)) { bp.why = "more than 2^28 CRS entries (32-bit byte offsets)"; return; }
   // its own partition: larger Morton chunks (16 elements = 16 rows of every class of a Q2 hex block: whole MFMA panels),
@@ -1052,7 +1051,7 @@ void AssemblyManager::prepareBlockPattern() {
   MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
   if (const char *m = std::getenv("MHA_BP_WGS")) num_cu = std::max(1, std::atoi(m));
   const BlockPatternPlan h = build_block_patterns(rb, n_, nsym, h_rowptr_.data(), has_fixed_ ? h_fixed_.data() : nullptr,
-                                                  slot.data(), elem_slot_bytes_, khat.data(), num_cu, size_t(150) * 1024, 256,
+                                                  slot.data(), elem_slot_bytes_, khat.data(), num_cu, size_t(142) * 1024, 256,
                                                   std::getenv("MHA_BP_SEGBLOCKS") ? std::atoi(std::getenv("MHA_BP_SEGBLOCKS")) : 0);
   bp.why = h.why;
   if (std::getenv("MHA_VERBOSE"))
@@ -1078,6 +1077,7 @@ void AssemblyManager::prepareBlockPattern() {
   BlockPatternDev &d = bp.dev;
   d.num_wgs = h.num_wgs;
   d.max_w_doubles = h.max_w_doubles;
+  d.max_rec_doubles = h.max_rec_doubles;
   d.dbg = 0;
   if (const char *m = std::getenv("MHA_BP_DBG")) d.dbg = std::atoi(m);
   d.erec2 = bp.erec2.data();

@@ -18,7 +18,7 @@ namespace {
 enum { R_EREC_LO = 0, R_EREC_HI, R_ESTRIDE, R_ROWB_LO, R_ROWB_HI, R_NRUNS, R_NBLOCKS, R_COST, R_WOFF_LO, R_WOFF_HI,
        R_WDOUBLES, R_PATTERN, R_NELEMS };
 // part header (kBpHdrInts ints)
-enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_PHASE, H_NPHASE, H_FLAGS, H_CLASS };
+enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_CT0, H_NTILE, H_FLAGS, H_CLASS, H_MASK0, H_MASK1, H_MASK2 };  // flags: 1 rows of fixed dofs, 2 a plain tail tile follows the group
 
 uint64_t fnv1a(const std::vector<uint8_t> &b) {
   uint64_t h = 1469598103934665603ull;
@@ -124,7 +124,8 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
     const int b = rep[pat];
     const int r0 = rb.row_ptr[b], R = rb.row_ptr[b + 1] - r0;
     const int t0 = rb.elem_ptr[b], T = rb.elem_ptr[b + 1] - t0;
-    if ((T + 1) * kBpRecDoubles >= 65536) return fail("a block touches too many elements");
+    if ((T + 1) * kBpRecDoubles > 512) return fail("a block touches more elements than the record loader fetches (63)");
+    pl.max_rec_doubles = std::max(pl.max_rec_doubles, (T + 1) * kBpRecDoubles);
     // runs of consecutive rows: contiguous in the CRS value array, so one offset per (block, run) locates every row
     std::vector<int> run_of(R), run_first;
     for (int o = 0; o < R; ++o) {
@@ -236,7 +237,12 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
             W[(m == nsym ? mass : 0) + static_cast<size_t>(k * ke + m) * rc.stride + rc.slots[k][sj]] +=
                 khat[m * nn + static_cast<size_t>(rc.si[k]) * n + sj];
     }
-    // tiles of 16 instances, split into parts by phase so that all wavefronts carry a similar load
+    // tiles of 16 instances, cut into UNITS of up to four column tiles (what one wavefront computes and stores per
+    // block: the products of a unit are transposed so that every store writes 64 consecutive entries of one row); a
+    // single left-over tile rides with the group before it, two or three form a unit of their own.  All wavefronts of
+    // a workgroup work on the same block at the same time (the rows of a block are neighbours in memory: written
+    // within microseconds of each other they leave the L2 as whole DRAM pages), so the units -- not blocks -- are what
+    // is dealt to the wavefronts, heaviest first.
     struct Tile { int cls, tile; int64_t cost; };
     std::vector<std::vector<Tile>> tiles(bin_fill.size());
     for (size_t c = 0; c < classes.size(); ++c) {
@@ -250,18 +256,33 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
       int64_t total = 0;
       for (const Tile &t : tiles[k]) total += t.cost;
       role.cost = total;
-      const double target = std::max(1.0, static_cast<double>(total) / kBpWaves);
-      struct PartBuild { int cls, tile, phase, nphase; double cost; };
+      struct PartBuild { int cls, tile, ct0, ntile, tail; double cost; };
       std::vector<PartBuild> parts;
       for (const Tile &t : tiles[k]) {
-        const int ns = std::max(1, std::min(kBpWaves, static_cast<int>(std::lround(t.cost / target))));
-        for (int ph = 0; ph < ns; ++ph) parts.push_back({t.cls, t.tile, ph, ns, static_cast<double>(t.cost) / ns});
+        const RowClass &rc = classes[t.cls];
+        const int ng = rc.nct / 4, rem = rc.nct % 4;
+        for (int g = 0; g < ng; ++g) {
+          const int tail = (g == ng - 1 && rem == 1) ? 1 : 0;
+          parts.push_back({t.cls, t.tile, 4 * g, 4, tail, static_cast<double>((4 + tail) * (rc.ks + 1))});
+        }
+        if (ng == 0 && rem == 1) parts.push_back({t.cls, t.tile, 0, 0, 1, static_cast<double>(rc.ks + 1)});
+        if (rem >= 2) parts.push_back({t.cls, t.tile, 4 * ng, rem, 0, static_cast<double>(rem * (rc.ks + 1) + 2)});
       }
       std::stable_sort(parts.begin(), parts.end(), [](const PartBuild &a, const PartBuild &c) { return a.cost > c.cost; });
+      // units of fixed rows (zeros, no products) go to wavefronts that carry no products when there are any: the
+      // kernel's fast forms take wavefronts whose units are all of one kind
+      std::stable_partition(parts.begin(), parts.end(), [&](const PartBuild &a) { return !classes[a.cls].fixed; });
       std::vector<double> load(kBpWaves, 0.0);
+      std::vector<char> has_products(kBpWaves, 0);
       for (const PartBuild &pb : parts) {
-        const int wv = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+        int wv = -1;
+        if (classes[pb.cls].fixed) {
+          for (int w = 0; w < kBpWaves; ++w)
+            if (!has_products[w] && (wv < 0 || load[w] < load[wv])) wv = w;
+        }
+        if (wv < 0) wv = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
         load[wv] += pb.cost;
+        if (!classes[pb.cls].fixed) has_products[wv] = 1;
         const RowClass &rc = classes[pb.cls];
         const int pidx = pl.num_parts++;
         role.wave_parts[wv].push_back(pidx);
@@ -270,10 +291,22 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
         hdr[H_KS] = rc.ks;
         hdr[H_NCT] = rc.nct;
         hdr[H_LEN] = rc.len;
-        hdr[H_PHASE] = pb.phase;
-        hdr[H_NPHASE] = pb.nphase;
-        hdr[H_FLAGS] = rc.fixed ? 1 : 0;
+        hdr[H_CT0] = pb.ct0;
+        hdr[H_NTILE] = pb.ntile;
+        hdr[H_FLAGS] = (rc.fixed ? 1 : 0) | (pb.tail ? 2 : 0);
         hdr[H_CLASS] = pl.num_classes + pb.cls;
+        if (!rc.fixed) {  // which 4 x 16 blocks of the unit's part of W hold anything: the kernel skips the products of the others
+          const double *Wk = pl.w.data() + role_woff[rc.bin] + rc.w_off, *Wm = Wk + bin_fill[rc.bin];
+          for (int sidx = 0; sidx < rc.ks; ++sidx)
+            for (int q = 0; q < pb.ntile + pb.tail; ++q) {
+              bool any = false;
+              for (int r = 4 * sidx; r < 4 * sidx + 4 && !any; ++r)
+                for (int cc = 16 * (pb.ct0 + q); cc < 16 * (pb.ct0 + q) + 16 && !any; ++cc)
+                  any = Wk[static_cast<size_t>(r) * rc.stride + cc] != 0.0 || Wm[static_cast<size_t>(r) * rc.stride + cc] != 0.0;
+              const int bit = sidx * 5 + q;
+              if (any) hdr[H_MASK0 + bit / 32] |= static_cast<int32_t>(1u << (bit % 32));
+            }
+        }
         pl.part_hdr.insert(pl.part_hdr.end(), hdr, hdr + kBpHdrInts);
         const size_t base = pl.part_lane.size();
         pl.part_lane.resize(base + static_cast<size_t>(kBpLaneRows) * 64, 0);
@@ -375,52 +408,61 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
     for (int wv = 0; wv < kBpWaves; ++wv)
       for (int p = pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv]; p < pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv + 1]; ++p) {
         const int32_t *h = &pl.part_hdr[static_cast<size_t>(p) * kBpHdrInts];
-        mf += static_cast<int64_t>(h[H_KS]) * h[H_NCT] * ((static_cast<int64_t>(blocks.size()) + h[H_NPHASE] - 1 - h[H_PHASE]) / h[H_NPHASE]);  // as if one segment
+        int bits = 0;
+        for (int wd = 0; wd < 3; ++wd) bits += __builtin_popcount(static_cast<uint32_t>(h[H_MASK0 + wd]));
+        mf += static_cast<int64_t>(bits) * static_cast<int64_t>(blocks.size());
       }
     pl.mfma_per_assembly += mf;
   }
   // ---- 5. persistent workgroups, exactly one per CU: the role-major block sequence is cut into num_cus contiguous
   //         pieces of equal cost; a piece that crosses a role boundary becomes several SEGMENTS (the workgroup reloads
-  //         the LDS image between them), so small roles cost no extra workgroup and nobody waits for a free CU ----
+  //         the LDS image between them), so small roles cost no extra workgroup and nobody waits for a free CU.
+  //         Starting a role costs about three blocks (image load, pipeline fill), continuing it in a new segment one ----
   {
-    double total_cost = 0.0;
-    for (const RoleBuild &r : roles) total_cost += static_cast<double>(members[r.pattern].size()) * std::max<int64_t>(1, r.cost);
     const int nwg = std::max(1, num_cus);
-    pl.wg_seg_ptr.assign(1, 0);
-    double done = 0.0;
-    int wg = 0;
-    for (int k = 0; k < pl.num_roles; ++k) {
-      const double c = static_cast<double>(std::max<int64_t>(1, roles[k].cost));
-      const int nb = static_cast<int>(members[roles[k].pattern].size());
-      int first = 0;
-      while (first < nb) {
-        // blocks of this role the current workgroup still takes: up to its share boundary
-        const double bound = total_cost * (wg + 1) / nwg;
-        int take = static_cast<int>(std::floor((bound - done) / c + 0.5));
-        if (wg == nwg - 1) take = nb - first;
+    auto block_cost = [&](int k) { return static_cast<double>(std::max<int64_t>(1, roles[k].cost)); };
+    double total_cost = 0.0;
+    for (int k = 0; k < pl.num_roles; ++k) total_cost += (static_cast<double>(members[roles[k].pattern].size()) + 3.0) * block_cost(k);
+    for (double target = total_cost / nwg;; target *= 1.02) {
+      pl.seg.clear();
+      pl.wg_seg_ptr.assign(1, 0);
+      int wg = 0;
+      double load = 0.0;  // of the current workgroup
+      int last_role = -1;
+      bool fits = true;
+      for (int k = 0; k < pl.num_roles && fits; ++k) {
+        const double c = block_cost(k);
+        const int nb = static_cast<int>(members[roles[k].pattern].size());
         int seg_cap = std::max(1, kBpSegInts / roles[k].nruns);
         if (seg_blocks > 0) seg_cap = std::min(seg_cap, seg_blocks);
-        const bool capped = take > seg_cap;
-        take = std::max(0, std::min(take, nb - first));
-        take = std::min(take, seg_cap);  // the kernel keeps a segment's run offsets in LDS
-        if (take > 0) {
+        int first = 0;
+        while (first < nb) {
+          const double start = (last_role == k ? 1.0 : 3.0) * c;
+          int take = static_cast<int>(std::floor((target - load - start) / c + 0.5));
+          if (take < 1 && load > 0.0) {  // no room for another segment: next workgroup
+            if (wg == nwg - 1) { fits = false; break; }
+            pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
+            ++wg;
+            load = 0.0;
+            last_role = -1;
+            continue;
+          }
+          take = std::max(1, std::min(std::min(take, nb - first), seg_cap));
           pl.seg.push_back(k);
           pl.seg.push_back(first);
           pl.seg.push_back(take);
           pl.seg.push_back(0);
           first += take;
-          done += take * c;
-        }
-        if ((first < nb && !capped) || (first >= nb && done >= bound - 0.5 * c)) {
-          if (wg < nwg - 1) {
-            pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
-            ++wg;
-          }
+          load += start + take * c;
+          last_role = k;
         }
       }
+      if (fits) {
+        while (static_cast<int>(pl.wg_seg_ptr.size()) < nwg + 1) pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
+        pl.wg_seg_ptr.back() = static_cast<int32_t>(pl.seg.size() / 4);
+        break;
+      }
     }
-    while (static_cast<int>(pl.wg_seg_ptr.size()) < nwg + 1) pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
-    pl.wg_seg_ptr.back() = static_cast<int32_t>(pl.seg.size() / 4);
     pl.num_wgs = nwg;
   }
   pl.usable = true;
@@ -449,8 +491,8 @@ void block_patterns_host_apply(const BlockPatternPlan &pl, const double *factors
         const bool fixed_class = h[H_FLAGS] & 1;
         if (fixed_class && !overwrite) continue;
         const double *W = Wrole + h[H_WOFF], *Wm = W + ro[R_WDOUBLES];
-        for (int i = h[H_PHASE];; i += h[H_NPHASE]) {
-          if (i >= nseg) break;
+        const int c_begin = 16 * h[H_CT0], c_end = std::min(len, 16 * (h[H_CT0] + h[H_NTILE] + ((h[H_FLAGS] & 2) ? 1 : 0)));
+        for (int i = 0; i < nseg; ++i) {
           const int64_t j = first + i;
           // the block's element records, as build_erec2_kernel lays them out
           rec.assign(static_cast<size_t>(estride) * kBpRecDoubles, 0.0);
@@ -465,7 +507,7 @@ void block_patterns_host_apply(const BlockPatternPlan &pl, const double *factors
             MHA_REQUIRE(packed == L[20 * 64 + row] && packed == L[20 * 64 + 48 + row], MHA_ERR_STATE, "row tables of a part disagree");
             if (packed < 0) continue;
             const int base = pl.rowbase[static_cast<size_t>(row_base + j * nruns + (packed >> 20))] + (packed & 0xfffff);
-            for (int c = 0; c < len; ++c) {
+            for (int c = c_begin; c < c_end; ++c) {
               double v = 0.0;
               for (int s = 0; s < ks; ++s)
                 for (int kk = 0; kk < 4; ++kk) {

@@ -36,7 +36,7 @@ namespace mha {
 constexpr int kBpWaves = 12;       // wavefronts of a persistent workgroup (768 threads, 168 registers each: one workgroup per CU)
 constexpr int kBpMaxKSteps = 16;   // GEMM depth held in registers: 64 = 9 hexes x 7 or 16 quads x 4
 constexpr int kBpLaneRows = 24;    // per part and lane: [0..15] A offsets (doubles), [16..19] result rows of the lane's registers, [20] tile row lane & 15: run << 20 | CRS offset inside the run
-constexpr int kBpHdrInts = 8;      // per part: LDS offset of W, k-steps, column tiles, row length, phase, nphase, flags, class
+constexpr int kBpHdrInts = 12;     // per unit: LDS offset of W, k-steps, column tiles, row length, first tile, tiles, flags, class, 3 words: bit s * 5 + q set = W block (k-step s, tile q) is not zero
 constexpr int kBpRoleInts = 16;    // see block_pattern.cpp
 constexpr int kBpSegInts = 2048;    // (blocks of one segment) x (runs of consecutive rows per block): their CRS offsets sit in LDS
 constexpr int kBpRecDoubles = 8;   // element record: g_0..g_{nsym-1}, detJ, zero padding
@@ -47,6 +47,7 @@ struct BlockPatternPlan {
   int ke = 0, nsym = 0;
   int num_patterns = 0, num_roles = 0, num_wgs = 0, num_parts = 0, num_classes = 0;
   int max_w_doubles = 0;               // LDS doubles of the largest role
+  int max_rec_doubles = 0;             // doubles of the largest block's element records
   std::vector<int32_t> role;           // [num_roles][kBpRoleInts]
   std::vector<int32_t> seg;            // [num_segs][4]: role, first block (inside the role), blocks, 0
   std::vector<int32_t> wg_seg_ptr;     // [num_wgs + 1] -> segments of a workgroup

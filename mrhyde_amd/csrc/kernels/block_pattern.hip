@@ -7,18 +7,24 @@
 // K = (elements around the dof) x (geometry components), on v_mfma_f64_16x16x4_f64 (operand maps: A[row = lane&15]
 // [k = lane>>4], B[k = lane>>4][col = lane&15], D reg t: row = (lane>>4) + 4t, col = lane&15).
 //
-// Structure (what the previous forms of this kernel lacked):
-//   * no dependent loads: a wavefront owns a PART (16 rows of one row class, every nphase-th block of its workgroup);
-//     the offsets of its A operands inside a block's element records and the block-local indices of its result rows are
-//     loop invariants in registers, the block's records / row offsets sit at  base + ordinal * stride;
-//   * no barriers, no LDS accumulator, no atomics: W (all classes of the pattern, <= 150 KB) is read-only in LDS;
-//   * A operands of the NEXT block are requested before the products of the current one; gfx950 counts loads and
-//     stores in one in-order vmcnt, so the loads are issued from inline asm (hipcc does not track them) and retired with
-//     a counted s_waitcnt vmcnt(4 * NCT) that leaves this block's stores in flight: a wavefront never waits for its own
-//     stores, 16 wavefronts keep ~250 KB of stores in flight per CU;
-//   * loads and stores go through raw buffer resources: 32-bit offsets (no 64-bit address arithmetic in the loops), and
-//     the hardware drops lanes whose offset is out of range -- padding columns / rows are switched off that way, so
-//     every store INSTRUCTION is always issued and the count behind the counted wait is exact.
+// Structure:
+//   * a workgroup (12 wavefronts, one per CU, persistent) walks its blocks one at a time; every wavefront owns a UNIT
+//     of the block's pattern -- up to four 16-column tiles of one 16-row class tile (block_pattern.hpp) -- and all
+//     wavefronts meet at a barrier after every block.  The rows of a block are neighbours in the CRS value array:
+//     written within a microsecond of each other they leave the L2 as whole DRAM pages.  (Free-running wavefronts, each
+//     streaming "its" rows of many blocks, wrote the same bytes at a third of the rate: the L2 -> memory write requests
+//     stalled, profiles/r2_pmc_mem.log.)
+//   * no dependent loads: the offsets of a unit's A operands inside a block's element records and its result rows are
+//     loop invariants in registers, the block's records sit at base + ordinal * stride, its row offsets in LDS;
+//   * no LDS accumulator, no atomics: W (all classes of the pattern, <= 150 KB) is read-only in LDS;
+//   * A operands of the next TWO blocks are in flight; gfx950 counts loads and stores in one in-order vmcnt, so the
+//     loads are issued from inline asm (hipcc does not track them) and retired with a counted s_waitcnt that leaves
+//     the stores of this and the previous block in flight: a wavefront never waits for its own stores;
+//   * loads and stores go through raw buffer resources: 32-bit offsets, and the hardware drops lanes whose offset is out
+//     of range -- padding columns / rows are switched off that way, so every store INSTRUCTION is always issued and the
+//     count behind the counted wait is exact;
+//   * an MFMA result register holds 4 rows x 16 columns; the products of a unit's four tiles are transposed across the
+//     quarter waves (gfx950 lane swaps) so that every store writes 64 consecutive entries of ONE row.
 // HBM traffic per assembly: the CRS values once (the compulsory write), 64 B per (block, touched element) of records.
 #include <hip/hip_runtime.h>
 
@@ -35,7 +41,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 enum { R_EREC_LO = 0, R_EREC_HI, R_ESTRIDE, R_ROWB_LO, R_ROWB_HI, R_NRUNS, R_NBLOCKS, R_COST, R_WOFF_LO, R_WOFF_HI,
        R_WDOUBLES, R_PATTERN, R_NELEMS };
-enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_PHASE, H_NPHASE, H_FLAGS, H_CLASS };
+enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_CT0, H_NTILE, H_FLAGS, H_CLASS, H_MASK0, H_MASK1, H_MASK2 };
 
 __global__ __launch_bounds__(256) void build_erec2_kernel(int64_t total, int nsym, const int32_t *__restrict__ erec_elem,
                                                           const double *__restrict__ geo, double *__restrict__ erec2) {
@@ -80,15 +86,25 @@ __device__ __forceinline__ void asm_wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// workgroup barrier that waits for LDS traffic only (a __syncthreads() would drain the stores in flight)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
-struct PartCtx {
+struct UnitCtx {
   v4i erec;                // role's element records (buffer resource)
   v4i out;                 // the CRS values (buffer resource)
   const double *erec_ptr;  // the same records as a pointer (generic form)
   double *vals;
   const int *sbase;        // LDS: [block of the segment][run] CRS offset of the run's first row
-  int nruns, estride, first, nblocks, phase, nphase, len;  // blocks first .. first + nblocks - 1 of the role
+  int nruns, estride, first, nblocks, len;  // blocks first .. first + nblocks - 1 of the role
+  int ct0;                 // first column tile of the unit
   const double *Wl;        // this lane's corner of the class's W image in LDS
+  unsigned mask[3];        // bit s * 5 + q: the W block of k-step s, tile q of the unit is not zero
+  double *recbuf;          // LDS: two images of a block's element records, recstride doubles apart
+  int recstride;
   long long *tlog;         // profiling (DBG & 8): 8 wall-clock stamps of this wavefront
 };
 
@@ -104,189 +120,211 @@ __device__ __forceinline__ void transpose_quarters(unsigned (&x)[4]) {
   swap16(x[2], x[3]);
 }
 
-// One part: depth KS and NCT column tiles known at compile time, B blocks per loop iteration; overwrite mode only.
+// Element records of a block: (T + 1) x 8 doubles, contiguous in memory.  One wavefront (the loader: wave 0) fetches
+// them with a handful of coalesced loads two blocks ahead and puts them into a double-buffered LDS image; every unit
+// reads its A operands from there.  (Gathered straight from memory by every unit they were ~100 scattered load
+// instructions per block in front of the CU's one address pipeline, which the stores already saturate.)
+constexpr int kRecLoads = 8;  // 64-lane loads of 8 bytes per block: (T + 1) * 8 doubles <= 512 (the host checks)
+
+// One unit over all blocks of the segment: depth KS, NT column tiles stored row-contiguous (0: none) and, with TAIL, one
+// more tile stored as it stands; overwrite mode.
 //
-// A wavefront's loop iteration exposes one memory round trip (operands of iteration g + 1 are requested at the top of
-// iteration g and awaited at its end), so the short row classes batch several blocks per iteration until an iteration
-// carries enough matrix-core work to cover it.
-//
-// Stores: an MFMA result register holds 4 rows x 16 columns; stored as it stands that is four 128-byte pieces of four
-// CRS rows per instruction, and the memory system takes such instructions at a third of the rate of contiguous ones
-// (profiles/r2_probe.log: 0.53 -> 0.19 ms for the same bytes).  So the products of FOUR column tiles are transposed
-// across the quarter waves (transpose_quarters: 32 lane-swap instructions per group) and every store instruction writes
-// 64 consecutive entries of ONE row; the row's offset is wave-uniform and rides in the scalar offset of the buffer store.
-// A last odd tile (NCT % 4 == 1) is stored as it stands; two or three left-over tiles fill a group with zero tiles.
-//
-// Register budget (168 at 12 waves per CU): operands of this and the next iteration 2 x 2 KS B, packed offsets KS / 2,
-// one accumulator group 32 -- the per-iteration `opaque` statements keep hipcc from hoisting the unpacked offsets out of
-// the loop, the scheduling barriers between the chains keep it from fetching the B operands of a whole group ahead
-// (either way the asm-load destinations would be spilled: stored before they have landed).
-template <int KS, int NCT, int B, int DBG>
-__device__ __forceinline__ void run_part(const PartCtx &c, const int32_t *__restrict__ L, int lane) {
-  constexpr int STRIDE = (NCT % 2 == 1) ? 16 * NCT : 16 * NCT + 16;
+// Software pipeline, one block deep: while the products of block i accumulate, the results of block i - 1 are
+// transposed and stored, a few store instructions after every k-step (a CU's store path takes one 512-byte instruction
+// per ~40 cycles -- 156 per block: 2.7 us -- and the matrix cores need ~2 us per block).  All wavefronts meet at a
+// barrier once per block: the rows of a block reach the memory together.  The loader's record fetches are inline asm
+// (hipcc does not track them; gfx950 counts loads and stores in one in-order vmcnt) retired with a counted s_waitcnt
+// that leaves the current block's stores in flight.
+template <int KS, int NT, bool TAIL, int DBG>
+__device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__restrict__ L, int lane, bool loader) {
   constexpr int NPK = (KS + 1) / 2;
-  constexpr int REM = NCT % 4;
-  constexpr int NGRP = NCT / 4 + (REM >= 2 ? 1 : 0);      // groups of four tiles stored row-contiguous
-  constexpr bool PLAIN_TAIL = REM == 1;                    // last tile stored as it stands
-  constexpr int STORES = 16 * NGRP + (PLAIN_TAIL ? 4 : 0);
-  static_assert(STORES * B < 64, "the counted wait must fit vmcnt");
-  unsigned apk[NPK];  // byte offsets of the A operands inside a block's records, two per register
+  constexpr int NQ = NT + (TAIL ? 1 : 0);                 // accumulation chains
+  constexpr int NGS = NT > 0 ? 16 : 0, STORES = NGS + (TAIL ? 4 : 0);
+  static_assert(STORES < 64, "the counted wait must fit vmcnt");
+  unsigned apk[NPK];  // offsets (doubles) of the A operands inside a block's records, two per register
 #pragma unroll
   for (int q = 0; q < NPK; ++q) {
-    const unsigned lo = (unsigned)L[(2 * q) * 64 + lane] * 8u;
-    const unsigned hi = (2 * q + 1 < KS) ? (unsigned)L[(2 * q + 1) * 64 + lane] * 8u : 0u;
+    const unsigned lo = (unsigned)L[(2 * q) * 64 + lane];
+    const unsigned hi = (2 * q + 1 < KS) ? (unsigned)L[(2 * q + 1) * 64 + lane] : 0u;
     apk[q] = lo | (hi << 16);
   }
   const int relrow = L[20 * 64 + lane];  // tile row (lane & 15): run << 20 | CRS offset inside the run, -1 = no row
+  const int nct_all = (c.len + 15) / 16;
+  const int stride = (nct_all % 2 == 1) ? 16 * nct_all : 16 * nct_all + 16;
   auto aoff = [&](int s) { return (s & 1) ? (apk[s >> 1] >> 16) : (apk[s >> 1] & 0xffffu); };
-  auto opaque = [&]() {
+  // lane l <- column 16 ct0 + l of the group's rows; the tail tile keeps the MFMA layout (16 columns x 4 rows per register)
+  const int gcol = 16 * c.ct0 + lane, tcol = 16 * (c.ct0 + NT) + (lane & 15);
+  const unsigned gvoff = (lane < 16 * NT && gcol < c.len) ? (unsigned)gcol * 8u : kOutOfRange;
+
+  // ---- loader state: records of block i + 1 in registers, block i + 2 in flight ----
+  const int rec_doubles = c.estride * kBpRecDoubles;
+  double Rc[kRecLoads];
+  auto fetch = [&](int i, double (&dst)[kRecLoads]) {  // past the end: the last block again (in bounds, counted)
+    const int boff = __builtin_amdgcn_readfirstlane((c.first + min(i, c.nblocks - 1)) * rec_doubles * 8);
 #pragma unroll
-    for (int q = 0; q < NPK; ++q) asm volatile("" : "+v"(apk[q]));
+    for (int k = 0; k < kRecLoads; ++k) dst[k] = asm_load_f64(c.erec, (unsigned)min(k * 64 + lane, rec_doubles - 1) * 8u, boff);
   };
-  // item b of iteration g is the part's block number phase + nphase (g B + b) inside the segment; past the end: the
-  // last block again (loads stay in bounds and counted, stores are switched off)
-  auto item = [&](int g, int b) { return c.phase + c.nphase * (g * B + b); };
-  auto load_group = [&](int g, double (&dst)[B][KS]) {
+  auto deposit = [&](double (&src)[kRecLoads], double *buf) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int i = min(item(g, b), c.nblocks - 1);
-      const int boff = __builtin_amdgcn_readfirstlane((c.first + i) * c.estride * (kBpRecDoubles * 8));
-#pragma unroll
-      for (int s = 0; s < KS; ++s) dst[b][s] = asm_load_f64(c.erec, aoff(s), boff);
+    for (int k = 0; k < kRecLoads; ++k) {
+      asm volatile("" : "+v"(src[k]));
+      if (k * 64 + lane < rec_doubles) buf[k * 64 + lane] = src[k];
     }
   };
-  auto chain = [&](const double (&A)[KS], int ct) {
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    if constexpr (!(DBG & 4)) {
+  if (loader) {
+    fetch(0, Rc);
+    asm_wait_vmcnt<0>();
+    deposit(Rc, c.recbuf);  // block 0: visible after the first barrier
+    fetch(1, Rc);
+  }
+
+  v4d accP[NQ];       // results of the previous block, stored during this one
+  int vrowP = -1;     // lane r < 16: CRS offset of its tile row r of the previous block, -1 = no store
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s], c.Wl[(4 * s) * STRIDE + 16 * ct], acc, 0, 0, 0);
+  for (int q = 0; q < NQ; ++q) accP[q] = v4d{0.0, 0.0, 0.0, 0.0};
+  // store j (0 .. STORES - 1) of the previous block: group stores first (register t = j / 4, row q = j % 4 + 4 t), then the tail's
+  unsigned tlo[4], thi[4];
+  auto store_prev = [&](int j) {
+    if (j < NGS) {
+      const int t = j >> 2, q = j & 3;
+      if (q == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          tlo[k] = k < NT ? (unsigned)__double2loint(accP[k < NT ? k : 0][t]) : 0u;
+          thi[k] = k < NT ? (unsigned)__double2hiint(accP[k < NT ? k : 0][t]) : 0u;
+        }
+        transpose_quarters(tlo);
+        transpose_quarters(thi);
+      }
+      const int rowoff = __builtin_amdgcn_readlane(vrowP, q + 4 * t);  // wave-uniform: the row this instruction writes
+      v2i bits;
+      bits[0] = (int)tlo[q];
+      bits[1] = (int)thi[q];
+      raw_buffer_store_b64(bits, c.out, (int)(rowoff >= 0 ? gvoff : kOutOfRange), rowoff * 8, 0);
     } else {
-      acc[0] = A[0] + c.Wl[16 * ct];
+      const int t = j - NGS;  // result register t of this lane belongs to tile row (lane >> 4) + 4 t
+      const int rowoff = __builtin_amdgcn_ds_bpermute(((lane >> 4) + 4 * t) * 4, vrowP);
+      v2i bits;
+      bits[0] = __double2loint(accP[NQ - 1][t]);
+      bits[1] = __double2hiint(accP[NQ - 1][t]);
+      raw_buffer_store_b64(bits, c.out, (int)((tcol < c.len && rowoff >= 0) ? (unsigned)(rowoff + tcol) * 8u : kOutOfRange), 0, 0);
     }
-    return acc;
   };
 
-  if (c.phase >= c.nblocks) return;
-  double A[B][KS], An[B][KS];
-  load_group(0, An);
-  asm_wait_vmcnt<0>();
+  for (int i = 0; i <= c.nblocks; ++i) {  // iteration i: products of block i (discarded at i = nblocks), stores of block i - 1
+    const int ic = min(i, c.nblocks - 1);
+    const int vrowC = (relrow >= 0 && i < c.nblocks && !(DBG & 2)) ? c.sbase[ic * c.nruns + (max(relrow, 0) >> 20)] + (relrow & 0xfffff) : -1;
+    lds_barrier();  // block i's records are in place; every wavefront has issued the stores of block i - 2
+    const double *rec = c.recbuf + (i & 1) * c.recstride;
+    v4d acc[NQ];
 #pragma unroll
-  for (int b = 0; b < B; ++b)
+    for (int q = 0; q < NQ; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int s = 0; s < KS; ++s) { asm volatile("" : "+v"(An[b][s])); A[b][s] = An[b][s]; }
-  for (int g = 0;; ++g) {
-    const bool more = item(g + 1, 0) < c.nblocks;
-    opaque();
-    if constexpr ((DBG & 8) != 0) { if (g == 2 && lane == 0) c.tlog[3] = wall_clock64(); }
-    load_group(more ? g + 1 : g, An);
-    if constexpr ((DBG & 8) != 0) { if (g == 2 && lane == 0) c.tlog[4] = wall_clock64(); }  // (the last iteration re-reads its own blocks: the count behind the wait stays exact)
+    for (int s = 0; s < KS; ++s) {
+      const double a = rec[aoff(s)];
+      if constexpr (!(DBG & 4)) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int i = item(g, b);
-      const bool valid = i < c.nblocks && !(DBG & 2);
-      // lane r < 16 (and its images in the other quarter waves): CRS offset of tile row r of this block, -1 = no store
-      const int vrow = (valid && relrow >= 0) ? c.sbase[min(i, c.nblocks - 1) * c.nruns + (max(relrow, 0) >> 20)] + (relrow & 0xfffff) : -1;
-#pragma unroll
-      for (int grp = 0; grp < NGRP; ++grp) {
-        v4d acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (4 * grp + q < NCT) acc[q] = chain(A[b], 4 * grp + q);
-          else acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        // lane l <- column 64 grp + l of rows q + 4 t
-        const unsigned voff = (64 * grp + lane < c.len) ? (unsigned)(64 * grp + lane) * 8u : kOutOfRange;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          unsigned lo[4], hi[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { lo[q] = (unsigned)__double2loint(acc[q][t]); hi[q] = (unsigned)__double2hiint(acc[q][t]); }
-          transpose_quarters(lo);
-          transpose_quarters(hi);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int rowoff = __builtin_amdgcn_readlane(vrow, q + 4 * t);  // wave-uniform: the row this instruction writes
-            v2i bits;
-            bits[0] = (int)lo[q];
-            bits[1] = (int)hi[q];
-            if constexpr ((DBG & 16) != 0)  // profiling: whole, aligned 128-byte lines only (clobbers the neighbouring rows)
-              raw_buffer_store_b64(bits, c.out, (int)(rowoff >= 0 ? (unsigned)(64 * grp + lane) * 8u : kOutOfRange), (rowoff * 8) & ~127, 0);
-            else
-              raw_buffer_store_b64(bits, c.out, (int)(rowoff >= 0 ? voff : kOutOfRange), rowoff * 8, 0);
-          }
-        }
+        for (int q = 0; q < NQ; ++q)  // (skipping the zero 4 x 16 blocks of W -- c.mask, a quarter of them -- costs a branch per
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c.Wl[(4 * s) * stride + 16 * q], acc[q], 0, 0, 0);  // product and spills)
+      } else {
+        acc[0][0] += a;
       }
-      if constexpr (PLAIN_TAIL) {
-        constexpr int ct = NCT - 1;
-        const v4d acc = chain(A[b], ct);
-        const bool in_row = 16 * ct + (lane & 15) < c.len;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          // result register t of this lane belongs to tile row (lane >> 4) + 4 t
-          const int rowoff = __builtin_amdgcn_ds_bpermute(((lane >> 4) + 4 * t) * 4, vrow);
-          v2i bits;
-          bits[0] = __double2loint(acc[t]);
-          bits[1] = __double2hiint(acc[t]);
-          raw_buffer_store_b64(bits, c.out, (int)((in_row && rowoff >= 0) ? (unsigned)(rowoff + 16 * ct + (lane & 15)) * 8u : kOutOfRange), 0, 0);
-        }
-      }
+      for (int j = (s * STORES) / KS; j < ((s + 1) * STORES) / KS; ++j) store_prev(j);
+      if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr ((DBG & 8) != 0) { if (g == 2 && lane == 0) c.tlog[5] = wall_clock64(); }
-    asm_wait_vmcnt<STORES * B>();  // next operands are in; this iteration's stores stay in flight
-    if constexpr ((DBG & 8) != 0) { if (g == 2 && lane == 0) c.tlog[6] = wall_clock64(); }
 #pragma unroll
-    for (int b = 0; b < B; ++b)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) { asm volatile("" : "+v"(An[b][s])); A[b][s] = An[b][s]; }
-    if (!more) break;
+    for (int q = 0; q < NQ; ++q) accP[q] = acc[q];
+    vrowP = vrowC;
+    if (loader) {
+      // block i + 1's records (requested one iteration ago) into the other buffer -- last read during block i - 1, and
+      // everybody has passed this iteration's barrier since; this iteration's stores stay in flight.  Then request
+      // block i + 2's into the same registers.
+      asm_wait_vmcnt<STORES>();
+      deposit(Rc, c.recbuf + ((i + 1) & 1) * c.recstride);
+      fetch(i + 2, Rc);
+    }
   }
 }
 
-// Any depth / width, store or accumulate, plain (compiler-counted) loads: parts the specialised forms do not cover,
-// rows of fixed dofs (zeros when storing), and the accumulate mode.
-__device__ void run_part_generic(const PartCtx &c, const int32_t *__restrict__ L, int lane, int ks, int nct, bool fixed_class,
-                                 bool overwrite) {
-  const int stride = (nct % 2 == 1) ? 16 * nct : 16 * nct + 16;
+// Units of fixed dofs (isFixedDOF rows: the scatter skips them, assemblyManager.cpp:4075, 4120): zeros when storing.  A
+// wavefront takes up to kMaxFixedUnits of them; no loads, one row per store instruction.
+constexpr int kMaxFixedUnits = 6;
+template <int DBG>
+__device__ __forceinline__ void run_fixed_units(UnitCtx &c, const BlockPatternDev &d, int p_begin, int p_end, int lane) {
+  const int nu = p_end - p_begin;
+  int relrow[kMaxFixedUnits], col0[kMaxFixedUnits], ncol[kMaxFixedUnits];
+#pragma unroll
+  for (int u = 0; u < kMaxFixedUnits; ++u) {
+    relrow[u] = -1; col0[u] = 0; ncol[u] = 0;
+    if (u < nu) {
+      const int32_t *h = d.part_hdr + (size_t)(p_begin + u) * kBpHdrInts;
+      relrow[u] = d.part_lane[(size_t)(p_begin + u) * kBpLaneRows * 64 + 20 * 64 + lane];
+      col0[u] = 16 * h[H_CT0];
+      ncol[u] = min(h[H_LEN], 16 * (h[H_CT0] + h[H_NTILE] + ((h[H_FLAGS] & 2) ? 1 : 0))) - col0[u];  // <= 80
+    }
+  }
+  const v2i zero = {0, 0};
+  for (int i = 0; i <= c.nblocks; ++i) {  // (nblocks + 1 barriers per segment: the product units run one block behind with their stores)
+    lds_barrier();
+    if (i == c.nblocks) break;
+#pragma unroll
+    for (int u = 0; u < kMaxFixedUnits; ++u) {
+      if (u >= nu) break;
+      const int vrow = (relrow[u] >= 0 && !(DBG & 2)) ? c.sbase[i * c.nruns + (max(relrow[u], 0) >> 20)] + (relrow[u] & 0xfffff) : -1;
+      for (int r = 0; r < 16; ++r) {
+        const int rowoff = __builtin_amdgcn_readlane(vrow, r);
+        if (rowoff < 0) continue;  // wave-uniform
+        raw_buffer_store_b64(zero, c.out, (int)(lane < ncol[u] ? (unsigned)(col0[u] + lane) * 8u : kOutOfRange), rowoff * 8, 0);
+        if (ncol[u] > 64) raw_buffer_store_b64(zero, c.out, (int)(lane + 64 < ncol[u] ? (unsigned)(col0[u] + 64 + lane) * 8u : kOutOfRange), rowoff * 8, 0);
+      }
+    }
+  }
+}
+
+// One block of one unit, any depth / width, store or accumulate, plain (compiler-counted) loads: units the specialised
+// form does not cover, rows of fixed dofs (zeros when storing), and the accumulate mode.
+__device__ void unit_generic(const UnitCtx &c, const int32_t *__restrict__ L, int lane, int i, int ks, int ntile,
+                             bool fixed_class, bool overwrite) {
+  const int nct_all = (c.len + 15) / 16;
+  const int stride = (nct_all % 2 == 1) ? 16 * nct_all : 16 * nct_all + 16;
   const int l15 = lane & 15;
   int rel[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) rel[t] = L[(16 + t) * 64 + lane];
-  for (int i = c.phase; i < c.nblocks; i += c.nphase) {
-    const double *eb = c.erec_ptr + (size_t)(c.first + i) * c.estride * kBpRecDoubles;
-    int base[4];
+  const double *eb = c.erec_ptr + (size_t)(c.first + i) * c.estride * kBpRecDoubles;
+  int base[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) base[t] = c.sbase[i * c.nruns + (max(rel[t], 0) >> 20)] + (rel[t] & 0xfffff);
-    double A[kBpMaxKSteps];
+  for (int t = 0; t < 4; ++t) base[t] = c.sbase[i * c.nruns + (max(rel[t], 0) >> 20)] + (rel[t] & 0xfffff);
+  double A[kBpMaxKSteps];
 #pragma unroll
-    for (int s = 0; s < kBpMaxKSteps; ++s) A[s] = (s < ks) ? eb[L[s * 64 + lane]] : 0.0;
-    for (int ct = 0; ct < nct; ++ct) {
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
+  for (int s = 0; s < kBpMaxKSteps; ++s) A[s] = (s < ks) ? eb[L[s * 64 + lane]] : 0.0;
+  for (int q = 0; q < ntile; ++q) {
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s = 0; s < kBpMaxKSteps; ++s)
-        if (s < ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s], c.Wl[(4 * s) * stride + 16 * ct], acc, 0, 0, 0);
-      const int col = 16 * ct + l15;
+    for (int s = 0; s < kBpMaxKSteps; ++s)
+      if (s < ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s], c.Wl[(4 * s) * stride + 16 * q], acc, 0, 0, 0);
+    const int col = 16 * (c.ct0 + q) + l15;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (rel[t] < 0 || col >= c.len) continue;
-        double *p = c.vals + (size_t)base[t] + col;
-        if (overwrite) *p = fixed_class ? 0.0 : acc[t];
-        else if (!fixed_class) *p += acc[t];
-      }
+    for (int t = 0; t < 4; ++t) {
+      if (rel[t] < 0 || col >= c.len) continue;
+      double *p = c.vals + (size_t)base[t] + col;
+      if (overwrite) *p = fixed_class ? 0.0 : acc[t];
+      else if (!fixed_class) *p += acc[t];
     }
   }
 }
 
-// DBG (profiling launches only, env MHA_BP_DBG): 1 plain-load form of every part, 2 no stores, 4 no products, 8 wall-clock
+// DBG (profiling launches only, env MHA_BP_DBG): 1 plain-load form of every unit, 2 no stores, 4 no products, 8 wall-clock
 // stamps of every wavefront
 template <int DBG>
 __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(BlockPatternDev d, RowOut out, double su, double st) {
-  extern __shared__ double W[];  // [max_w_doubles] the role's image, then [kBpSegInts] ints: the segment's run offsets
+  extern __shared__ double W[];  // [max_w_doubles] the role's image, [kBpSegInts] ints: the segment's run offsets, 2 x element records of a block
   int *sbase = reinterpret_cast<int *>(W + d.max_w_doubles);
+  double *recbuf = reinterpret_cast<double *>(sbase + kBpSegInts);  // [2][max_rec_doubles]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  PartCtx c;
+  UnitCtx c;
   c.vals = out.vals;
   c.out = make_rsrc(out.vals, (unsigned)(d.nnz * 8));
   long long *tlog = nullptr;
@@ -294,9 +332,9 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
   constexpr bool TIMING = (DBG & 8) != 0;
   if constexpr (TIMING) tlog = d.timing + ((size_t)blockIdx.x * kBpWaves + wave) * 8;
   c.tlog = tlog;
-  auto stamp = [&]() {  // slots 0 start, 1 image loaded, 2 first part done, 7 last part done; 3..6: iteration 2 of the first part
+  auto stamp = [&]() {  // slots 0 start, 1 image loaded, 2.. segments done, 7 end
     if constexpr (TIMING) {
-      const int slot = tslot < 3 ? tslot : 7;
+      const int slot = tslot < 7 ? tslot : 7;
       if (lane == 0) tlog[slot] = wall_clock64();
       ++tslot;
     }
@@ -307,7 +345,7 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
   for (int sg = sg_begin; sg < sg_end; ++sg) {
     const int role = d.seg[4 * sg];
     const int32_t *ro = d.role + (size_t)role * kBpRoleInts;
-    if (sg > sg_begin) __syncthreads();  // every wave is done with the previous segment (role image, run offsets)
+    if (sg > sg_begin) lds_barrier();  // every wavefront is done with the previous segment's run offsets and image
     if (role != cur_role) {
       cur_role = role;
       // the role's image comes in two halves: rows of the stiffness components (x alpha_u kappa) and of the mass
@@ -335,43 +373,85 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
     c.erec_ptr = d.erec2 + ((((long long)ro[R_EREC_HI]) << 32) | (unsigned)ro[R_EREC_LO]) * kBpRecDoubles;
     c.erec = make_rsrc(c.erec_ptr, (unsigned)ro[R_NBLOCKS] * (unsigned)ro[R_ESTRIDE] * (kBpRecDoubles * 8u));
     c.estride = ro[R_ESTRIDE];
+    c.recbuf = recbuf;
+    c.recstride = d.max_rec_doubles;
     const int32_t *pp = d.part_ptr + (size_t)role * (kBpWaves + 1);
     const int p_begin = pp[wave], p_end = pp[wave + 1];
-    for (int p = p_begin; p < p_end; ++p) {
+    auto setup = [&](int p, int &ks, int &ntile, bool &fixed_class, bool &tail) -> const int32_t * {
       const int32_t *h = d.part_hdr + (size_t)p * kBpHdrInts;
-      const int32_t *L = d.part_lane + (size_t)p * kBpLaneRows * 64;
-      const int ks = h[H_KS], nct = h[H_NCT];
-      const bool fixed_class = (h[H_FLAGS] & 1) != 0;
-      c.phase = __builtin_amdgcn_readfirstlane(h[H_PHASE]);
-      c.nphase = __builtin_amdgcn_readfirstlane(h[H_NPHASE]);
+      ks = h[H_KS];
+      ntile = h[H_NTILE];
+      fixed_class = (h[H_FLAGS] & 1) != 0;
+      tail = (h[H_FLAGS] & 2) != 0;
       c.len = h[H_LEN];
+      c.ct0 = __builtin_amdgcn_readfirstlane(h[H_CT0]);
+#pragma unroll
+      for (int wd = 0; wd < 3; ++wd) c.mask[wd] = (unsigned)__builtin_amdgcn_readfirstlane(h[H_MASK0 + wd]);
+      const int nct = h[H_NCT];
       const int stride = (nct % 2 == 1) ? 16 * nct : 16 * nct + 16;
-      c.Wl = W + h[H_WOFF] + (lane >> 4) * stride + (lane & 15);
-      if (fixed_class && !out.overwrite) continue;
-      const int key = (out.overwrite && !fixed_class && !(DBG & 1)) ? ks * 16 + nct : -1;
+      c.Wl = W + h[H_WOFF] + (lane >> 4) * stride + (lane & 15) + 16 * c.ct0;
+      return d.part_lane + (size_t)p * kBpLaneRows * 64;
+    };
+    // fast form: this wavefront owns exactly one unit of a shape that is instantiated; it runs the whole segment (one
+    // barrier per block inside).  Everything else goes block by block through the plain form.
+    bool done = false;
+    const bool loader = wave == 0;
+    if (p_end - p_begin == 1 && out.overwrite && !(DBG & 1)) {
+      int ks, ntile;
+      bool fixed_class, tail;
+      const int32_t *L = setup(p_begin, ks, ntile, fixed_class, tail);
+      const int key = fixed_class ? -1 : (ks * 8 + ntile) * 2 + (tail ? 1 : 0);
+      done = true;
       switch (key) {
-        // (depth, column tiles) -> blocks per iteration: as many as 16 operand registers and the 6-bit vmcnt allow
         // Q2 hexes: 8 / 4 / 2 / 1 elements around a vertex / edge / face / cell dof
-        case 14 * 16 + 8: run_part<14, 8, 1, DBG>(c, L, lane); break;
-        case 7 * 16 + 5: run_part<7, 5, 2, DBG>(c, L, lane); break;
-        case 4 * 16 + 3: run_part<4, 3, 3, DBG>(c, L, lane); break;
-        case 2 * 16 + 2: run_part<2, 2, 3, DBG>(c, L, lane); break;
+        case (14 * 8 + 4) * 2: run_unit<14, 4, false, DBG>(c, L, lane, loader); break;
+        case (7 * 8 + 4) * 2 + 1: run_unit<7, 4, true, DBG>(c, L, lane, loader); break;
+        case (7 * 8 + 4) * 2: run_unit<7, 4, false, DBG>(c, L, lane, loader); break;
+        case (4 * 8 + 3) * 2: run_unit<4, 3, false, DBG>(c, L, lane, loader); break;
+        case (2 * 8 + 2) * 2: run_unit<2, 2, false, DBG>(c, L, lane, loader); break;
         // Q1 hexes
-        case 14 * 16 + 2: run_part<14, 2, 1, DBG>(c, L, lane); break;
-        case 7 * 16 + 2: run_part<7, 2, 2, DBG>(c, L, lane); break;
-        case 4 * 16 + 1: run_part<4, 1, 4, DBG>(c, L, lane); break;
-        case 2 * 16 + 1: run_part<2, 1, 8, DBG>(c, L, lane); break;
-        // quads (one k-step per element): Q2 vertex rows, Q1 rows, cell rows; Q4
-        case 4 * 16 + 2: run_part<4, 2, 3, DBG>(c, L, lane); break;
-        case 1 * 16 + 1: run_part<1, 1, 14, DBG>(c, L, lane); break;
-        case 4 * 16 + 6: run_part<4, 6, 1, DBG>(c, L, lane); break;
-        case 2 * 16 + 3: run_part<2, 3, 3, DBG>(c, L, lane); break;
-        case 1 * 16 + 2: run_part<1, 2, 3, DBG>(c, L, lane); break;
-        default: run_part_generic(c, L, lane, ks, nct, fixed_class, out.overwrite != 0); break;
+        case (14 * 8 + 2) * 2: run_unit<14, 2, false, DBG>(c, L, lane, loader); break;
+        case (7 * 8 + 2) * 2: run_unit<7, 2, false, DBG>(c, L, lane, loader); break;
+        case (4 * 8 + 0) * 2 + 1: run_unit<4, 0, true, DBG>(c, L, lane, loader); break;
+        case (2 * 8 + 0) * 2 + 1: run_unit<2, 0, true, DBG>(c, L, lane, loader); break;
+        // quads (one k-step per element)
+        case (4 * 8 + 2) * 2: run_unit<4, 2, false, DBG>(c, L, lane, loader); break;
+        case (4 * 8 + 4) * 2: run_unit<4, 4, false, DBG>(c, L, lane, loader); break;
+        case (2 * 8 + 3) * 2: run_unit<2, 3, false, DBG>(c, L, lane, loader); break;
+        case (1 * 8 + 2) * 2: run_unit<1, 2, false, DBG>(c, L, lane, loader); break;
+        case (1 * 8 + 0) * 2 + 1: run_unit<1, 0, true, DBG>(c, L, lane, loader); break;
+        default: done = false; break;
       }
-      stamp();
     }
+    if (!done && !loader && out.overwrite && !(DBG & 1) && p_end > p_begin && p_end - p_begin <= kMaxFixedUnits) {
+      bool all_fixed = true;
+      for (int p = p_begin; p < p_end; ++p) all_fixed = all_fixed && (d.part_hdr[(size_t)p * kBpHdrInts + H_FLAGS] & 1);
+      if (all_fixed) {
+        run_fixed_units<DBG>(c, d, p_begin, p_end, lane);
+        done = true;
+      }
+    }
+    if (!done) {
+      for (int i = 0; i <= c.nblocks; ++i) {
+        if (loader && i < c.nblocks) {  // plain form of the record fetch: this block's records, just in time
+          const double *src = c.erec_ptr + (size_t)(c.first + i) * c.estride * kBpRecDoubles;
+          double *dst = recbuf + (i & 1) * c.recstride;
+          for (int k = lane; k < c.estride * kBpRecDoubles; k += 64) dst[k] = src[k];
+        }
+        lds_barrier();
+        if (i == c.nblocks) break;
+        for (int p = p_begin; p < p_end; ++p) {
+          int ks, ntile;
+          bool fixed_class, tail;
+          const int32_t *L = setup(p, ks, ntile, fixed_class, tail);
+          if (fixed_class && !out.overwrite) continue;
+          unit_generic(c, L, lane, i, ks, ntile + (tail ? 1 : 0), fixed_class, out.overwrite != 0);
+        }
+      }
+    }
+    stamp();
   }
+  if constexpr (TIMING) { tslot = 7; stamp(); }
 }
 
 }  // namespace
@@ -387,7 +467,7 @@ void launch_build_erec2(int64_t total_records, int nsym, const int32_t *erec_ele
 
 void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, double su, double st, hipStream_t stream) {
   if (d.num_wgs <= 0 || !out.vals) return;
-  const size_t lds = sizeof(double) * (size_t)d.max_w_doubles + sizeof(int) * kBpSegInts;
+  const size_t lds = sizeof(double) * (size_t)d.max_w_doubles + sizeof(int) * kBpSegInts + 2 * sizeof(double) * (size_t)d.max_rec_doubles;
   MHA_REQUIRE(lds <= 160 * 1024, MHA_ERR_INVALID, "pattern matrices of " << lds << " B do not fit the LDS");
   auto go = [&](auto kern) {
     MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -400,8 +480,6 @@ void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, 
     case 4: go(block_pattern_jacobian_kernel<4>); break;
     case 6: go(block_pattern_jacobian_kernel<6>); break;
     case 8: go(block_pattern_jacobian_kernel<8>); break;
-    case 16: go(block_pattern_jacobian_kernel<16>); break;
-    case 24: go(block_pattern_jacobian_kernel<24>); break;
     case 10: go(block_pattern_jacobian_kernel<10>); break;
     case 12: go(block_pattern_jacobian_kernel<12>); break;
     case 14: go(block_pattern_jacobian_kernel<14>); break;

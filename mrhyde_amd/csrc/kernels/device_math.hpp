@@ -32,8 +32,10 @@ __device__ __forceinline__ void invert<3>(const double *J, double *Ji, double &d
 // sin(x) for moderate |x|: Cody-Waite reduction by pi/2 and the fdlibm kernel polynomials (< 1 ulp);
 // falls back to the library routine for huge arguments.  About a quarter of the instructions of the
 // full-range sin(), which matters because the source term is evaluated at every integration point.
+// (the full-range routine stays out of line: inlined at every integration point it made the kernels several times larger)
+__device__ __noinline__ double sin_full_range(double x) { return sin(x); }
 __device__ __forceinline__ double sin_moderate(double x) {
-  if (!(fabs(x) < 1.0e5)) return sin(x);
+  if (!(fabs(x) < 1.0e5)) return sin_full_range(x);
   const double kd = rint(x * 6.36619772367581382433e-01);
   const int k = (int)kd;
   double r = fma(-kd, 1.57079632673412561417e+00, x);

@@ -211,6 +211,7 @@ struct SwhElementDev {
 // Row blocks keyed by assembly pattern (block_pattern.hpp) for the matrix-core row-owner Jacobian.
 struct BlockPatternDev {
   int num_wgs = 0, max_w_doubles = 0;
+  int max_rec_doubles = 0;             // doubles of the largest block's element records ((T + 1) * 8): LDS image size
   int dbg = 0;                         // profiling / cross-check aid (env MHA_BP_DBG): 1 plain-load form of every part, 2 no stores, 4 no products
   const double *erec2 = nullptr;       // role-major, block-major element records [T + 1][8]
   const int32_t *rowbase = nullptr;    // role-major, block-major CRS offsets of the owned rows [R]

@@ -9,7 +9,11 @@
 // gradients at the points by the 1-D collocation derivative  D[q][q'] = sum_i phi_i'(xi_q) (Phi^-1)[q'][i], the
 // transposed operations on the way back.  ~1e3 FMAs and ~60 live doubles per element instead of the n x nq = 729
 // four-term products (and 32 lanes) of the lane-per-dof form this replaces; all 64 lanes of a wavefront do useful work.
+// The sinprod source is separable on axis-aligned elements (checked per element): DIM x (order + 1) sines instead of
+// DIM x (order + 1)^DIM.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -49,15 +53,42 @@ __device__ __forceinline__ void apply1d(double *v, const double *T) {
   }
 }
 
+// 64 consecutive elements per wavefront.  Their LID lists (64 x N ints) and geometry records (64 x 20 doubles) are
+// contiguous in memory: fetched with coalesced loads into a per-wave LDS buffer and read back one record per lane
+// (odd strides: conflict-free), instead of 64 different cache lines per load instruction.
 template <int DIM, int P, bool TR, bool EXPR>
 __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(BlockDev b, ThermalDev ph,
                                                                               const double *__restrict__ geo,
-                                                                              AffineTables1D tab, double *res) {
+                                                                              AffineTables1D tab, double *res, int dbg) {
   constexpr int M = P + 1, N = cpow(M, DIM);
-  const int idx = blockIdx.x * kK1tThreads + threadIdx.x;
-  if (idx >= b.e_count) return;
-  const int e = b.e_begin + idx;
-  const int32_t *L = b.lids + (size_t)e * N;
+  constexpr int GS = kGeoRec + 1;  // padded record stride (doubles): odd -> one record per lane without bank conflicts
+  __shared__ int s_lid[kK1tThreads / 64][64 * N];
+  __shared__ double s_geo[kK1tThreads / 64][64 * GS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int first = (blockIdx.x * (kK1tThreads / 64) + wave) * 64;  // first element of this wavefront (inside the range)
+  if (first >= b.e_count) return;
+  const int nvalid = min(64, b.e_count - first);
+  const bool active = lane < nvalid;
+  const int e = b.e_begin + first + (active ? lane : 0);
+  {
+    const int32_t *src = b.lids + (size_t)(b.e_begin + first) * N;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int idx = k * 64 + lane;
+      s_lid[wave][idx] = idx < nvalid * N ? src[idx] : 0;
+    }
+    const double *gsrc = geo + (size_t)(b.e_begin + first) * kGeoRec;
+#pragma unroll
+    for (int k = 0; k < kGeoRec; ++k) {
+      const int idx = k * 64 + lane;
+      s_geo[wave][(idx / kGeoRec) * GS + idx % kGeoRec] = idx < nvalid * kGeoRec ? gsrc[idx] : 0.0;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int *L = &s_lid[wave][(active ? lane : 0) * N];
+  const double *g = &s_geo[wave][(active ? lane : 0) * GS];
   const TimeDev &tm = ph.time;
 
   // performGather + computeSoln*Seeded values, basis (tensor) order
@@ -65,7 +96,7 @@ __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(Bl
 #pragma unroll
   for (int ib = 0; ib < N; ++ib) {
     const int row = L[b.offsets[ib]];
-    const double cu = tm.u[row];
+    const double cu = (dbg & 4) ? 1.0 : tm.u[row];
     double ue = cu;
     if constexpr (TR) {
       const double *cp = tm.u_prev + (size_t)row * tm.nsteps;
@@ -90,7 +121,6 @@ __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(Bl
     if constexpr (DIM == 3) apply1d<DIM, M, DIM - 1, true>(Ud, tab.phi);
   }
   // cached geometry of the (affine) element
-  const double *g = geo + (size_t)e * kGeoRec;
   double G[DIM][DIM], J[DIM][DIM], xc[DIM];
   {
     int k = 0;
@@ -107,6 +137,23 @@ __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(Bl
     for (int c = 0; c < DIM; ++c) J[r][c] = g[kGeoJ + r * DIM + c];
   }
   const double kap = ph.diff.amp, rc = ph.rho.amp * ph.cp.amp;  // element-wise constants on this path
+
+  // closed-form source amp prod_d sin(freq_d x_d) on an axis-aligned element: x_d at point q depends on q_d only, so
+  // DIM x M sines serve all M^DIM points (the same values the general evaluation produces point by point)
+  bool separable = ph.source.kind != MHA_FUNC_CONSTANT && ph.source.kind != MHA_FUNC_IP_ARRAY && ph.source.kind != MHA_FUNC_EXPRESSION;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int c = 0; c < DIM; ++c)
+      if (r != c && J[r][c] != 0.0) separable = false;
+  double s1d[DIM][M];
+  if (dbg & 2) separable = false;
+  if (separable) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d)
+#pragma unroll
+      for (int q = 0; q < M; ++q) s1d[d][q] = sin_moderate(ph.source.freq[d] * (xc[d] + J[d][d] * tab.gp[q]));
+  }
 
   // point loop: W accumulates what multiplies the basis VALUES at each point (the flux terms enter through D^T)
   double W[N];
@@ -128,14 +175,21 @@ __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(Bl
       }
       gh[d] = s;
     }
+    double f;
+    if (separable) {
+      f = ph.source.amp;
 #pragma unroll
-    for (int r = 0; r < DIM; ++r) {
-      double s = xc[r];
+      for (int d = 0; d < DIM; ++d) f *= s1d[d][qd[d]];
+    } else {
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) s += J[r][c] * tab.gp[qd[c]];
-      x[r] = s;
+      for (int r = 0; r < DIM; ++r) {
+        double s = xc[r];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) s += J[r][c] * tab.gp[qd[c]];
+        x[r] = s;
+      }
+      f = eval_func<DIM, EXPR>(ph.source, e, pt, N, x);
     }
-    const double f = eval_func<DIM, EXPR>(ph.source, e, pt, N, x);
     const double tt = TR ? Ud[TR ? pt : 0] : 0.0;
     W[pt] += (rc * tt - f) * det * wq;
 #pragma unroll
@@ -156,10 +210,12 @@ __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(Bl
   apply1d<DIM, M, 1, false>(W, tab.phi);
   if constexpr (DIM == 3) apply1d<DIM, M, DIM - 1, false>(W, tab.phi);
   // the global vector receives -res.val(); fixed rows are skipped (assemblyManager.cpp:4075, 4094)
+  if (active && !(dbg & 1)) {
 #pragma unroll
-  for (int ib = 0; ib < N; ++ib) {
-    const int row = L[b.offsets[ib]];
-    if (!(b.fixed && b.fixed[row])) atomicAdd(res + row, -W[ib]);
+    for (int ib = 0; ib < N; ++ib) {
+      const int row = L[b.offsets[ib]];
+      if (!(b.fixed && b.fixed[row])) atomicAdd(res + row, -W[ib]);
+    }
   }
 }
 
@@ -167,9 +223,10 @@ template <int DIM, int P>
 void launch_t(const BlockDev &b, const ThermalDev &ph, const double *geo, const AffineTables1D &tab, double *res,
               hipStream_t stream) {
   if (b.e_count <= 0) return;
-  const int grid = (b.e_count + kK1tThreads - 1) / kK1tThreads;
+  const int grid = (b.e_count + kK1tThreads - 1) / kK1tThreads;  // a wavefront takes 64 consecutive elements
   const bool tr = ph.time.transient != 0;
-  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1tThreads), 0, stream, b, ph, geo, tab, res); };
+  static const int dbg = [] { const char *m = std::getenv("MHA_K1_DBG"); return m ? std::atoi(m) : 0; }();  // profiling aid: 1 no atomics, 2 general source evaluation, 4 no gather
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1tThreads), 0, stream, b, ph, geo, tab, res, dbg); };
   if (has_expression(ph.source)) {
     if (tr) go(thermal_affine_residual_kernel<DIM, P, true, true>);
     else go(thermal_affine_residual_kernel<DIM, P, false, true>);
