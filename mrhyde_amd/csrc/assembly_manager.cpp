@@ -806,6 +806,8 @@ void AssemblyManager::prepareRowOwner() {
   // 2. row blocks
   std::vector<double> nodes(static_cast<size_t>(nelem_) * nnodes_ * dim_);
   d_nodes_.download(nodes.data());
+  for (int d = 0; d < 3; ++d) ro.max_abs_coord[d] = 0.0;
+  for (size_t i = 0; i < nodes.size(); ++i) ro.max_abs_coord[i % dim_] = std::max(ro.max_abs_coord[i % dim_], std::fabs(nodes[i]));
   int max_row = 0;
   for (int r = 0; r < nrows_; ++r) max_row = std::max(max_row, h_rowptr_[r + 1] - h_rowptr_[r]);
   MHA_REQUIRE(max_row <= 65536, MHA_ERR_INVALID, "CRS rows longer than 65536 entries are not supported");
@@ -1166,7 +1168,7 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   static const int overlap = [] { const char *m = std::getenv("MHA_K1K2_OVERLAP"); return m ? std::atoi(m) : 1; }();
   const double su = ph.time.alpha_u * ph.diff.amp, st = ph.time.alpha_t * ph.rho.amp * ph.cp.amp;
   auto residual = [&](hipStream_t s) {  // K1: one thread per element (default) or the 32-lanes-per-element form (MHA_K1=lanes)
-    if (ro_.k1_thread) launch_thermal_affine_residual(dim_, order_, blockDev(), ph, ro_.geo.data(), ro_.tab1d, res, s);
+    if (ro_.k1_thread) launch_thermal_affine_residual(dim_, order_, blockDev(), ph, ro_.geo.data(), ro_.tab1d, res, ro_.max_abs_coord, s);
     else launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, s);
   };
   auto jacobian = [&](hipStream_t s) {  // K2: pattern GEMMs on the matrix cores when the rows group, row blocks otherwise

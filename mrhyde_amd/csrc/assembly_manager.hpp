@@ -133,6 +133,7 @@ class AssemblyManager {
     DeviceBuffer<double> khat, phi, dphi, gw, gp, k1_t1, k1_t2;
     AffineTables1D tab1d;  // thread-per-element K1
     bool k1_thread = false;
+    double max_abs_coord[3] = {0, 0, 0};  // of the block's vertices (bounds the arguments of a closed-form source)
     int slot_bytes = 1;
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
     bool all_rows_covered = false;

@@ -32,10 +32,14 @@ __device__ __forceinline__ void invert<3>(const double *J, double *Ji, double &d
 // sin(x) for moderate |x|: Cody-Waite reduction by pi/2 and the fdlibm kernel polynomials (< 1 ulp);
 // falls back to the library routine for huge arguments.  About a quarter of the instructions of the
 // full-range sin(), which matters because the source term is evaluated at every integration point.
-// (the full-range routine stays out of line: inlined at every integration point it made the kernels several times larger)
-__device__ __noinline__ double sin_full_range(double x) { return sin(x); }
+// sin_reduced: the reduction + polynomials alone, valid for |x| < 1e5 -- for kernels whose launcher has checked the bound
+// (no branch, no call: the full-range routine inlined at every integration point made those kernels several times larger).
+__device__ __forceinline__ double sin_reduced(double x);
 __device__ __forceinline__ double sin_moderate(double x) {
-  if (!(fabs(x) < 1.0e5)) return sin_full_range(x);
+  if (!(fabs(x) < 1.0e5)) return sin(x);
+  return sin_reduced(x);
+}
+__device__ __forceinline__ double sin_reduced(double x) {
   const double kd = rint(x * 6.36619772367581382433e-01);
   const int k = (int)kd;
   double r = fma(-kd, 1.57079632673412561417e+00, x);
@@ -120,7 +124,7 @@ __device__ __noinline__ double eval_expression(const FuncDesc &f, const double *
 // EXPR: whether MHA_FUNC_EXPRESSION can occur.  The interpreter is a real call with a private stack; a kernel that
 // merely contains the call pays its register budget and scratch (the affine element kernel went from 8 to 2 waves per
 // SIMD), so kernels are instantiated both ways and the launcher picks by has_expression().
-template <int DIM, bool EXPR = false>
+template <int DIM, bool EXPR = false, bool SMALL_ARGS = false>
 __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int nq, const double *x,
                                             const double *nrm = nullptr, double h = 0.0) {
   if (f.kind == MHA_FUNC_CONSTANT) return f.amp;
@@ -130,7 +134,7 @@ __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int
   }
   double s = f.amp;
 #pragma unroll
-  for (int d = 0; d < DIM; ++d) s *= sin_moderate(f.freq[d] * x[d]);
+  for (int d = 0; d < DIM; ++d) s *= SMALL_ARGS ? sin_reduced(f.freq[d] * x[d]) : sin_moderate(f.freq[d] * x[d]);
   return s;
 }
 

@@ -13,7 +13,9 @@
 // DIM x (order + 1)^DIM.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -56,8 +58,9 @@ __device__ __forceinline__ void apply1d(double *v, const double *T) {
 // 64 consecutive elements per wavefront.  Their LID lists (64 x N ints) and geometry records (64 x 20 doubles) are
 // contiguous in memory: fetched with coalesced loads into a per-wave LDS buffer and read back one record per lane
 // (odd strides: conflict-free), instead of 64 different cache lines per load instruction.
-template <int DIM, int P, bool TR, bool EXPR>
-__global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(BlockDev b, ThermalDev ph,
+// SMALL: the launcher has checked |freq_d x_d| < 1e5 over the mesh (closed-form source): sines without the full-range fallback
+template <int DIM, int P, bool TR, bool EXPR, bool SMALL>
+__global__ __launch_bounds__(kK1tThreads, 2) void thermal_affine_residual_kernel(BlockDev b, ThermalDev ph,
                                                                               const double *__restrict__ geo,
                                                                               AffineTables1D tab, double *res, int dbg) {
   constexpr int M = P + 1, N = cpow(M, DIM);
@@ -148,63 +151,71 @@ __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(Bl
       if (r != c && J[r][c] != 0.0) separable = false;
   double s1d[DIM][M];
   if (dbg & 2) separable = false;
-  if (separable) {
+  if (__builtin_amdgcn_ballot_w64(!separable) == 0) {
 #pragma unroll
     for (int d = 0; d < DIM; ++d)
 #pragma unroll
-      for (int q = 0; q < M; ++q) s1d[d][q] = sin_moderate(ph.source.freq[d] * (xc[d] + J[d][d] * tab.gp[q]));
+      for (int q = 0; q < M; ++q) s1d[d][q] = SMALL ? sin_reduced(ph.source.freq[d] * (xc[d] + J[d][d] * tab.gp[q])) : sin_moderate(ph.source.freq[d] * (xc[d] + J[d][d] * tab.gp[q]));
   }
 
-  // point loop: W accumulates what multiplies the basis VALUES at each point (the flux terms enter through D^T)
+  // point loop: W accumulates what multiplies the basis VALUES at each point (the flux terms enter through D^T).  Two
+  // copies, chosen per wavefront: every lane's element is axis-aligned (separable source) or the general evaluation
+  auto point_loop = [&](auto sep_tag, double *W) {
+    constexpr bool SEP = decltype(sep_tag)::value;
+#pragma unroll
+    for (int pt = 0; pt < N; ++pt) {
+      const int q0 = pt % M, q1 = (pt / M) % M, q2 = pt / (M * M);
+      const int qd[3] = {q0, q1, q2};
+      double gh[DIM], wq = 1.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        wq *= tab.gw[qd[d]];
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < M; ++v) {
+          const int src = d == 0 ? with_digit<M, 0>(pt, v) : (d == 1 ? with_digit<M, 1>(pt, v) : with_digit<M, 2>(pt, v));
+          s += tab.dcol[qd[d] * M + v] * U[src];
+        }
+        gh[d] = s;
+      }
+      double f;
+      if constexpr (SEP) {
+        f = ph.source.amp;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) f *= s1d[d][qd[d]];
+      } else {
+        double x[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+          double s = xc[r];
+#pragma unroll
+          for (int c = 0; c < DIM; ++c) s += J[r][c] * tab.gp[qd[c]];
+          x[r] = s;
+        }
+        f = eval_func<DIM, EXPR, SMALL>(ph.source, e, pt, N, x);
+      }
+      const double tt = TR ? Ud[TR ? pt : 0] : 0.0;
+      W[pt] += (rc * tt - f) * det * wq;
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {  // F_a = w_q kappa detJ sum_c (J^-1 J^-T)_ac d_c T
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) s += G[a][c] * gh[c];
+        const double Fa = wq * kap * s;
+#pragma unroll
+        for (int v = 0; v < M; ++v) {
+          const int dst = a == 0 ? with_digit<M, 0>(pt, v) : (a == 1 ? with_digit<M, 1>(pt, v) : with_digit<M, 2>(pt, v));
+          W[dst] += tab.dcol[qd[a] * M + v] * Fa;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one point at a time: interleaved, the points' temporaries cost another 150 registers
+    }
+  };
   double W[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) W[i] = 0.0;
-#pragma unroll
-  for (int pt = 0; pt < N; ++pt) {
-    const int q0 = pt % M, q1 = (pt / M) % M, q2 = pt / (M * M);
-    const int qd[3] = {q0, q1, q2};
-    double gh[DIM], x[3] = {0.0, 0.0, 0.0}, wq = 1.0;
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      wq *= tab.gw[qd[d]];
-      double s = 0.0;
-#pragma unroll
-      for (int v = 0; v < M; ++v) {
-        const int src = d == 0 ? with_digit<M, 0>(pt, v) : (d == 1 ? with_digit<M, 1>(pt, v) : with_digit<M, 2>(pt, v));
-        s += tab.dcol[qd[d] * M + v] * U[src];
-      }
-      gh[d] = s;
-    }
-    double f;
-    if (separable) {
-      f = ph.source.amp;
-#pragma unroll
-      for (int d = 0; d < DIM; ++d) f *= s1d[d][qd[d]];
-    } else {
-#pragma unroll
-      for (int r = 0; r < DIM; ++r) {
-        double s = xc[r];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) s += J[r][c] * tab.gp[qd[c]];
-        x[r] = s;
-      }
-      f = eval_func<DIM, EXPR>(ph.source, e, pt, N, x);
-    }
-    const double tt = TR ? Ud[TR ? pt : 0] : 0.0;
-    W[pt] += (rc * tt - f) * det * wq;
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) {  // F_a = w_q kappa detJ sum_c (J^-1 J^-T)_ac d_c T
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < DIM; ++c) s += G[a][c] * gh[c];
-      const double Fa = wq * kap * s;
-#pragma unroll
-      for (int v = 0; v < M; ++v) {
-        const int dst = a == 0 ? with_digit<M, 0>(pt, v) : (a == 1 ? with_digit<M, 1>(pt, v) : with_digit<M, 2>(pt, v));
-        W[dst] += tab.dcol[qd[a] * M + v] * Fa;
-      }
-    }
-  }
+  if (__builtin_amdgcn_ballot_w64(!separable) == 0) point_loop(std::true_type(), W);
+  else point_loop(std::false_type(), W);
   // point weights -> residual rows
   apply1d<DIM, M, 0, false>(W, tab.phi);
   apply1d<DIM, M, 1, false>(W, tab.phi);
@@ -221,18 +232,21 @@ __global__ __launch_bounds__(kK1tThreads) void thermal_affine_residual_kernel(Bl
 
 template <int DIM, int P>
 void launch_t(const BlockDev &b, const ThermalDev &ph, const double *geo, const AffineTables1D &tab, double *res,
-              hipStream_t stream) {
+              bool small_args, hipStream_t stream) {
   if (b.e_count <= 0) return;
   const int grid = (b.e_count + kK1tThreads - 1) / kK1tThreads;  // a wavefront takes 64 consecutive elements
   const bool tr = ph.time.transient != 0;
   static const int dbg = [] { const char *m = std::getenv("MHA_K1_DBG"); return m ? std::atoi(m) : 0; }();  // profiling aid: 1 no atomics, 2 general source evaluation, 4 no gather
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1tThreads), 0, stream, b, ph, geo, tab, res, dbg); };
   if (has_expression(ph.source)) {
-    if (tr) go(thermal_affine_residual_kernel<DIM, P, true, true>);
-    else go(thermal_affine_residual_kernel<DIM, P, false, true>);
+    if (tr) go(thermal_affine_residual_kernel<DIM, P, true, true, false>);
+    else go(thermal_affine_residual_kernel<DIM, P, false, true, false>);
+  } else if (small_args) {
+    if (tr) go(thermal_affine_residual_kernel<DIM, P, true, false, true>);
+    else go(thermal_affine_residual_kernel<DIM, P, false, false, true>);
   } else {
-    if (tr) go(thermal_affine_residual_kernel<DIM, P, true, false>);
-    else go(thermal_affine_residual_kernel<DIM, P, false, false>);
+    if (tr) go(thermal_affine_residual_kernel<DIM, P, true, false, false>);
+    else go(thermal_affine_residual_kernel<DIM, P, false, false, false>);
   }
   MHA_HIP(hipGetLastError());
 }
@@ -244,12 +258,15 @@ bool thermal_affine_residual_supported(int dim, int order, int nq1) {
 }
 
 void launch_thermal_affine_residual(int dim, int order, const BlockDev &b, const ThermalDev &ph, const double *geo,
-                                    const AffineTables1D &tab, double *res, hipStream_t stream) {
-  if (dim == 2 && order == 1) return launch_t<2, 1>(b, ph, geo, tab, res, stream);
-  if (dim == 2 && order == 2) return launch_t<2, 2>(b, ph, geo, tab, res, stream);
-  if (dim == 2 && order == 4) return launch_t<2, 4>(b, ph, geo, tab, res, stream);
-  if (dim == 3 && order == 1) return launch_t<3, 1>(b, ph, geo, tab, res, stream);
-  if (dim == 3 && order == 2) return launch_t<3, 2>(b, ph, geo, tab, res, stream);
+                                    const AffineTables1D &tab, double *res, const double *max_abs_coord, hipStream_t stream) {
+  // closed-form source amp prod sin(freq_d x_d): arguments bounded by |freq_d| max|x_d| over the mesh
+  bool small_args = ph.source.kind != MHA_FUNC_CONSTANT && ph.source.kind != MHA_FUNC_IP_ARRAY && ph.source.kind != MHA_FUNC_EXPRESSION;
+  for (int d = 0; d < dim; ++d) small_args = small_args && std::fabs(ph.source.freq[d]) * max_abs_coord[d] < 0.5e5;
+  if (dim == 2 && order == 1) return launch_t<2, 1>(b, ph, geo, tab, res, small_args, stream);
+  if (dim == 2 && order == 2) return launch_t<2, 2>(b, ph, geo, tab, res, small_args, stream);
+  if (dim == 2 && order == 4) return launch_t<2, 4>(b, ph, geo, tab, res, small_args, stream);
+  if (dim == 3 && order == 1) return launch_t<3, 1>(b, ph, geo, tab, res, small_args, stream);
+  if (dim == 3 && order == 2) return launch_t<3, 2>(b, ph, geo, tab, res, small_args, stream);
   MHA_REQUIRE(false, MHA_ERR_INVALID, "thread-per-element residual kernel: unsupported (dim, order)");
 }
 

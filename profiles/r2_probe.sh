@@ -1,9 +1,17 @@
 #!/bin/bash
-# parity, bench lines (pattern K2: serialised / overlapped with K1; row-block K2), per-workgroup end times
+# K1 (thread per element) after the register diet: parity + kernel-level durations
 cd "$GRAFT_REPO_ROOT"
-MHA_K2=pattern timeout -k 10 600 python -m pytest tests/test_thermal_gpu.py -x -q -k "row_owner" 2>&1 | tail -2
-for mode in "MHA_K2=pattern MHA_K1K2_OVERLAP=0" "MHA_K2=pattern MHA_K1K2_OVERLAP=1" "MHA_K2=pattern MHA_K1K2_OVERLAP=2" "MHA_K2=blocks MHA_K1K2_OVERLAP=1" "MHA_K2=blocks MHA_K1=lanes MHA_K1K2_OVERLAP=1"; do
+timeout -k 10 600 python -m pytest tests/test_thermal_gpu.py -x -q -k "row_owner" 2>&1 | tail -2
+export MHA_K1K2_OVERLAP=0
+i=0
+for mode in "MHA_K1_DBG=0" "MHA_K1_DBG=1" "MHA_K1_DBG=2"; do
+  i=$((i+1))
   echo "== $mode"
-  env $mode timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])" || exit 1
+  env $mode bash profiles/kstats.sh r2p$i bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  python - <<PY
+import csv
+for r in csv.DictReader(open("gpurun_out/r2p${i}_kernel_stats.csv")):
+    if "residual" in r["Name"] or "affine_element" in r["Name"] or "jacobian" in r["Name"]:
+        print("  %-60s %4s calls  %9.1f us" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
 done
-MHA_K2=pattern MHA_K1K2_OVERLAP=0 MHA_BP_TIMING=gpurun_out/bp_timing.bin timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 && python profiles/r2_timing.py gpurun_out/bp_timing.bin
