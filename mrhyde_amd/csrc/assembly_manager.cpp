@@ -58,7 +58,8 @@ AssemblyManager::AssemblyManager(const mha_block_desc &desc) {
   MHA_REQUIRE(e == hipSuccess && ndev > 0, MHA_ERR_DEVICE,
               "no HIP device available (" << hipGetErrorString(e) << "): the MI355X path has no CPU fallback");
   MHA_REQUIRE(desc.device >= 0 && desc.device < ndev, MHA_ERR_INVALID, "device ordinal out of range");
-  MHA_HIP(hipSetDevice(desc.device));
+  device_ = desc.device;
+  DeviceGuard guard(device_);  // the caller's current device is restored when the constructor returns
 
   d_ref_basis_.upload(ref_.basis);
   d_ref_grad_.upload(ref_.grad);
@@ -227,14 +228,12 @@ void AssemblyManager::launchPointEngine(int compute_jacobian, const ElemOut &out
 void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "mha_set_graph before mha_set_mesh");
   if (rowptr && colind) {
+    MHA_REQUIRE(rowptr[0] == 0, MHA_ERR_INVALID, "rowptr[0] must be 0");
+    for (int r = 0; r < nrows_; ++r)
+      MHA_REQUIRE(rowptr[r + 1] >= rowptr[r], MHA_ERR_INVALID, "rowptr must be non-decreasing");
+    validate_crs_graph(nrows_, nelem_, n_, h_lids_.data(), rowptr, colind);
     h_rowptr_.assign(rowptr, rowptr + nrows_ + 1);
-    MHA_REQUIRE(h_rowptr_[0] == 0, MHA_ERR_INVALID, "rowptr[0] must be 0");
-    for (int r = 0; r < nrows_; ++r)
-      MHA_REQUIRE(h_rowptr_[r + 1] >= h_rowptr_[r], MHA_ERR_INVALID, "rowptr must be non-decreasing");
     h_colind_.assign(colind, colind + h_rowptr_[nrows_]);
-    for (int r = 0; r < nrows_; ++r)
-      for (int p = h_rowptr_[r] + 1; p < h_rowptr_[r + 1]; ++p)
-        MHA_REQUIRE(h_colind_[p] > h_colind_[p - 1], MHA_ERR_INVALID, "colind must be strictly ascending in row " << r);
   } else {
     MHA_REQUIRE(!rowptr && !colind, MHA_ERR_INVALID, "pass both rowptr and colind, or neither");
     build_crs_graph(nrows_, nelem_, n_, h_lids_.data(), h_rowptr_, h_colind_);
@@ -415,7 +414,14 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
                 "assembly path " << path << " is not available for this physics module");
   }
   if (path == MHA_PATH_AUTO) {
-    if (!ro_.ready && thermal_row_owner_supported(dim_, order_, ref_.nq1)) prepareRowOwner();
+    if (!ro_.ready && !ro_.failed && thermal_row_owner_supported(dim_, order_, ref_.nq1)) {
+      try {
+        prepareRowOwner();
+      } catch (const Error &) {  // e.g. a row exceeds the row-block caps: AUTO keeps the general path, once and for all
+        ro_ = RowOwnerData();
+        ro_.failed = true;
+      }
+    }
     // affine elements with constant coefficients: fused row-owner kernels; otherwise dense element matrices + the
     // atomic-free row gather (4.1 ms against 7.4 ms for the atomic scatter on the perturbed config-2 mesh)
     path = rowOwnerUsable(nullptr) ? MHA_PATH_ROW_OWNER : MHA_PATH_ROW_GATHER;
@@ -464,6 +470,12 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         wkset_.numElem = nelem_;
         wkset_.res = o;
         useGeneralKernel(false);
+        if (!wkset_.use_general) {
+          // MHA_BASELINE_ELEMENT_KERNEL=1 (cross-check knob): the baseline kernel ACCUMULATES into local_J / local_res
+          // (updateJac / updateRes convention) and ignores local_store, so the scratch must start from zero
+          if (compute_jacobian) MHA_HIP(hipMemsetAsync(d_gather_J_.data(), 0, sizeof(double) * d_gather_J_.size(), stream_));
+          MHA_HIP(hipMemsetAsync(d_gather_res_.data(), 0, sizeof(double) * d_gather_res_.size(), stream_));
+        }
         physics_->volumeResidual();
       } else {
         launchPointEngine(compute_jacobian, o, 0, nelem_);
@@ -940,34 +952,6 @@ void AssemblyManager::prepareRowOwner() {
       khat[static_cast<size_t>(nsym) * n_ * n_ + idx] = m;
     }
   ro.khat.upload(khat);
-  {
-    // operand tables of the matrix-core K1 (kernels/thermal_row_owner.hip): one double per lane and MFMA.
-    //   t1[(c, h)][s][lane]: A[row = point 16h + l15][k = dof 4s + l4], c < dim: d N_j / d xi_c, c = dim: N_j
-    //   t2[it][(c2, h, t)][lane]: A[row = dof 16 it + l15][k = point 16h + 4t + l4], c2 = 0: N_i, c2 = 1 + a: d N_i / d xi_a
-    const int H = (nq_ + 15) / 16, KJ = (n_ + 3) / 4, IT = (n_ + 15) / 16, K2S = (dim_ + 1) * H * 4;
-    std::vector<double> t1(static_cast<size_t>(dim_ + 1) * H * KJ * 64, 0.0), t2(static_cast<size_t>(IT) * K2S * 64, 0.0);
-    for (int c = 0; c <= dim_; ++c)
-      for (int h = 0; h < H; ++h)
-        for (int s = 0; s < KJ; ++s)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int q = 16 * h + (lane & 15), j = 4 * s + (lane >> 4);
-            if (q >= nq_ || j >= n_) continue;
-            t1[((static_cast<size_t>(c) * H + h) * KJ + s) * 64 + lane] =
-                c < dim_ ? ref_.grad[(static_cast<size_t>(j) * nq_ + q) * dim_ + c] : ref_.basis[j * nq_ + q];
-          }
-    for (int it = 0; it < IT; ++it)
-      for (int c2 = 0; c2 <= dim_; ++c2)
-        for (int h = 0; h < H; ++h)
-          for (int t = 0; t < 4; ++t)
-            for (int lane = 0; lane < 64; ++lane) {
-              const int i = 16 * it + (lane & 15), q = 16 * h + 4 * t + (lane >> 4);
-              if (q >= nq_ || i >= n_) continue;
-              t2[(static_cast<size_t>(it) * K2S + (c2 * H + h) * 4 + t) * 64 + lane] =
-                  c2 == 0 ? ref_.basis[i * nq_ + q] : ref_.grad[(static_cast<size_t>(i) * nq_ + q) * dim_ + c2 - 1];
-            }
-    ro.k1_t1.upload(t1);
-    ro.k1_t2.upload(t2);
-  }
   // thread-per-element K1: 1-D tables by value; the collocation derivative D = Phi'^T Phi^-T (Gauss-Jordan on the
   // small, well-conditioned point-value matrix)
   ro.k1_thread = false;
@@ -1048,9 +1032,7 @@ void AssemblyManager::prepareBlockPattern() {
   const int nsym = dim_ * (dim_ + 1) / 2;
   std::vector<double> khat(static_cast<size_t>(nsym + 1) * n_ * n_);
   ro_.khat.download(khat.data());
-  int dev = 0, num_cu = 0;
-  MHA_HIP(hipGetDevice(&dev));
-  MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  int num_cu = current_device_num_cus();
   if (const char *m = std::getenv("MHA_BP_WGS")) num_cu = std::max(1, std::atoi(m));
   const BlockPatternPlan h = build_block_patterns(rb, n_, nsym, h_rowptr_.data(), has_fixed_ ? h_fixed_.data() : nullptr,
                                                   slot.data(), elem_slot_bytes_, khat.data(), num_cu, size_t(142) * 1024, 256,
@@ -1149,9 +1131,6 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   af.erec = ro_.erec.data();
   af.pair_off16 = ro_.pair_off16.data();
   af.slot_pair = ro_.slot_pair.data();
-  af.k1_t1 = ro_.k1_t1.data();
-  af.k1_t2 = ro_.k1_t2.data();
-  if (const char *m = std::getenv("MHA_K1_DBG")) af.k1_dbg = std::atoi(m);
   RowOut out;
   out.res = res;
   out.vals = crs_vals;

@@ -67,6 +67,7 @@ class AssemblyManager {
   const std::vector<int32_t> &rowptr() const { return h_rowptr_; }
   const std::vector<int32_t> &colind() const { return h_colind_; }
   int numRows() const { return nrows_; }
+  int device() const { return device_; }
 
  private:
   void requireReady(bool need_graph) const;
@@ -101,6 +102,7 @@ class AssemblyManager {
   bool has_mesh_ = false, has_graph_ = false;
   int last_path_ = 0;
   hipStream_t stream_ = nullptr;
+  int device_ = 0;  // the context's device (mha_block_desc.device): every C-ABI entry runs under a DeviceGuard for it
 
   RefTables ref_;
   DeviceBuffer<double> d_ref_basis_, d_ref_grad_, d_ref_wts_, d_nodeval_, d_nodegrad_;
@@ -120,6 +122,7 @@ class AssemblyManager {
   // row-owner path (row_blocks.hpp, kernels/thermal_row_owner.hip), built lazily
   struct RowOwnerData {
     bool ready = false;
+    bool failed = false;  // prepareRowOwner threw: AUTO stops trying
     RowBlocks rb;
     DeviceBuffer<int32_t> row_ptr, rows, row_off, acc_size, elem_ptr, elems, pair_ptr, affine_list, general_list;
     DeviceBuffer<int32_t> pair_off, row_base, row_len, emask, epbase, seg_ptr, seg_acc, seg_base, seg_len;
@@ -130,7 +133,7 @@ class AssemblyManager {
     DeviceBuffer<int> slot_pair;  // LID slots paired by co-ownership (K2 lane layout)
     DeviceBuffer<uint32_t> pairs;
     DeviceBuffer<uint8_t> slot, flags;
-    DeviceBuffer<double> khat, phi, dphi, gw, gp, k1_t1, k1_t2;
+    DeviceBuffer<double> khat, phi, dphi, gw, gp;
     AffineTables1D tab1d;  // thread-per-element K1
     bool k1_thread = false;
     double max_abs_coord[3] = {0, 0, 0};  // of the block's vertices (bounds the arguments of a closed-form source)

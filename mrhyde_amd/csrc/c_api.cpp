@@ -23,9 +23,20 @@ struct mha_context {
 
 namespace {
 thread_local std::string g_last_error;
+// device the caller had current when the entry point was called, once mgr() has switched to the context's (-1: not switched)
+thread_local int g_caller_device = -1;
+
+struct RestoreCallerDevice {
+  RestoreCallerDevice() { g_caller_device = -1; }
+  ~RestoreCallerDevice() {
+    if (g_caller_device >= 0) (void)hipSetDevice(g_caller_device);
+    g_caller_device = -1;
+  }
+};
 
 template <class F>
 int guarded(F &&f) {
+  RestoreCallerDevice restore;
   try {
     f();
     g_last_error.clear();
@@ -42,8 +53,16 @@ int guarded(F &&f) {
   }
 }
 
+// The context's manager, with the context's device made current (uploads, allocations, launches, stream and event
+// creation all go to the device the context was created on); guarded() restores the caller's device.
 mha::AssemblyManager &mgr(mha_context *ctx) {
   MHA_REQUIRE(ctx != nullptr, MHA_ERR_INVALID, "null context");
+  int cur = -1;
+  MHA_HIP(hipGetDevice(&cur));
+  if (cur != ctx->mgr.device()) {
+    if (g_caller_device < 0) g_caller_device = cur;
+    MHA_HIP(hipSetDevice(ctx->mgr.device()));
+  }
   return ctx->mgr;
 }
 }  // namespace
@@ -67,7 +86,13 @@ int mha_block_create(const mha_block_desc *desc, mha_context **out) {
   });
 }
 
-void mha_block_destroy(mha_context *ctx) { delete ctx; }
+void mha_block_destroy(mha_context *ctx) {
+  if (!ctx) return;
+  (void)guarded([&] {
+    mha::DeviceGuard guard(ctx->mgr.device());
+    delete ctx;
+  });
+}
 
 int mha_set_stream(mha_context *ctx, void *hip_stream) {
   return guarded([&] { mgr(ctx).setStream(static_cast<hipStream_t>(hip_stream)); });

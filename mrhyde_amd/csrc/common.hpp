@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdlib>
 #include <cstdint>
 #include <sstream>
 #include <stdexcept>
@@ -80,6 +81,52 @@ class DeviceBuffer {
   T *p_ = nullptr;
   size_t n_ = 0;
 };
+
+// Makes `device` the current HIP device for the lifetime of the object and restores the caller's device afterwards:
+// every entry point of the C ABI that works on a context runs under one (a context is bound to the device it was
+// created on, mha_block_desc.device; the caller's current device is none of our business).
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    if (device >= 0 && device != prev_) { MHA_HIP(hipSetDevice(device)); changed_ = true; }
+  }
+  ~DeviceGuard() {
+    if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+
+ private:
+  int prev_ = -1;
+  bool changed_ = false;
+};
+
+// CU count of the CURRENT device (cached per ordinal: launchers size their persistent grids with it).
+inline int current_device_num_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  MHA_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) { int n = 0; MHA_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev)); return n; }
+  if (!cache[dev]) MHA_HIP(hipDeviceGetAttribute(&cache[dev], hipDeviceAttributeMultiprocessorCount, dev));
+  return cache[dev];
+}
+
+// A kernel whose register spills need a large private (scratch) segment makes the runtime carve per-wave x all-wave-slots
+// bytes out of device memory at launch; when that fails the HSA runtime abort()s the process -- nothing the C ABI can
+// catch (the round-1 `MHA_ENGINE_MINW` build variants of the point engine spilled up to 359 registers = 1.4 KB per lane,
+// 0.75 GB for the chip, and their porousMixed run died with SIGABRT).  Launchers of kernels that CAN spill ask here
+// first: more than the limit (default 1 KB per lane, env MHA_MAX_SCRATCH_BYTES) is refused with MHA_ERR_DEVICE.
+template <class Kernel>
+inline void require_modest_scratch(Kernel kern, const char *what) {
+  hipFuncAttributes attr;
+  MHA_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern)));
+  size_t limit = 1024;
+  if (const char *e = std::getenv("MHA_MAX_SCRATCH_BYTES")) limit = static_cast<size_t>(std::atoll(e));
+  MHA_REQUIRE(attr.localSizeBytes <= limit, MHA_ERR_DEVICE,
+              what << ": the kernel needs " << attr.localSizeBytes << " B of scratch per lane (limit " << limit
+                   << "): refusing a launch the runtime may not be able to back");
+}
 
 inline int ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
 

@@ -105,10 +105,6 @@ struct AffineDev {
   const uint16_t *pair_off16 = nullptr;  // block-major [pair]: accumulator offset of the pair's row
   const int *slot_pair = nullptr;        // [2*ceil(n/2)]: LID slots paired by co-ownership (-1 = none), K2's lane layout
   int slot_bytes = 1;              // 1 (uint8) or 2 (uint16)
-  // MFMA operand tables of the matrix-core K1 (thermal_row_owner.hip: thermal_affine_element_mfma_kernel), one double
-  // per lane and MFMA: k1_t1 [(component, point half)][dof step][64], k1_t2 [dof tile][(component, point half, t)][64]
-  const double *k1_t1 = nullptr, *k1_t2 = nullptr;
-  int k1_dbg = 0;  // profiling aid (env MHA_K1_DBG): 1 no residual atomics, 2 no source evaluation, 4 no gather
 };
 
 // 1-D tables of the thread-per-element residual kernel (kernels/thermal_affine_residual.hip), passed by value: as many

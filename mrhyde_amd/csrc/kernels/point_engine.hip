@@ -453,12 +453,7 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
     if (tables + g * per_group <= 160 * 1024 && (g == 1 || vl.n_tot <= 64)) { groups = g; break; }
   const size_t lds = tables + groups * per_group;
   MHA_REQUIRE(lds <= 160 * 1024, MHA_ERR_INVALID, "element needs " << lds << " B of LDS (limit 160 KB)");
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    MHA_HIP(hipGetDevice(&dev));
-    MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int num_cu = current_device_num_cus();
   const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(size_t(2), (160 * 1024) / lds)));
   PhysParamsDev ppd = pp;
   if (const char *st = std::getenv("MHA_ENGINE_STOP")) { if (pp.physics > 0) ppd.p[7] = std::atof(st); }
@@ -466,6 +461,7 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
   const uint8_t *s8 = (slot && slot_bytes == 1) ? static_cast<const uint8_t *>(slot) : nullptr;
   const uint16_t *s16 = (slot && slot_bytes == 2) ? static_cast<const uint16_t *>(slot) : nullptr;
   auto go = [&](auto kern) {
+    require_modest_scratch(kern, "point engine");
     MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kEngineThreads), lds, stream, b, vl, ppd, tm, out, s8, s16);

@@ -473,12 +473,7 @@ void launch_one(const BlockDev &b, const ThermalDev &ph, const AffineDev &af, co
   using S1 = GK<DIM, P, NQ1, true>;
   const size_t lds = sizeof(double) * (tr ? S1::SHARED + (size_t)S1::EPB * S1::REC : S0::SHARED + (size_t)S0::EPB * S0::REC);
   MHA_REQUIRE(lds <= 150 * 1024, MHA_ERR_INVALID, "general element kernel needs " << lds << " B of LDS");
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    MHA_HIP(hipGetDevice(&dev));
-    MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int num_cu = current_device_num_cus();
   // persistent workgroups: as many as are resident at once (LDS-limited), each wave strides over the elements
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
   const int grid = std::max(1, std::min((b.e_count + S0::EPB - 1) / S0::EPB, num_cu * per_cu));

@@ -143,29 +143,6 @@ __global__ __launch_bounds__(256) void affine_geometry_kernel(BlockDev b, double
 // K1: element-wise residual
 // ---------------------------------------------------------------------------------------------
 
-#ifndef MHA_K1_DPP
-#define MHA_K1_DPP 0  // 1: residual contraction transposed (lane = point), DPP row reductions instead of LDS broadcasts;
-                      // parity-tested, same speed alone and beside K2 (profiles/r1_ab_k1_dpp.log), so the simpler form stays
-#endif
-
-// x + (x moved across lanes by the DPP control CTRL), lanes of rows outside ROWMASK add zero.  v_mov_b32_dpp x2 + v_add_f64:
-// data movement inside the vector ALU, no LDS.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_add(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xF, false);
-  return x + __hiloint2double(hi, lo);
-}
-// sum over the 32 lanes of a half wave; complete in lanes 16..31 (and 48..63)
-[[maybe_unused]] __device__ __forceinline__ double half_wave_sum(double x) {
-  x = dpp_add<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
-  x = dpp_add<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
-  x = dpp_add<0x141, 0xF>(x);  // row_half_mirror
-  x = dpp_add<0x140, 0xF>(x);  // row_mirror: every lane of a 16-lane row holds the row's sum
-  x = dpp_add<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
-  return x;
-}
-
 template <int DIM, int P, int NQ1, bool TR>
 struct EK {
   static constexpr int M = P + 1;
@@ -268,56 +245,12 @@ __global__ __launch_bounds__(kK1Threads) void thermal_affine_element_kernel(Bloc
 #pragma unroll
       for (int c = 0; c < DIM; ++c) s += G[a][c] * gh[c];
       my_F[a] = wq * kap * s;
-      if (!MHA_K1_DPP) E[S::O_F + q * DIM + a] = my_F[a];
+      E[S::O_F + q * DIM + a] = my_F[a];
     }
     const double f = eval_func<DIM, EXPR>(ph.source, e, q, NQ, x);
     my_rq = (rc * tt - f) * E[S::O_DET] * wq;
-    if (!MHA_K1_DPP) E[S::O_RQ + q] = my_rq;
+    E[S::O_RQ + q] = my_rq;
   }
-#if MHA_K1_DPP
-  // C'. residual rows, transposed: this lane keeps ITS point's data in registers and walks the dofs; the sum over the
-  //     points is a DPP reduction over the half wave (the LDS broadcasts of the other form kept the LDS pipe busy for
-  //     78 % of the kernel and collided with K2's accumulator traffic).  Result of dof ib lands in lane 16 + (ib & 15).
-  {
-    int qq = (l < NQ) ? l : 0;
-    double Pt[DIM][M], Dt[DIM][M];  // 1-D basis values / derivatives at this lane's point, per direction
-#pragma unroll
-    for (int d = 0; d < DIM; ++d) {
-      const int qd = qq % NQ1;
-      qq /= NQ1;
-#pragma unroll
-      for (int a = 0; a < M; ++a) { Pt[d][a] = phi[a * NQ1 + qd]; Dt[d][a] = dphi[a * NQ1 + qd]; }
-    }
-    double mine[(N + 15) / 16];
-#pragma unroll
-    for (int k = 0; k < (N + 15) / 16; ++k) mine[k] = 0.0;
-#pragma unroll
-    for (int ib = 0; ib < N; ++ib) {
-      const int i0 = ib % M, i1 = (ib / M) % M, i2 = ib / (M * M);
-      double c;
-      if constexpr (DIM == 2) {
-        (void)i2;
-        c = my_rq * Pt[0][i0] * Pt[1][i1] + my_F[0] * Dt[0][i0] * Pt[1][i1] + my_F[1] * Pt[0][i0] * Dt[1][i1];
-      } else {
-        const double a12 = Pt[1][i1] * Pt[DIM - 1][i2];
-        c = (my_rq * Pt[0][i0] + my_F[0] * Dt[0][i0]) * a12 +
-            Pt[0][i0] * (my_F[1] * Dt[1][i1] * Pt[DIM - 1][i2] + my_F[DIM - 1] * Pt[1][i1] * Dt[DIM - 1][i2]);
-      }
-      const double sum = half_wave_sum(c);
-      if (l >= 16 && (l & 15) == (ib & 15)) mine[ib >> 4] = sum;
-    }
-    if (active && l >= 16) {
-#pragma unroll
-      for (int k = 0; k < (N + 15) / 16; ++k) {
-        const int ib = (l & 15) + 16 * k;
-        if (ib >= N) continue;
-        const int row = b.lids[(size_t)e * N + s_offs[ib]];
-        if (!(b.fixed && b.fixed[row])) atomicAdd(res + row, -mine[k]);  // -res.val(), fixed rows skipped
-      }
-    }
-  }
-  return;
-#endif
   __syncthreads();
 
   // C. residual rows by quadrature (l = LID slot): r_i = sum_q rq N_i + F . grad_ref N_i
@@ -356,164 +289,6 @@ __global__ __launch_bounds__(kK1Threads) void thermal_affine_element_kernel(Bloc
       atomicAdd(res + row, -r);  // the global vector receives -res.val() (assemblyManager.cpp:4094)
     }
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1 on the matrix cores: one wavefront per 16 elements.
-//   fields:    grad_ref T(q) [and T_t(q)] = sum_j Nhat-tables[(c,q)][j] * u_j        [(c,q) x dofs] x [dofs x 16 elements]
-//   pointwise: F = w kappa detJ J^-1 J^-T grad_ref T,  rq = (rho cp T_t - f) detJ w   (the lane that received a
-//              point's field values from the first product owns that point: no data movement between the products)
-//   residual:  r_i = sum_(c,q) tables[i][(c,q)] * {rq, F}(q)                           [dofs x (c,q)] x [(c,q) x 16 elements]
-// Operand maps of v_mfma_f64_16x16x4_f64: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15], D reg t:
-// row = (lane>>4) + 4t, col = lane&15.  With the element in the column, lane (l15, l4) holds for ITS element the points
-// q = 16h + l4 + 4t of every field component; the second product numbers its depth k = ((c, h, t), l4) accordingly.
-// The constant operands come straight from memory (59 KB of tables, L2/L1 resident, one coalesced 8-byte load per lane
-// and MFMA): no LDS, so the kernel stays co-resident with K2.  Same arithmetic as thermal_affine_element_kernel
-// (reference: src/physics/thermal.cpp:125-163 with the gather / seeding of src/tools/workset.cpp:823-859, 559-792),
-// about 70 instead of 500 vector instructions per element.
-// ---------------------------------------------------------------------------------------------
-template <int DIM, int P, int NQ1, bool TR, bool EXPR>
-__global__ __launch_bounds__(256, 2) void thermal_affine_element_mfma_kernel(BlockDev b, ThermalDev ph, AffineDev af,
-                                                                             double *res) {
-  typedef double v4d __attribute__((ext_vector_type(4)));
-  using S = EK<DIM, P, NQ1, TR>;
-  constexpr int N = S::N, NQ = S::NQ;
-  constexpr int H = (NQ + 15) / 16;        // point halves: q = 16h + l4 + 4t
-  constexpr int KJ = (N + 3) / 4;          // depth steps of the field product (dofs)
-  constexpr int IT = (N + 15) / 16;        // dof tiles of the residual product
-  constexpr int NC1 = DIM + 1;             // components of the field tables: d/dxi_a, value
-  constexpr int K2S = (DIM + 1) * H * 4;   // depth steps of the residual product
-  static_assert(N <= 32 && NQ <= 32, "two tiles of 16");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const TimeDev &tm = ph.time;
-  // the residual product's table (32 KB for Q2 hexes) lives in LDS for the life of the persistent workgroup: read
-  // from memory it was 0.9 GB of L2 traffic per assembly; the field table (22 KB) stays in L1/L2
-  extern __shared__ double t2s[];
-  for (int i = threadIdx.x; i < IT * K2S * 64; i += 256) t2s[i] = af.k1_t2[i];
-  int offs_j[KJ], offs_i[IT][4];  // LID slots of this lane's dofs in the two products
-#pragma unroll
-  for (int s = 0; s < KJ; ++s) offs_j[s] = (4 * s + l4 < N) ? b.offsets[4 * s + l4] : 0;
-#pragma unroll
-  for (int it = 0; it < IT; ++it)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) offs_i[it][t] = (16 * it + l4 + 4 * t < N) ? b.offsets[16 * it + l4 + 4 * t] : 0;
-  __syncthreads();
-  for (int tile = blockIdx.x * 4 + wave; tile * 16 < b.e_count; tile += gridDim.x * 4) {
-  const int el = tile * 16 + l15;
-  const bool valid = el < b.e_count;
-  const int e = b.e_begin + (valid ? el : 0);
-  const int32_t *L = b.lids + (size_t)e * N;
-  int opaque = 0;  // keeps the (loop-invariant) field-table loads inside the loop: hoisted they cost 84 registers
-  asm volatile("" : "+s"(opaque));
-
-  // ---- gather + seeding values: B operand U[j = 4s + l4][element l15] ----
-  double ub[KJ], ud[TR ? KJ : 1];
-#pragma unroll
-  for (int s = 0; s < KJ; ++s) {
-    const int j = 4 * s + l4;
-    ub[s] = 0.0;
-    if constexpr (TR) ud[s] = 0.0;
-    if (valid && j < N && !(af.k1_dbg & 4)) {
-      const int row = L[offs_j[s]];
-      const double cu = tm.u[row];
-      double ue = cu;
-      if constexpr (TR) {
-        const double *cp = tm.u_prev + (size_t)row * tm.nsteps;
-        const double *cs = tm.u_stage + (size_t)row * tm.nstages;
-        double beta_u = (1.0 - tm.alpha_u) * cp[0];
-        for (int k = 0; k < tm.stage; ++k) beta_u += tm.stage_ratio[k] * (cs[k] - cp[0]);
-        double beta_t = 0.0;
-        for (int k = 1; k < tm.nsteps + 1; ++k) beta_t += tm.bdf[k] * cp[k - 1];
-        beta_t *= tm.timewt;
-        ue = tm.alpha_u * cu + beta_u;
-        ud[s] = tm.alpha_t * cu + beta_t;
-      }
-      ub[s] = ue;
-    }
-  }
-  // ---- fields at the points: one 16 x 16 tile per (component, half) ----
-  constexpr int NT1 = (TR ? NC1 : DIM) * H;
-  v4d f1[NT1];
-#pragma unroll
-  for (int r1 = 0; r1 < NT1; ++r1) {
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    const double *T1 = af.k1_t1 + (size_t)r1 * KJ * 64 + lane + opaque;
-    const bool value_rows = r1 >= DIM * H;  // T_t from the time-derivative coefficients
-#pragma unroll
-    for (int s = 0; s < KJ; ++s)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T1[s * 64], (TR && value_rows) ? ud[TR ? s : 0] : ub[s], acc, 0, 0, 0);
-    f1[r1] = acc;
-  }
-  // ---- pointwise: this lane's points q = 16h + l4 + 4t of element l15 ----
-  double G[DIM][DIM], J[DIM][DIM], xc[DIM], det;
-  {
-    const double *g = af.geo + (size_t)e * kGeoRec;
-    int k = 0;
-#pragma unroll
-    for (int a = 0; a < DIM; ++a)
-#pragma unroll
-      for (int c = a; c < DIM; ++c) { G[a][c] = g[k]; G[c][a] = G[a][c]; ++k; }
-    det = g[kGeoDet];
-#pragma unroll
-    for (int r = 0; r < DIM; ++r) {
-      xc[r] = g[kGeoXc + r];
-#pragma unroll
-      for (int c = 0; c < DIM; ++c) J[r][c] = g[kGeoJ + r * DIM + c];
-    }
-  }
-  const double kap = ph.diff.amp, rc = ph.rho.amp * ph.cp.amp;  // element-wise constants on this path
-  double V[K2S];  // B operand of the residual product: [(component: rq, F_0..), h, t]
-#pragma unroll
-  for (int h = 0; h < H; ++h)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int q = 16 * h + l4 + 4 * t;
-      const bool ok = valid && q < NQ;
-      double wq = 1.0, xi[DIM], x[3] = {0, 0, 0};
-      {
-        int qq = ok ? q : 0;
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) { wq *= af.gw1d[qq % NQ1]; xi[d] = af.gp1d[qq % NQ1]; qq /= NQ1; }
-      }
-#pragma unroll
-      for (int r = 0; r < DIM; ++r) {
-        double sx = xc[r];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) sx += J[r][c] * xi[c];
-        x[r] = sx;
-      }
-      double gh[DIM];
-#pragma unroll
-      for (int c = 0; c < DIM; ++c) gh[c] = f1[c * H + h][t];
-      const double tt = TR ? f1[(TR ? DIM : 0) * H + h][t] : 0.0;
-#pragma unroll
-      for (int a = 0; a < DIM; ++a) {  // F_a = w_q * kappa * detJ * sum_b (J^{-1}J^{-T})_ab * d_b T
-        double sg = 0.0;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) sg += G[a][c] * gh[c];
-        V[((1 + a) * H + h) * 4 + t] = ok ? wq * kap * sg : 0.0;
-      }
-      double rq = 0.0;
-      if (ok) rq = (rc * tt - ((af.k1_dbg & 2) ? x[0] : eval_func<DIM, EXPR>(ph.source, e, q, NQ, x))) * det * wq;
-      V[(0 * H + h) * 4 + t] = rq;
-    }
-  // ---- residual rows: one tile per 16 dofs, then -res.val() into the global vector (assemblyManager.cpp:4094) ----
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    const double *T2 = t2s + it * K2S * 64 + lane;
-#pragma unroll
-    for (int s2 = 0; s2 < K2S; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[s2 * 64], V[s2], acc, 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int i = 16 * it + l4 + 4 * t;  // basis dof; the result column is this lane's element
-      if (!valid || i >= N) continue;
-      const int row = L[offs_i[it][t]];
-      if ((af.k1_dbg & 1) && acc[t] != 12345.678) continue;
-      if (!(b.fixed && b.fixed[row])) atomicAdd(res + row, -acc[t]);  // fixed rows are skipped (assemblyManager.cpp:4075)
-    }
-  }
-  }  // tiles
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -879,32 +654,6 @@ template <int DIM, int P, int NQ1>
 void launch_k1(const BlockDev &b, const ThermalDev &ph, const AffineDev &af, double *res, hipStream_t stream) {
   if (b.e_count <= 0) return;
   const bool tr = ph.time.transient != 0;
-  // matrix-core form (one wavefront per 16 elements): opt-in with MHA_K1=mfma.  Alone it is a little faster than the
-  // 32-lane form (0.19 against 0.22 ms on config 2) but it shares the CU worse with K2: 0.72 against 0.65 ms per
-  // assembly with the two kernels co-resident (profiles/README.md)
-  const char *k1mode = std::getenv("MHA_K1");
-  const bool use_mfma = k1mode && std::string(k1mode) == "mfma";
-  if (use_mfma && af.k1_t1 && af.k1_t2) {
-    using SK = EK<DIM, P, NQ1, false>;
-    const size_t ldsm = sizeof(double) * ((SK::N + 15) / 16) * ((DIM + 1) * ((SK::NQ + 15) / 16) * 4) * 64;
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0;
-      MHA_HIP(hipGetDevice(&dev));
-      MHA_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    const int gridm = std::max(1, std::min((b.e_count + 63) / 64, num_cu * 2));
-    auto gom = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(gridm), dim3(256), ldsm, stream, b, ph, af, res); };
-    if (has_expression(ph.source)) {
-      if (tr) gom(thermal_affine_element_mfma_kernel<DIM, P, NQ1, true, true>);
-      else gom(thermal_affine_element_mfma_kernel<DIM, P, NQ1, false, true>);
-    } else {
-      if (tr) gom(thermal_affine_element_mfma_kernel<DIM, P, NQ1, true, false>);
-      else gom(thermal_affine_element_mfma_kernel<DIM, P, NQ1, false, false>);
-    }
-    MHA_HIP(hipGetLastError());
-    return;
-  }
   const int grid = (b.e_count + kK1Elems - 1) / kK1Elems;
   // MHA_K1_LDS_PAD: unused dynamic LDS per workgroup -- throttles how many K1 workgroups share a CU with K2 (experiment)
   static const size_t pad = [] { const char *m = std::getenv("MHA_K1_LDS_PAD"); return m ? (size_t)std::atoi(m) : (size_t)0; }();

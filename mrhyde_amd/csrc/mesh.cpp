@@ -68,9 +68,10 @@ void mesh_structured(int dim, int order, const int *nc, const double *lo, const 
     for (int k = 0; k <= (dim == 3 ? N[2] : 0); ++k)
       for (int j = 0; j <= N[1]; ++j)
         for (int i = 0; i <= N[0]; ++i, ++v) {
-          verts[v * dim + 0] = lo[0] + i * h[0];
-          verts[v * dim + 1] = lo[1] + j * h[1];
-          if (dim == 3) verts[v * dim + 2] = lo[2] + k * h[2];
+          const size_t vo = static_cast<size_t>(v) * dim;
+          verts[vo + 0] = lo[0] + i * h[0];
+          verts[vo + 1] = lo[1] + j * h[1];
+          if (dim == 3) verts[vo + 2] = lo[2] + k * h[2];
         }
   }
   // offsets: tensor dof -> slot in the element's LID list (vertices in shards order first)
@@ -96,12 +97,12 @@ void mesh_structured(int dim, int order, const int *nc, const double *lo, const 
         for (int v = 0; v < nn; ++v) {
           const int vi = i + (ref_vertex_sign(dim, v, 0) > 0), vj = j + (ref_vertex_sign(dim, v, 1) > 0);
           const int vk = dim == 3 ? k + (ref_vertex_sign(dim, v, 2) > 0) : 0;
-          cell2vert[e * nn + v] = (vk * (N[1] + 1) + vj) * (N[0] + 1) + vi;
+          cell2vert[static_cast<size_t>(e) * nn + v] = (vk * (N[1] + 1) + vj) * (N[0] + 1) + vi;
         }
         for (int t = 0; t < n; ++t) {
           const int64_t gi = int64_t(order) * i + t % m, gj = int64_t(order) * j + (t / m) % m;
           const int64_t gk = dim == 3 ? int64_t(order) * k + t / (m * m) : 0;
-          lids[e * n + slot[t]] = static_cast<int32_t>((gk * Dy + gj) * Dx + gi);
+          lids[static_cast<size_t>(e) * n + slot[t]] = static_cast<int32_t>((gk * Dy + gj) * Dx + gi);
         }
       }
   if (boundary_dof) {
@@ -136,6 +137,33 @@ void build_row_incidence(int nrows, int nelem, int n, const int32_t *lids, std::
     }
 }
 
+// A caller-supplied graph must be a CRS pattern the scatter can use: rowptr from 0, non-decreasing, nnz < 2^31; columns
+// strictly ascending inside [0, nrows); and every coupling (LID_i, LID_j) of every element present -- the slot maps of
+// the device paths are built by a column search, and a missing column has no slot (the reference's sumIntoValues would
+// drop such a contribution silently; here it is an input error).
+void validate_crs_graph(int nrows, int nelem, int n, const int32_t *lids, const int32_t *rowptr, const int32_t *colind) {
+  MHA_REQUIRE(rowptr[0] == 0, MHA_ERR_INVALID, "rowptr[0] must be 0");
+  for (int r = 0; r < nrows; ++r)
+    MHA_REQUIRE(rowptr[r + 1] >= rowptr[r], MHA_ERR_INVALID, "rowptr must be non-decreasing (row " << r << ")");
+  for (int r = 0; r < nrows; ++r)
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+      MHA_REQUIRE(colind[p] >= 0 && colind[p] < nrows, MHA_ERR_INVALID, "column " << colind[p] << " of row " << r << " outside [0," << nrows << ")");
+      MHA_REQUIRE(p == rowptr[r] || colind[p] > colind[p - 1], MHA_ERR_INVALID, "colind must be strictly ascending in row " << r);
+    }
+  std::atomic<int> bad_elem(-1);
+  parallel_for_rows(nelem, [&](int e, std::vector<int32_t> &) {
+    if (bad_elem.load(std::memory_order_relaxed) >= 0) return;
+    const int32_t *l = lids + static_cast<size_t>(e) * n;
+    for (int i = 0; i < n; ++i) {
+      const int32_t *lo = colind + rowptr[l[i]], *hi = colind + rowptr[l[i] + 1];
+      for (int j = 0; j < n; ++j)
+        if (!std::binary_search(lo, hi, l[j])) { bad_elem.store(e); return; }
+    }
+  });
+  MHA_REQUIRE(bad_elem.load() < 0, MHA_ERR_INVALID,
+              "the CRS graph misses a coupling of element " << bad_elem.load() << " (every pair of dofs of an element must be a graph entry)");
+}
+
 void build_crs_graph(int nrows, int nelem, int n, const int32_t *lids, std::vector<int32_t> &rowptr,
                      std::vector<int32_t> &colind) {
   std::vector<int32_t> ptr, elem, lpos;
@@ -144,6 +172,10 @@ void build_crs_graph(int nrows, int nelem, int n, const int32_t *lids, std::vect
   // pass 1: count unique columns per row; pass 2: fill
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1) {
+      int64_t nnz = 0;  // the counts are summed in 64 bits: local ordinals are int32 (LO = int), so nnz must stay below 2^31
+      for (int r = 0; r < nrows; ++r) nnz += rowptr[r + 1];
+      MHA_REQUIRE(nnz < (int64_t(1) << 31), MHA_ERR_INVALID,
+                  "the block's CRS graph has " << nnz << " entries: more than int32 row offsets hold (2^31 - 1)");
       for (int r = 0; r < nrows; ++r) rowptr[r + 1] += rowptr[r];
       colind.assign(static_cast<size_t>(rowptr[nrows]), 0);
     }

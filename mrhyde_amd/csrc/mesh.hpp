@@ -19,6 +19,9 @@ void mesh_structured(int dim, int order, const int *ncell, const double *lo, con
 void build_crs_graph(int nrows, int nelem, int n, const int32_t *lids, std::vector<int32_t> &rowptr,
                      std::vector<int32_t> &colind);
 
+// Checks a caller-supplied graph (throws MHA_ERR_INVALID): well-formed CRS, and every (LID_i, LID_j) of every element present.
+void validate_crs_graph(int nrows, int nelem, int n, const int32_t *lids, const int32_t *rowptr, const int32_t *colind);
+
 // row -> incident (element, local position) pairs, CSR layout, element-ascending per row.
 void build_row_incidence(int nrows, int nelem, int n, const int32_t *lids, std::vector<int32_t> &ptr,
                          std::vector<int32_t> &elem, std::vector<int32_t> &lpos);

@@ -17,8 +17,11 @@ ScatterPlan::ScatterPlan(int n, int num_elems, int num_rows, const int32_t *lids
   for (size_t k = 0; k < nl; ++k)
     MHA_REQUIRE(lids[k] >= 0 && lids[k] < num_rows, MHA_ERR_INVALID, "scatter plan: LID " << lids[k] << " out of range");
   if (rowptr && colind) {
+    MHA_REQUIRE(rowptr[0] == 0, MHA_ERR_INVALID, "rowptr[0] must be 0");
+    for (int r = 0; r < num_rows; ++r)
+      MHA_REQUIRE(rowptr[r + 1] >= rowptr[r], MHA_ERR_INVALID, "rowptr must be non-decreasing");
+    validate_crs_graph(num_rows, num_elems, n, lids, rowptr, colind);  // sorted rows, every element coupling present
     h_rowptr_.assign(rowptr, rowptr + num_rows + 1);
-    MHA_REQUIRE(h_rowptr_[0] == 0, MHA_ERR_INVALID, "rowptr[0] must be 0");
     h_colind_.assign(colind, colind + h_rowptr_[num_rows]);
   } else {
     build_crs_graph(num_rows, num_elems, n, lids, h_rowptr_, h_colind_);

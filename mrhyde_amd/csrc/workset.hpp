@@ -129,7 +129,9 @@ inline View Workset::get(const std::string &name) const {
     v.ptr = const_cast<int32_t *>(dev.lids + static_cast<size_t>(views_first_) * n);
     v.rank = 2; v.extent[0] = ne; v.extent[1] = n; v.is_int = true;
   } else if (name == "offsets") {
-    v.ptr = const_cast<int32_t *>(dev.offsets); v.rank = 2; v.extent[0] = numVars; v.extent[1] = n; v.is_int = true;
+    // one flat list for the block: the dofs of variable v occupy positions varptr[v] .. varptr[v + 1] of it (the
+    // reference's offsets(var, dof) ragged array, workset.hpp:61, concatenated)
+    v.ptr = const_cast<int32_t *>(dev.offsets); v.rank = 2; v.extent[0] = 1; v.extent[1] = n; v.is_int = true;
   } else {
     // the reference prints "Error: could not find ..." and continues (workset.cpp:1576-1577)
     throw Error(MHA_ERR_UNKNOWN_FIELD, "unknown workset view '" + name + "'");

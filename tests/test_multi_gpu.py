@@ -327,6 +327,29 @@ def test_single_element_and_ragged_groups(oracle, physics):
         assert rel_err(res2.cpu().numpy(), ref["res"]) < RTOL
 
 
+def test_launch_that_needs_too_much_scratch_is_refused(oracle, monkeypatch):
+    """A kernel whose spills need a large scratch arena can take the process down inside the runtime (the round-1
+    MHA_ENGINE_MINW variants of the engine did, on porousMixed 128^3).  The launchers check the kernel's private segment
+    first: over the limit -> MHA_ERR_DEVICE and a message, not SIGABRT.  The deck-string instantiation of the engine
+    carries the interpreter's 640-byte stack: with the limit lowered below that it must be refused, and run with the
+    default limit."""
+    torch = _torch()
+    import mrhyde_amd
+    m = warp(oracle.mesh_multi(3, (2, 2, 2), [oracle.HVOL, oracle.HDIV], [0, 1]))
+    blk = make_block(m, "porousMixed", 2)
+    blk.set_function("source", "sin(x)*y + 0.5")
+    ud = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    monkeypatch.setenv("MHA_MAX_SCRATCH_BYTES", "16")
+    with pytest.raises(mrhyde_amd.MhaError) as e:
+        blk.assemble_jacres(ud, res, None, compute_jacobian=False, path=mrhyde_amd.PATH_POINT_ENGINE)
+    assert e.value.code == 3 and "scratch" in str(e.value)  # MHA_ERR_DEVICE
+    monkeypatch.delenv("MHA_MAX_SCRATCH_BYTES")
+    blk.assemble_jacres(ud, res, None, compute_jacobian=False, path=mrhyde_amd.PATH_POINT_ENGINE)
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(res.cpu().numpy()))
+
+
 def test_workset_views_of_multi_variable_blocks(oracle):
     """Geometry views (wts, x, y, z) work for any block; per-variable basis views are not built and say so."""
     _torch()

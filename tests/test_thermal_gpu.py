@@ -257,6 +257,57 @@ def affine_mesh(oracle, dim, order, ncell, shear=True):
     return m
 
 
+def test_caller_graph_is_validated(oracle):
+    """A caller-supplied CRS graph that lacks an element coupling (or is unsorted) is an input error at mha_set_graph /
+    mha_scatter_plan_create: the device slot maps are built by a column search and a missing column has no slot."""
+    _torch()
+    import mrhyde_amd
+    dim, order, qdeg, ncell = 2, 1, 2, (3, 3)
+    m = oracle.mesh_structured(dim, order, ncell)
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    blk = mrhyde_amd.Block(dim, order, quadrature=qdeg)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+    # drop the last column of row 5
+    keep = np.ones(len(colind), bool)
+    keep[rowptr[6] - 1] = False
+    rp = rowptr.copy()
+    rp[6:] -= 1
+    with pytest.raises(mrhyde_amd.MhaError, match="misses a coupling"):
+        blk.set_graph(rp, colind[keep])
+    # unsorted row
+    ci = colind.copy()
+    ci[rowptr[5]], ci[rowptr[5] + 1] = ci[rowptr[5] + 1], ci[rowptr[5]]
+    with pytest.raises(mrhyde_amd.MhaError, match="ascending"):
+        blk.set_graph(rowptr, ci)
+    with pytest.raises(mrhyde_amd.MhaError, match="misses a coupling"):
+        mrhyde_amd.ScatterPlan(m["lids"], m["ndof"], rp, colind[keep])
+    blk.set_graph(rowptr, colind)  # the complete graph is accepted
+
+
+def test_baseline_kernel_knob_on_the_row_gather_path(oracle, monkeypatch):
+    """MHA_BASELINE_ELEMENT_KERNEL=1 (the documented cross-check knob) on a perturbed mesh with AUTO: the baseline element
+    kernel accumulates into the row gather's scratch, which must therefore be zeroed every call -- two assemblies in a
+    row, both equal to the oracle (the scratch used to keep the previous call's contents)."""
+    torch = _torch()
+    import mrhyde_amd
+    monkeypatch.setenv("MHA_BASELINE_ELEMENT_KERNEL", "1")
+    dim, order, qdeg, ncell = 3, 2, 4, (3, 3, 2)
+    m = perturbed(oracle, dim, order, ncell, seed=12)
+    u = np.random.default_rng(6).uniform(-1, 1, m["ndof"])
+    fixed = m["boundary"]
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed, source=("const", 1.5))
+    blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+    blk.set_function("thermal source", 1.5)
+    res = torch.full((m["ndof"],), 3.0, dtype=torch.float64, device="cuda")
+    vals = torch.full((len(ref["colind"]),), 3.0, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True)
+        torch.cuda.synchronize()
+        assert blk.info("last_path") == mrhyde_amd.PATH_ROW_GATHER
+        assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+        assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+
+
 RO_CASES = [  # dim, order, qdeg, ncell
     (2, 1, 2, (9, 7)),
     (2, 2, 4, (6, 5)),
@@ -276,7 +327,7 @@ def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, 
     torch = _torch()
     import mrhyde_amd
     monkeypatch.setenv("MHA_K2", k2)
-    monkeypatch.setenv("MHA_K1", "mfma" if k2 == "pattern" else "lanes")
+    monkeypatch.setenv("MHA_K1", "thread" if k2 == "pattern" else "lanes")  # K1: one thread / 32 lanes per element
     m = affine_mesh(oracle, dim, order, ncell)
     rng = np.random.default_rng(21)
     u = rng.uniform(-1, 1, m["ndof"])
@@ -323,7 +374,7 @@ def test_row_owner_transient_and_source_array(oracle, monkeypatch, k2):
     torch = _torch()
     import mrhyde_amd
     monkeypatch.setenv("MHA_K2", k2)
-    monkeypatch.setenv("MHA_K1", "mfma" if k2 == "pattern" else "lanes")
+    monkeypatch.setenv("MHA_K1", "thread" if k2 == "pattern" else "lanes")  # K1: one thread / 32 lanes per element
     dim, order, qdeg, ncell = 3, 2, 4, (3, 4, 3)
     m = affine_mesh(oracle, dim, order, ncell)
     rng = np.random.default_rng(23)
