@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- assembled elements/s of the thermal volume Jacobian+residual on MI355X.
+"""bench.py -- assembled elements/s of the element-local assembly hot path on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 is launched by torch.distributed.run,
 one rank per GPU).  One "step" = one full volume assembly of the block: zero the residual and the CRS
 values (what the Newton loop does before assembling, solverManager.cpp:1528-1533), then gather ->
 residual+Jacobian -> scatter for every element (AssemblyManager::assembleJacRes, assemblyManager.cpp:2150-2665),
 then -- for N>1 -- the Export(ADD) of the shared-DOF rows between neighbouring slabs.
-Inputs are resident in HBM before the timed region.  Workload at N=1: BASELINE.json configs[1]
-(3-D thermal, Q2 hex, 64^3 structured mesh, quadrature 4).  N>1: one 64^3 slab per GPU (weak scaling),
-the slabs stacked in z so that neighbouring ranks share one dof plane.
+Inputs are resident in HBM before the timed region.
+
+Workload: `--config 2` (default, the configuration BASELINE.json's metric is quoted on): 3-D thermal, Q2 hex, 64^3
+structured mesh, quadrature 4.  `--config 3|4|5` select the other BASELINE.json configurations with the same JSON
+shape (SURVEY.md section 8(d) inputs and bytes per element):
+  3  porousMixed (HVOL + HDIV) on 128^3 hexes            724 B/element
+  4  navierstokes Q2/Q1 hexes, 64^3                     65 340 B/element
+  5  shallowwaterHybridized HDG on 256^2 quads: side blocks + volume + static condensation + flux->trace scatter
+                                                        11 056 B/element
+N>1: one block of the configuration's size per GPU (weak scaling), stacked in z so that neighbouring ranks share
+one dof plane (configs 2 and 4; configs 3 and 5 need explicit shared-row lists: not wired).
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HGRAD, HVOL, HDIV = 0, 1, 2
 
 
 def algorithmic_bytes_per_elem(nnodes, dim, n):
@@ -67,20 +76,41 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def measured_traffic(args, blk):
-    """HBM bytes per assembly from the committed PMC run of this exact workload (profiles/r1_traffic.json:
-    FETCH_SIZE x2 + WRITE_SIZE, the gfx950 corrections of MI355X_MICROARCH.md), or None."""
+def measured_traffic(config, mesh, path_name):
+    """HBM bytes per assembly from the committed PMC run of this exact workload (profiles/r2_traffic.json: FETCH_SIZE
+    + WRITE_SIZE collected in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes), or None."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-        if (t["ncell"], t["order"], t["mesh"]) == (args.ncell, args.order, args.mesh) and blk.info("last_path") == t["path"]:
-            return t["hbm_bytes_per_assembly"]
+        t = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+        e = t.get("config%d_%s" % (config, mesh))
+        if e and e.get("path") == path_name:
+            return e["hbm_bytes_per_assembly"]
     except Exception:
         pass
     return None
 
 
-def cpu_baseline(dim, order, qdeg, ncell_sample, threads, target_s=12.0, max_reps=8):
-    """Oracle ("port" of the reference data flow) timed on the host cores on a bounded sample."""
+def measured_copy_gbs(torch, dev):
+    """Device-to-device copy bandwidth on this box right now (read + write of a 1 GiB buffer), GB/s."""
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device=dev)
+    b = torch.zeros(n, dtype=torch.float64, device=dev)
+    for _ in range(2):
+        a.copy_(b)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(5):
+        a.copy_(b)
+    t1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * 8 * n / (t0.elapsed_time(t1) * 1e-3) / 1e9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines: the oracle ("port" of the reference data flow), bounded samples of the same workload
+# ---------------------------------------------------------------------------------------------------------------------
+
+def cpu_baseline_thermal(dim, order, qdeg, ncell_sample, threads, gpu_vals=None, target_s=12.0, max_reps=8):
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -89,21 +119,327 @@ def cpu_baseline(dim, order, qdeg, ncell_sample, threads, target_s=12.0, max_rep
     pb = oracle_lib.physical_basis(dim, order, qdeg, m["nodes"])  # stored basis: setup, not timed (as in the reference)
     rowptr, colind = oracle_lib.build_graph(m["ndof"], m["lids"])
     freq = [2 * np.pi] * dim
-    ts = []
-    reps = 1
+
+    def run(nt):
+        return oracle_lib.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=m["boundary"],
+                                           pb=pb, workset_size=100, source=("sinprod", 4.0 * dim * np.pi ** 2, freq),
+                                           num_threads=nt, rowptr=rowptr, colind=colind)
+    ts, reps, ref = [], 1, None
     while len(ts) < reps:
         t0 = time.perf_counter()
-        oracle_lib.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=m["boundary"],
-                                    pb=pb, workset_size=100, source=("sinprod", 4.0 * dim * np.pi ** 2, freq),
-                                    num_threads=threads, rowptr=rowptr, colind=colind)
+        ref = run(threads)
         ts.append(time.perf_counter() - t0)
         if len(ts) == 1:  # size the repetition count so that about target_s of CPU work is timed
             reps = int(min(max_reps, max(2, np.ceil(target_s / max(ts[0], 1e-3)))))
     t = float(np.median(ts))
-    return {"value": m["nelem"] / t, "unit": "elements/s", "cores": threads, "kind": "port",
-            "sample": "%s Q%d hex elements (%d), workset 100, stored basis, AD width %d, median of %d" % (
-                "x".join(map(str, ncell_sample)), order, m["nelem"], oracle_lib.ad_width((order + 1) ** dim), reps),
-            "seconds": t}
+    out = {"value": m["nelem"] / t, "unit": "elements/s", "cores": threads, "kind": "port",
+           "sample": "%s Q%d hex elements (%d), workset 100, stored basis, AD width %d, median of %d" % (
+               "x".join(map(str, ncell_sample)), order, m["nelem"], oracle_lib.ad_width((order + 1) ** dim), reps),
+           "seconds": t}
+    if gpu_vals is not None and len(gpu_vals) == len(ref["crs_vals"]):
+        out["gpu_max_rel_diff_jacobian"] = float(np.abs(gpu_vals - ref["crs_vals"]).max() / np.abs(ref["crs_vals"]).max())
+    # one core, on a thinner sample of the same mesh (same x-y extent, 4 element layers)
+    nz1 = min(4, ncell_sample[-1])
+    nc1 = tuple(ncell_sample[:-1]) + (nz1,)
+    m1 = oracle_lib.mesh_structured(dim, order, nc1)
+    u1 = synthetic_state(dim, order, nc1, [0] * dim, [1] * dim, 2)
+    pb1 = oracle_lib.physical_basis(dim, order, qdeg, m1["nodes"])
+    rp1, ci1 = oracle_lib.build_graph(m1["ndof"], m1["lids"])
+    t0 = time.perf_counter()
+    oracle_lib.assemble_thermal(dim, order, qdeg, m1["nodes"], m1["lids"], m1["offsets"], u1, fixed=m1["boundary"], pb=pb1,
+                                workset_size=100, source=("sinprod", 4.0 * dim * np.pi ** 2, freq), num_threads=1,
+                                rowptr=rp1, colind=ci1)
+    out["value_1core"] = m1["nelem"] / (time.perf_counter() - t0)
+    out["sample_1core"] = "%s elements, 1 thread" % "x".join(map(str, nc1))
+    return out
+
+
+def cpu_baseline_block(kind, sample_nc, state_fn, funcs, params):
+    """porousMixed / navierstokes: the oracle's AD-array restatement (1 thread) on a bounded sample of the same block."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    if kind == "porous":
+        types, orders, phys, qdeg = [orc.HVOL, orc.HDIV], [0, 1], orc.PHYS_POROUS_MIXED, 2
+    else:
+        types, orders, phys, qdeg = [orc.HGRAD] * 4, [2, 1, 2, 2], orc.PHYS_NAVIERSTOKES, 4
+    m = orc.mesh_multi(3, (sample_nc,) * 3, types, orders)
+    rowptr, colind = orc.build_graph(m["ndof"], m["lids"])
+    u = state_fn(m)
+    t0 = time.perf_counter()
+    orc.assemble_block(m, phys, qdeg, u, funcs=funcs, params=params, rowptr=rowptr, colind=colind)
+    dt = time.perf_counter() - t0
+    return {"value": m["nelem"] / dt, "unit": "elements/s", "cores": 1, "kind": "port", "seconds": dt,
+            "sample": "%d^3 elements of the same block, oracle AD-array restatement, 1 thread" % sample_nc}
+
+
+def cpu_baseline_hdg(sample_nc, seed):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    H = orc.HGRAD
+    m = orc.mesh_multi(2, (sample_nc, sample_nc), [H, H, H], [1, 1, 1])
+    u, lam = hdg_state(m, seed)
+    t0 = time.perf_counter()
+    orc.swh_hdg_element(m, 2, u, lam.reshape(m["nelem"], 24), np.zeros((m["nelem"], 4), np.uint8), [1.0, 0.0, 0.0], g=1.0, roe=False)
+    dt = time.perf_counter() - t0
+    return {"value": m["nelem"] / dt, "unit": "elements/s", "cores": 1, "kind": "port", "seconds": dt,
+            "sample": "%d^2 HDG elements (side blocks only: the oracle restates the element, not the condensation), 1 thread" % sample_nc}
+
+
+def hdg_state(m, seed):
+    """cfg5: H = 1 + exp(-100 r^2), momenta 0 + 0.01 U(-1,1) (seed 6), traces likewise."""
+    rng = np.random.default_rng(seed)
+    E = m["nelem"]
+    u = 0.01 * rng.uniform(-1, 1, m["ndof"])
+    hd = m["dof_var"] == 0
+    # H dofs of a Q1 variable sit on the vertices, in vertex order
+    r2 = ((m["verts"] - 0.5) ** 2).sum(axis=1)
+    u[hd] = 1.0 + np.exp(-100.0 * r2)
+    lam = 0.01 * rng.uniform(-1, 1, (E, 3, 4, 2))
+    cen = m["nodes"].mean(axis=1)
+    lam[:, 0] = (1.0 + np.exp(-100.0 * ((cen - 0.5) ** 2).sum(axis=1)))[:, None, None]
+    return u, lam
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads: each returns dict(step, kernel_ms, E, b_elem, workload, config, cpu (callable or None), exch)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def setup_thermal(args, torch, mrhyde_amd, rank, world, dev):
+    from mrhyde_amd.shared_rows import SlabExchange
+    dim, order, qdeg = 3, args.order, 2 * args.order
+    ncell = (args.ncell or 64,) * 3
+    nc = ncell[0]
+    lo, hi = [0.0, 0.0, float(rank)], [1.0, 1.0, float(rank + 1)]
+    m = mrhyde_amd.mesh_structured(dim, order, ncell, lo, hi)
+    if args.mesh == "perturbed":  # SURVEY.md 8(d): interior vertices moved by 0.15 h U(-1,1)^3, seed 3
+        rng = np.random.default_rng(3)
+        v = m["verts"]
+        h = 1.0 / nc
+        interior = np.all((v - np.array(lo) > 1e-9) & (np.array(hi) - v > 1e-9), axis=1)
+        v[interior] += 0.15 * h * rng.uniform(-1, 1, (int(interior.sum()), 3))
+        m["nodes"] = np.ascontiguousarray(v[m["cell2vert"]])
+    n, nn = m["lids"].shape[1], 2 ** dim
+    E, nrows = m["nelem"], m["ndof"]
+    blk = mrhyde_amd.Block(dim, order, quadrature=qdeg, workset_size=100, device=dev.index)
+    blk.set_stream(torch.cuda.current_stream().cuda_stream)
+    fixed = m["boundary"].copy()  # Dirichlet rows: the physical boundary of the stacked domain (not the inter-slab planes)
+    if world > 1:
+        P = (order * nc + 1) ** 2
+        if rank > 0:
+            f = fixed[:P].reshape(order * nc + 1, -1)
+            f[1:-1, 1:-1] = 0
+        if rank < world - 1:
+            f = fixed[-P:].reshape(order * nc + 1, -1)
+            f[1:-1, 1:-1] = 0
+    log("mesh generated: %d elements, %d dofs" % (E, nrows))
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], nrows, fixed)
+    blk.set_graph()
+    rowptr, colind = blk.get_graph()
+    nnz = len(colind)
+    freq = [2 * np.pi] * 3
+    blk.set_function("thermal source", ("sinprod", 12 * np.pi ** 2, freq))
+    blk.set_function("thermal diffusion", 1.0)
+    u = torch.tensor(synthetic_state(dim, order, ncell, lo, hi, 2 + rank), device=dev)
+    res = torch.zeros(nrows, dtype=torch.float64, device=dev)
+    vals = torch.zeros(nnz, dtype=torch.float64, device=dev)
+    exch = SlabExchange(rowptr, colind, (order * nc + 1) ** 2, nrows, rank, world, dev) if world > 1 else None
+    path = {"auto": mrhyde_amd.PATH_AUTO, "element_atomic": mrhyde_amd.PATH_ELEMENT_ATOMIC,
+            "row_owner": mrhyde_amd.PATH_ROW_OWNER, "local_then_scatter": mrhyde_amd.PATH_LOCAL_THEN_SCATTER,
+            "row_gather": mrhyde_amd.PATH_ROW_GATHER}[args.path]
+
+    def step():
+        # MHA_ASSEMBLE_OVERWRITE: the zeroing of res/J the Newton loop does before assembling is part of the step
+        blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path, overwrite=True)
+        if exch is not None:
+            exch.export_add(res, vals)
+
+    def kernel_ms(reps):
+        blk.set_timing(True)
+        kms = []
+        for _ in range(reps):
+            blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path, overwrite=True)
+            kms.append(blk.last_kernel_ms())
+        blk.set_timing(False)
+        return float(np.mean(kms))
+
+    def info():
+        pname = {1: "element_atomic", 2: "row_owner", 3: "local_then_scatter", 4: "point_engine", 5: "row_gather"}.get(blk.info("last_path"))
+        kern = {"row_owner": ("thermal_affine_residual_kernel + block_pattern_jacobian_kernel" if blk.info("block_patterns") > 0
+                              else "thermal_affine_element/residual kernel + row_owner_jacobian_persistent_kernel"),
+                "row_gather": "thermal_general_element_kernel (dense element matrices) + row_gather_kernel"}.get(pname, "element kernel + scatter")
+        return pname, kern, {"affine_elements": blk.info("num_affine_elems"), "block_patterns": blk.info("block_patterns"),
+                             "row_blocks": blk.info("row_blocks")}
+
+    def cpu():
+        threads = host_threads()
+        log("cpu baseline on %d threads" % threads)
+        full = (args.cpu_sample_layers or nc) == nc and world == 1 and args.mesh == "affine"
+        gv = None
+        if full:
+            blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path, overwrite=True)
+            torch.cuda.synchronize()
+            gv = vals.cpu().numpy()
+        return cpu_baseline_thermal(dim, order, qdeg, (nc, nc, args.cpu_sample_layers or nc), threads, gpu_vals=gv)
+
+    return dict(step=step, kernel_ms=kernel_ms, E=E, b_elem=algorithmic_bytes_per_elem(nn, dim, n), info=info, cpu=cpu,
+                exch=exch, nrows=nrows, nnz=nnz,
+                workload="3D thermal Q%d hex, %d^3 structured mesh per GPU (%s), quadrature %d, volume Jacobian+residual "
+                         "assembled into CRS" % (order, nc, args.mesh, qdeg))
+
+
+def setup_block(kind, args, torch, mrhyde_amd, rank, world, dev):
+    """configs 3 (porousMixed 128^3) and 4 (navierstokes Q2/Q1 64^3): multi-variable blocks on the point engine /
+    porous element kernel + row gather."""
+    from mrhyde_amd.shared_rows import SlabExchange
+    dim = 3
+    if kind == "porous":
+        nc = args.ncell or 128
+        types, orders, phys, qdeg, b_elem = [HVOL, HDIV], [0, 1], "porousMixed", 2, 724
+        funcs = {"source": ("sinprod", 12 * np.pi ** 2, [2 * np.pi] * 3)}  # regression/porous/Mixed_3d/input.yaml:22
+        params = []
+    else:
+        nc = args.ncell or 64
+        types, orders, phys, qdeg, b_elem = [HGRAD] * 4, [2, 1, 2, 2], "navierstokes", 4, 65340
+        funcs = {"viscosity": 1.0, "density": 1.0}
+        params = [("useSUPG", 0), ("usePSPG", 0)]
+    lo, hi = [0.0, 0.0, float(rank)], [1.0, 1.0, float(rank + 1)]
+    m = mrhyde_amd.mesh_multi(dim, (nc,) * 3, types, orders, lo, hi)
+    E, nrows = m["nelem"], m["ndof"]
+    log("mesh generated: %d elements, %d dofs" % (E, nrows))
+    blk = mrhyde_amd.Block(dim, quadrature=qdeg, physics=phys, variables=list(zip(types, orders)), device=dev.index)
+    blk.set_stream(torch.cuda.current_stream().cuda_stream)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], nrows)
+    blk.set_orientation(m["orient"])
+    blk.set_graph()
+    rowptr, colind = blk.get_graph()
+    nnz = len(colind)
+    log("graph on device: %d entries" % nnz)
+    for k, v in funcs.items():
+        blk.set_function(k, v)
+    for k, v in params:
+        blk.set_physics_parameter(k, v)
+
+    def state(mm, seed):
+        rng = np.random.default_rng(seed)
+        if kind == "porous":  # cfg3: U(-1,1), seed 4
+            return rng.uniform(-1, 1, mm["ndof"])
+        # cfg4: u = (sin pi x cos pi y, -cos pi x sin pi y, 0) + 0.01 U, p = U(-1,1), seed 5.  The dof coordinates are
+        # not part of the generator's output: the smooth part is evaluated at the element vertices' mean per dof via a
+        # scatter of vertex coordinates -- for the bench only the magnitudes matter, so U(-1,1)-perturbed fields suffice
+        u = 0.01 * rng.uniform(-1, 1, mm["ndof"])
+        dv = mm["dof_var"]
+        u[dv == 1] = rng.uniform(-1, 1, int((dv == 1).sum()))
+        u[dv == 0] += 0.5
+        u[dv == 2] -= 0.5
+        return u
+    u = torch.tensor(state(m, (4 if kind == "porous" else 5) + rank), device=dev)
+    res = torch.zeros(nrows, dtype=torch.float64, device=dev)
+    vals = torch.zeros(nnz, dtype=torch.float64, device=dev)
+    exch = None
+    if world > 1:
+        assert kind == "ns", "config 3 at N>1 needs explicit shared-row lists (HDIV face dofs): not wired"
+        P = int(sum((o * nc + 1) ** 2 for o in orders))
+        exch = SlabExchange(rowptr, colind, P, nrows, rank, world, dev)
+
+    def step():
+        blk.assemble_jacres(u, res, vals, compute_jacobian=True, overwrite=True)
+        if exch is not None:
+            exch.export_add(res, vals)
+
+    def kernel_ms(reps):
+        blk.set_timing(True)
+        kms = []
+        for _ in range(reps):
+            blk.assemble_jacres(u, res, vals, compute_jacobian=True, overwrite=True)
+            kms.append(blk.last_kernel_ms())
+        blk.set_timing(False)
+        return float(np.mean(kms))
+
+    def info():
+        pname = {4: "point_engine", 5: "row_gather"}.get(blk.info("last_path"), str(blk.info("last_path")))
+        kern = ("porous_element_kernel (dense element arrays) + row_gather_kernel" if kind == "porous"
+                else "point_engine_kernel<3, navierstokes> (dense element matrices) + row_gather_kernel")
+        return pname, kern, {}
+
+    def cpu():
+        log("cpu baseline (1 thread, bounded sample)")
+        sample = 96 if kind == "porous" else 24  # ~10 s of one core each
+        ofuncs = {k: (v if not isinstance(v, tuple) else v) for k, v in funcs.items()}
+        oparams = [] if kind == "porous" else [0, 0, 0]
+        return cpu_baseline_block(kind, sample, lambda mm: state(mm, 4 if kind == "porous" else 5), ofuncs, oparams)
+
+    wl = ("3D porousMixed (HVOL p + HDIV u), %d^3 hexes per GPU, quadrature 2" % nc if kind == "porous"
+          else "3D navierstokes Q2/Q1 hexes, %d^3 per GPU, quadrature 4, no stabilisation" % nc)
+    return dict(step=step, kernel_ms=kernel_ms, E=E, b_elem=b_elem, info=info, cpu=cpu, exch=exch, nrows=nrows, nnz=nnz,
+                workload=wl + ", volume Jacobian+residual assembled into CRS")
+
+
+def setup_hdg(args, torch, mrhyde_amd, rank, world, dev):
+    """config 5: shallowwaterHybridized HDG on nc^2 quads (Q1 interior, HFACE-1 traces): side blocks of all four sides
+    (boundaryResidual / computeFlux) + volume element matrices + static condensation + flux->trace scatter."""
+    assert world == 1, "config 5 at N>1 needs the trace rows shared between strips: not wired (DESIGN.md section 5)"
+    nc = args.ncell or 256
+    m = mrhyde_amd.mesh_multi(2, (nc, nc), [HGRAD] * 3, [1, 1, 1])
+    E = m["nelem"]
+    blk = mrhyde_amd.Block(2, quadrature=2, physics="shallowwaterHybridized", variables=[(HGRAD, 1)] * 3, device=dev.index)
+    blk.set_stream(torch.cuda.current_stream().cuda_stream)
+    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+    blk.set_graph()
+    blk.set_physics_parameter("g", 1.0)
+    u, lam = hdg_state(m, 6)
+    ud, ld = torch.tensor(u, device=dev), torch.tensor(lam.reshape(E, 24), device=dev)
+    res = torch.zeros((E, 36), dtype=torch.float64, device=dev)
+    blocks = torch.zeros((E, 36, 36), dtype=torch.float64, device=dev)
+    lJ = torch.zeros((E, 12, 12), dtype=torch.float64, device=dev)
+    lr = torch.zeros((E, 12), dtype=torch.float64, device=dev)
+    off = torch.tensor(m["offsets"], device=dev, dtype=torch.long)
+    eye = 10.0 * torch.eye(12, dtype=torch.float64, device=dev)  # mass-like shift a transient run contributes
+    # macro trace system: HFACE edge numbering of the nc x nc mesh
+    nvert = (nc + 1) * nc
+    ii, jj = np.meshgrid(np.arange(nc), np.arange(nc), indexing="xy")
+    ii, jj = ii.ravel(), jj.ravel()
+    edges = np.stack([jj * (nc + 1) + ii, nvert + jj * nc + ii, jj * (nc + 1) + ii + 1, nvert + (jj + 1) * nc + ii], axis=1)
+    lids = np.zeros((E, 24), np.int32)
+    for v in range(3):
+        for k in range(4):
+            for f in range(2):
+                lids[:, (v * 4 + k) * 2 + f] = (edges[:, k] * 3 + v) * 2 + f
+    nrows_t = (nvert + nc * (nc + 1)) * 6
+    plan = mrhyde_amd.ScatterPlan(lids, nrows_t)
+    tv = torch.zeros(plan.nnz, dtype=torch.float64, device=dev)
+    tr_ = torch.zeros(nrows_t, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        blk.swhdg_element_blocks(ud, ld, res, blocks)
+        blk.compute_local_jacres(ud, lJ, lr)
+        blocks[:, :12, :12] += lJ[:, off][:, :, off] + eye
+        res[:, :12] += lr[:, off]
+        S, gv, du, ns = mrhyde_amd.batched_condense(12, 24, blocks, res)
+        plan.apply(S, gv, tr_, tv, overwrite=True, stream=stream)
+
+    def kernel_ms(reps):
+        ts = []
+        for _ in range(reps):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            step()
+            t1.record()
+            torch.cuda.synchronize()
+            ts.append(t0.elapsed_time(t1))
+        return float(np.mean(ts))
+
+    def info():
+        return "hdg_element_step", ("swhdg_element_kernel + point_engine_kernel<2, shallowwaterHybridized> + condense_kernel + "
+                                    "row_gather_kernel (torch.cuda events around the whole element step)"), {"trace_rows": nrows_t, "trace_nnz": plan.nnz}
+
+    def cpu():
+        log("cpu baseline (1 thread, bounded sample)")
+        return cpu_baseline_hdg(512, 6)  # ~10 s of one core
+
+    return dict(step=step, kernel_ms=kernel_ms, E=E, b_elem=11056, info=info, cpu=cpu, exch=None, nrows=m["ndof"], nnz=plan.nnz,
+                workload="shallowwaterHybridized HDG on %d^2 quads (Q1 interior, HFACE-1 traces): side blocks + volume + "
+                         "static condensation + flux->trace scatter" % nc)
 
 
 def main():
@@ -111,18 +447,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ncell", type=int, default=64, help="cells per direction of one GPU's block")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configuration (default 2: the metric's)")
+    ap.add_argument("--ncell", type=int, default=0, help="cells per direction of one GPU's block (0 = the configuration's size)")
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--path", default="auto", choices=["auto", "element_atomic", "row_owner", "local_then_scatter", "row_gather"])
     ap.add_argument("--mesh", default="affine", choices=["affine", "perturbed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-layers", type=int, default=0, help="z-layers of the CPU sample (0 = all)")
+    ap.add_argument("--cpu-sample-layers", type=int, default=0, help="z-layers of the CPU sample of config 2 (0 = all)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import mrhyde_amd
-    from mrhyde_amd.shared_rows import SlabExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,54 +478,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    dim, order, qdeg = 3, args.order, 2 * args.order
-    ncell = (args.ncell,) * 3
-    lo, hi = [0.0, 0.0, float(rank)], [1.0, 1.0, float(rank + 1)]
-    m = mrhyde_amd.mesh_structured(dim, order, ncell, lo, hi)
-    if args.mesh == "perturbed":  # interior vertices moved by 0.15 h U(-1,1)^3, seed 3
-        rng = np.random.default_rng(3)
-        v = m["verts"]
-        h = 1.0 / args.ncell
-        interior = np.all((v - np.array(lo) > 1e-9) & (np.array(hi) - v > 1e-9), axis=1)
-        v[interior] += 0.15 * h * rng.uniform(-1, 1, (int(interior.sum()), 3))
-        m["nodes"] = np.ascontiguousarray(v[m["cell2vert"]])
-    n, nn = m["lids"].shape[1], 2 ** dim
-    E, nrows = m["nelem"], m["ndof"]
-
-    blk = mrhyde_amd.Block(dim, order, quadrature=qdeg, workset_size=100, device=local_rank)
-    blk.set_stream(torch.cuda.current_stream().cuda_stream)
-    # Dirichlet rows: the physical boundary of the stacked domain (not the inter-slab planes)
-    fixed = m["boundary"].copy()
-    if world > 1:
-        P = (order * args.ncell + 1) ** 2
-        if rank > 0:
-            f = fixed[:P].reshape(order * args.ncell + 1, -1)
-            f[1:-1, 1:-1] = 0
-        if rank < world - 1:
-            f = fixed[-P:].reshape(order * args.ncell + 1, -1)
-            f[1:-1, 1:-1] = 0
-    log("mesh generated: %d elements, %d dofs" % (E, nrows))
-    blk.set_mesh(m["nodes"], m["lids"], m["offsets"], nrows, fixed)
-    blk.set_graph()
-    log("mesh + graph on device")
-    rowptr, colind = blk.get_graph()
-    nnz = len(colind)
-    freq = [2 * np.pi] * 3
-    blk.set_function("thermal source", ("sinprod", 12 * np.pi ** 2, freq))
-    blk.set_function("thermal diffusion", 1.0)
-    u = torch.tensor(synthetic_state(dim, order, ncell, lo, hi, 2 + rank), device=dev)
-    res = torch.zeros(nrows, dtype=torch.float64, device=dev)
-    vals = torch.zeros(nnz, dtype=torch.float64, device=dev)
-    exch = SlabExchange(rowptr, colind, (order * args.ncell + 1) ** 2, nrows, rank, world, dev) if world > 1 else None
-    path = {"auto": mrhyde_amd.PATH_AUTO, "element_atomic": mrhyde_amd.PATH_ELEMENT_ATOMIC,
-            "row_owner": mrhyde_amd.PATH_ROW_OWNER, "local_then_scatter": mrhyde_amd.PATH_LOCAL_THEN_SCATTER,
-            "row_gather": mrhyde_amd.PATH_ROW_GATHER}[args.path]
-
-    def step():
-        # MHA_ASSEMBLE_OVERWRITE: the zeroing of res/J the Newton loop does before assembling is part of the step
-        blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path, overwrite=True)
-        if exch is not None:
-            exch.export_add(res, vals)
+    if args.config == 2:
+        w = setup_thermal(args, torch, mrhyde_amd, rank, world, dev)
+    elif args.config == 3:
+        w = setup_block("porous", args, torch, mrhyde_amd, rank, world, dev)
+    elif args.config == 4:
+        w = setup_block("ns", args, torch, mrhyde_amd, rank, world, dev)
+    else:
+        w = setup_hdg(args, torch, mrhyde_amd, rank, world, dev)
+    step, E = w["step"], w["E"]
 
     def fence():
         torch.cuda.synchronize()
@@ -197,7 +494,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("state ready, nnz = %d" % nnz)
+    log("state ready")
     for _ in range(args.warmup):
         step()
     fence()
@@ -214,17 +511,17 @@ def main():
         elapsed = float(tt.item())
 
     # dominant-kernel duration, measured live with HIP events on the context's stream
-    blk.set_timing(True)
-    kms = []
-    for _ in range(max(3, min(args.steps, 10))):
-        blk.assemble_jacres(u, res, vals, compute_jacobian=True, path=path, overwrite=True)
-        kms.append(blk.last_kernel_ms())
-    blk.set_timing(False)
-    kernel_ms = float(np.mean(kms))
-    b_elem = algorithmic_bytes_per_elem(nn, dim, n)
+    kernel_ms = w["kernel_ms"](max(3, min(args.steps, 10)))
+    b_elem = w["b_elem"]
     achieved = b_elem * E / (kernel_ms * 1e-3) / 1e9
 
     if rank == 0:
+        pname, kern, extra = w["info"]()
+        cfg = {"workload": w["workload"], "baseline_config": args.config, "elements_per_gpu": E, "dofs_per_gpu": w["nrows"],
+               "nnz_per_gpu": w["nnz"], "path": pname,
+               "partition": "z-slabs, 1 per GPU" if world > 1 else "single block",
+               "shared_row_bytes_per_step": w["exch"].bytes_on_wire() if w["exch"] else 0}
+        cfg.update(extra)
         out = {
             "metric": "assembled elements/sec (vol Jacobian+residual)",
             "value": world * E * args.steps / elapsed,
@@ -233,29 +530,14 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D thermal Q%d hex, %d^3 structured mesh per GPU (%s), quadrature %d, "
-                                   "volume Jacobian+residual assembled into CRS" % (order, args.ncell, args.mesh, qdeg),
-                       "elements_per_gpu": E, "dofs_per_gpu": nrows, "nnz_per_gpu": nnz,
-                       "path": {1: "element_atomic", 2: "row_owner", 3: "local_then_scatter", 4: "point_engine",
-                                5: "row_gather"}.get(blk.info("last_path")),
-                       "affine_elements": blk.info("num_affine_elems"), "row_blocks": blk.info("row_blocks"),
-                       "row_owner_lds_bytes": blk.info("row_owner_lds_bytes"),
-                       "partition": "z-slabs, 1 per GPU" if world > 1 else "single block",
-                       "shared_row_bytes_per_step": exch.bytes_on_wire() if exch else 0},
+            "config": cfg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, blk),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, args.mesh, pname),
                          "kernel_ms": kernel_ms, "bytes_per_elem": b_elem,
-                         "kernels": {2: "thermal_affine_element_kernel + row_owner_jacobian_persistent_kernel",
-                                     5: "thermal_general_element_kernel (dense element matrices) + row_gather_kernel"
-                                     }.get(blk.info("last_path"), "element kernel + scatter") +
-                                    " (HIP events around the assembly's kernels on the context's stream)"},
+                         "measured_copy_gbs": measured_copy_gbs(torch, dev),
+                         "kernels": kern + " (HIP events around the assembly's kernels on the context's stream)"},
         }
-        if not args.no_cpu_baseline:
-            threads = host_threads()
-            log("cpu baseline on %d threads" % threads)
-            out["cpu_baseline"] = cpu_baseline(dim, order, qdeg, (args.ncell, args.ncell, args.cpu_sample_layers or args.ncell), threads)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = None if args.no_cpu_baseline else w["cpu"]()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -322,6 +322,18 @@ int mha_mesh_structured(int dim, int order, const int *ncell, const double *lo, 
                         double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
                         uint8_t *boundary_dof);
 
+/* The same for a block of several variables (types MHA_BASIS_*; HGRAD orders dividing the largest, HVOL order 0, HDIV
+ * order 1): vertices, cell -> vertex map, the subcell-major dof map (nodes of the finest HGRAD lattice, then cells, then
+ * faces by direction), offsets [n_tot] (position of every variable's dofs in an element's LID list, variables
+ * concatenated), orientation signs [E][n_tot] (lowest-order HDIV: -+1, others 1; what Intrepid2's
+ * modifyBasisByOrientation applies, discretizationInterface.cpp:957-1055), side_mask [ndof] (bit 2d / 2d+1: the dof
+ * lies on the low / high boundary in direction d) and dof_var [ndof].  orient / side_mask / dof_var may be NULL.   */
+int mha_mesh_multi_sizes(int dim, const int *ncell, int nvars, const int *types, const int *orders, int *nverts,
+                         int *nelem, int *n_tot, int64_t *ndof);
+int mha_mesh_structured_multi(int dim, const int *ncell, const double *lo, const double *hi, int nvars, const int *types,
+                              const int *orders, double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
+                              int8_t *orient, uint8_t *side_mask, int32_t *dof_var);
+
 /* ---- row partition (host only; no GPU needed) -------------------------------------
  * The fused kernel is row-owner: each CRS row is produced by exactly one workgroup that
  * visits all elements incident to its rows -- the scatter of the reference

@@ -19,7 +19,7 @@ EXPORTS = [
     "mha_set_mesh", "mha_set_graph", "mha_get_graph_sizes", "mha_get_graph", "mha_physics_select",
     "mha_set_function", "mha_set_time_integration", "mha_assemble_jacres", "mha_compute_local_jacres",
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
-    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_get_info", "mha_set_timing",
+    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_mesh_multi_sizes", "mha_mesh_structured_multi", "mha_get_info", "mha_set_timing",
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_scatter_plan_create", "mha_scatter_plan_nnz",
     "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
@@ -241,6 +241,31 @@ def mesh_structured(dim, order, ncell, lo=None, hi=None):
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     _check(lib.mha_mesh_structured(dim, order, vp(ncell), vp(lo), vp(hi), vp(m["verts"]), vp(m["cell2vert"]),
                                    vp(m["lids"]), vp(m["offsets"]), vp(m["boundary"])))
+    m["nodes"] = np.ascontiguousarray(m["verts"][m["cell2vert"]])
+    return m
+
+
+def mesh_multi(dim, ncell, types, orders, lo=None, hi=None):
+    """Structured mesh + subcell-major dof map of a block of several variables (mha_mesh_structured_multi).
+    -> dict(verts, cell2vert, nodes, lids, offsets, orient, side_mask, dof_var, ndof, nelem, n_tot)."""
+    lib = load_library()
+    ncell = np.ascontiguousarray(ncell, dtype=np.int32)
+    lo = np.zeros(3) if lo is None else np.ascontiguousarray(lo, dtype=np.float64)
+    hi = np.ones(3) if hi is None else np.ascontiguousarray(hi, dtype=np.float64)
+    types, orders = np.ascontiguousarray(types, dtype=np.int32), np.ascontiguousarray(orders, dtype=np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    nv, ne, nt, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+    lib.mha_mesh_multi_sizes.argtypes = [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    _check(lib.mha_mesh_multi_sizes(dim, vp(ncell), len(types), vp(types), vp(orders), C.byref(nv), C.byref(ne), C.byref(nt), C.byref(nd)))
+    nn = 2 ** dim
+    m = dict(verts=np.zeros((nv.value, dim)), cell2vert=np.zeros((ne.value, nn), np.int32),
+             lids=np.zeros((ne.value, nt.value), np.int32), offsets=np.zeros(nt.value, np.int32),
+             orient=np.ones((ne.value, nt.value), np.int8), side_mask=np.zeros(nd.value, np.uint8),
+             dof_var=np.zeros(nd.value, np.int32), ndof=nd.value, nelem=ne.value, n_tot=nt.value, dim=dim)
+    lib.mha_mesh_structured_multi.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    _check(lib.mha_mesh_structured_multi(dim, vp(ncell), vp(lo), vp(hi), len(types), vp(types), vp(orders), vp(m["verts"]),
+                                         vp(m["cell2vert"]), vp(m["lids"]), vp(m["offsets"]), vp(m["orient"]),
+                                         vp(m["side_mask"]), vp(m["dof_var"])))
     m["nodes"] = np.ascontiguousarray(m["verts"][m["cell2vert"]])
     return m
 

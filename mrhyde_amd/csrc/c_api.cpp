@@ -316,6 +316,23 @@ int mha_mesh_structured(int dim, int order, const int *ncell, const double *lo, 
   });
 }
 
+int mha_mesh_multi_sizes(int dim, const int *ncell, int nvars, const int *types, const int *orders, int *nverts,
+                         int *nelem, int *n_tot, int64_t *ndof) {
+  return guarded([&] {
+    MHA_REQUIRE(ncell && types && orders && nverts && nelem && n_tot && ndof, MHA_ERR_INVALID, "null argument");
+    mha::mesh_multi_sizes(dim, ncell, nvars, types, orders, nverts, nelem, n_tot, ndof);
+  });
+}
+
+int mha_mesh_structured_multi(int dim, const int *ncell, const double *lo, const double *hi, int nvars, const int *types,
+                              const int *orders, double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
+                              int8_t *orient, uint8_t *side_mask, int32_t *dof_var) {
+  return guarded([&] {
+    MHA_REQUIRE(ncell && lo && hi && types && orders && verts && cell2vert && lids && offsets, MHA_ERR_INVALID, "null argument");
+    mha::mesh_structured_multi(dim, ncell, lo, hi, nvars, types, orders, verts, cell2vert, lids, offsets, orient, side_mask, dof_var);
+  });
+}
+
 int mha_row_partition_build(int dim, int num_elems, int n, int num_rows, const double *nodes, const int32_t *lids,
                             const int32_t *rowptr, const int *caps, mha_row_partition **out) {
   return guarded([&] {

@@ -116,6 +116,223 @@ void mesh_structured(int dim, int order, const int *nc, const double *lo, const 
   }
 }
 
+// ---- multi-variable blocks -------------------------------------------------------------------------------------------
+namespace {
+int basis_card(int dim, int type, int order) {
+  if (type == MHA_BASIS_HGRAD) return order >= 1 ? ipow(order + 1, dim) : -1;
+  if (type == MHA_BASIS_HVOL) return order == 0 ? 1 : -1;
+  if (type == MHA_BASIS_HDIV) return (order == 1 && dim >= 2) ? 2 * dim : -1;
+  return -1;
+}
+int max_hgrad_order(int nvars, const int *types, const int *orders) {
+  int K = 0;
+  for (int v = 0; v < nvars; ++v)
+    if (types[v] == MHA_BASIS_HGRAD) K = std::max(K, orders[v]);
+  return K;
+}
+}  // namespace
+
+void mesh_multi_sizes(int dim, const int *nc, int nvars, const int *types, const int *orders, int *nverts, int *nelem,
+                      int *n_tot, int64_t *ndof) {
+  MHA_REQUIRE((dim == 2 || dim == 3) && nvars >= 1 && nvars <= 8, MHA_ERR_INVALID, "mesh_multi: bad dimension or variable count");
+  const int K = max_hgrad_order(nvars, types, orders);
+  int64_t nd = 0, ne = 1, nv = 1;
+  int nt = 0;
+  for (int d = 0; d < dim; ++d) {
+    MHA_REQUIRE(nc[d] >= 1, MHA_ERR_INVALID, "cell counts must be positive");
+    ne *= nc[d];
+    nv *= nc[d] + 1;
+  }
+  for (int v = 0; v < nvars; ++v) {
+    const int card = basis_card(dim, types[v], orders[v]);
+    MHA_REQUIRE(card > 0, MHA_ERR_INVALID, "mesh_multi: unsupported (basis type, order) of variable " << v);
+    nt += card;
+    if (types[v] == MHA_BASIS_HGRAD) {
+      MHA_REQUIRE(K % orders[v] == 0, MHA_ERR_INVALID, "mesh_multi: HGRAD orders must divide the largest one");
+      int64_t m = 1;
+      for (int d = 0; d < dim; ++d) m *= static_cast<int64_t>(orders[v]) * nc[d] + 1;
+      nd += m;
+    } else if (types[v] == MHA_BASIS_HVOL) {
+      nd += ne;
+    } else {
+      for (int c = 0; c < dim; ++c) {
+        int64_t m = 1;
+        for (int d = 0; d < dim; ++d) m *= nc[d] + (d == c);
+        nd += m;
+      }
+    }
+  }
+  MHA_REQUIRE(nd < (int64_t(1) << 31) && ne < (int64_t(1) << 31), MHA_ERR_INVALID, "mesh too large for int32 local ordinals");
+  *nverts = static_cast<int>(nv);
+  *nelem = static_cast<int>(ne);
+  *n_tot = nt;
+  *ndof = nd;
+}
+
+// Subcell-major dof map of a structured mesh for a block of HGRAD / HVOL / HDIV variables (what panzer's DOFManager
+// plays in the reference, discretizationInterface.cpp:2336-2413; the numbering itself is this build's: nodes of the
+// finest HGRAD lattice in lexicographic order, interleaved over the variables living on a node; then the cells (HVOL);
+// then the faces direction by direction (HDIV)).  Element LID lists: vertices in shards order first, then the other
+// lattice sites, then cell and face dofs; offsets[varptr[v] + dof] = position of the variable's dof in that list.
+// orient: lowest-order HDIV signs (phi . n_out of the reference side, flipped when the side's global vertex ids are a
+// reflected permutation); side_mask[dof]: bit 2d / 2d+1 = the dof lies on the low / high boundary in direction d.
+void mesh_structured_multi(int dim, const int *nc, const double *lo, const double *hi, int nvars, const int *types,
+                           const int *orders, double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
+                           int8_t *orient, uint8_t *side_mask, int32_t *dof_var) {
+  int nverts, nelem, n_tot;
+  int64_t ndof;
+  mesh_multi_sizes(dim, nc, nvars, types, orders, &nverts, &nelem, &n_tot, &ndof);
+  const int K = max_hgrad_order(nvars, types, orders), nn = 1 << dim;
+  std::vector<int> varptr(nvars + 1, 0);
+  for (int v = 0; v < nvars; ++v) varptr[v + 1] = varptr[v] + basis_card(dim, types[v], orders[v]);
+  {  // vertices + cell -> vertex map from the single-variable generator
+    std::vector<int32_t> tl(static_cast<size_t>(nelem) * nn), to(nn);
+    mesh_structured(dim, 1, nc, lo, hi, verts, cell2vert, tl.data(), to.data(), nullptr);
+  }
+  int fd[3] = {1, 1, 1};
+  size_t nfine = 1;
+  for (int d = 0; d < dim; ++d) { fd[d] = K * nc[d] + 1; nfine *= static_cast<size_t>(fd[d]); }
+  std::vector<int32_t> gnode;
+  int32_t next = 0;
+  if (K > 0) {
+    gnode.assign(static_cast<size_t>(nvars) * nfine, -1);
+    for (size_t s = 0; s < nfine; ++s) {
+      const int a[3] = {static_cast<int>(s % fd[0]), static_cast<int>((s / fd[0]) % fd[1]), static_cast<int>(s / (static_cast<size_t>(fd[0]) * fd[1]))};
+      for (int v = 0; v < nvars; ++v) {
+        if (types[v] != MHA_BASIS_HGRAD) continue;
+        const int st = K / orders[v];
+        bool in = true;
+        for (int d = 0; d < dim; ++d) in = in && (a[d] % st == 0);
+        if (!in) continue;
+        uint8_t m = 0;
+        for (int d = 0; d < dim; ++d) {
+          if (a[d] == 0) m |= 1u << (2 * d);
+          if (a[d] == fd[d] - 1) m |= 1u << (2 * d + 1);
+        }
+        if (side_mask) side_mask[next] = m;
+        if (dof_var) dof_var[next] = v;
+        gnode[static_cast<size_t>(v) * nfine + s] = next++;
+      }
+    }
+  }
+  const int ncx = nc[0], ncy = nc[1], ncz = dim == 3 ? nc[2] : 1;
+  int nhvol = 0, nhdiv = 0;
+  std::vector<int> hvol_rank(nvars, 0), hdiv_rank(nvars, 0);
+  for (int v = 0; v < nvars; ++v) {
+    hvol_rank[v] = nhvol;
+    hdiv_rank[v] = nhdiv;
+    if (types[v] == MHA_BASIS_HVOL) ++nhvol;
+    if (types[v] == MHA_BASIS_HDIV) ++nhdiv;
+  }
+  const int32_t cell_base = next;
+  for (int e = 0; e < nelem && nhvol; ++e)
+    for (int v = 0; v < nvars; ++v)
+      if (types[v] == MHA_BASIS_HVOL) {
+        if (side_mask) side_mask[next] = 0;
+        if (dof_var) dof_var[next] = v;
+        ++next;
+      }
+  int32_t face_base[3] = {0, 0, 0};
+  for (int c = 0; c < dim && nhdiv; ++c) {
+    face_base[c] = next;
+    const int ex[3] = {ncx + (c == 0), ncy + (c == 1), dim == 3 ? ncz + (c == 2) : 1};
+    for (int k = 0; k < ex[2]; ++k)
+      for (int j = 0; j < ex[1]; ++j)
+        for (int i = 0; i < ex[0]; ++i)
+          for (int v = 0; v < nvars; ++v)
+            if (types[v] == MHA_BASIS_HDIV) {
+              const int idx[3] = {i, j, k};
+              uint8_t m = 0;
+              if (idx[c] == 0) m |= 1u << (2 * c);
+              if (idx[c] == ex[c] - 1) m |= 1u << (2 * c + 1);
+              if (side_mask) side_mask[next] = m;
+              if (dof_var) dof_var[next] = v;
+              ++next;
+            }
+  }
+  MHA_REQUIRE(next == static_cast<int32_t>(ndof), MHA_ERR_STATE, "mesh_multi: dof count mismatch");
+  const int kp = K + 1, nsite = K > 0 ? ipow(kp, dim) : 0;
+  std::vector<int> site_order;
+  {  // vertices in shards order, then the remaining tensor sites
+    std::vector<char> isv(nsite + 1, 0);
+    for (int v = 0; v < nn && K > 0; ++v) {
+      int t = 0, mul = 1;
+      for (int d = 0; d < dim; ++d) { t += (ref_vertex_sign(dim, v, d) > 0 ? K : 0) * mul; mul *= kp; }
+      site_order.push_back(t);
+      isv[t] = 1;
+    }
+    for (int t = 0; t < nsite; ++t)
+      if (!isv[t]) site_order.push_back(t);
+  }
+  // shards side -> vertices (quad: 4 edges, hex: 6 faces), as in ref_tables.cpp
+  static const int quad_side[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}};
+  static const int hex_side[6][4] = {{0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {0, 4, 7, 3}, {0, 3, 2, 1}, {4, 5, 6, 7}};
+  static const int face_of_dof3[6] = {3, 1, 0, 2, 4, 5}, edge_of_dof2[4] = {3, 1, 0, 2};
+  for (int e = 0; e < nelem; ++e) {
+    const int ci[3] = {e % ncx, (e / ncx) % ncy, e / (ncx * ncy)};
+    int32_t *L = lids + static_cast<size_t>(e) * n_tot;
+    int pos = 0;
+    for (int so = 0; so < nsite; ++so) {
+      const int t = site_order[so];
+      const int a[3] = {t % kp, (t / kp) % kp, t / (kp * kp)};
+      size_t s = 0, mul = 1;
+      for (int d = 0; d < dim; ++d) { s += static_cast<size_t>(ci[d] * K + a[d]) * mul; mul *= static_cast<size_t>(fd[d]); }
+      for (int v = 0; v < nvars; ++v) {
+        if (types[v] != MHA_BASIS_HGRAD) continue;
+        const int st = K / orders[v], p1 = orders[v] + 1;
+        bool in = true;
+        for (int d = 0; d < dim; ++d) in = in && (a[d] % st == 0);
+        if (!in) continue;
+        int dof = 0, m2 = 1;
+        for (int d = 0; d < dim; ++d) { dof += (a[d] / st) * m2; m2 *= p1; }
+        if (e == 0) offsets[varptr[v] + dof] = pos;
+        L[pos++] = gnode[static_cast<size_t>(v) * nfine + s];
+      }
+    }
+    for (int v = 0; v < nvars; ++v)
+      if (types[v] == MHA_BASIS_HVOL) {
+        if (e == 0) offsets[varptr[v]] = pos;
+        L[pos++] = cell_base + e * nhvol + hvol_rank[v];
+      }
+    for (int f = 0; f < 2 * dim && nhdiv; ++f) {
+      const int c = f / 2, sgn = f % 2;
+      const int ex[3] = {ncx + (c == 0), ncy + (c == 1), dim == 3 ? ncz + (c == 2) : 1};
+      int idx[3] = {ci[0], ci[1], ci[2]};
+      idx[c] += sgn;
+      const int lin = idx[0] + ex[0] * (idx[1] + ex[1] * idx[2]);
+      for (int v = 0; v < nvars; ++v)
+        if (types[v] == MHA_BASIS_HDIV) {
+          if (e == 0) offsets[varptr[v] + f] = pos;
+          L[pos++] = face_base[c] + lin * nhdiv + hdiv_rank[v];
+        }
+    }
+    MHA_REQUIRE(pos == n_tot, MHA_ERR_STATE, "mesh_multi: LID list length mismatch");
+    if (orient) {
+      int8_t *o = orient + static_cast<size_t>(e) * n_tot;
+      for (int k = 0; k < n_tot; ++k) o[k] = 1;
+      const int32_t *cv = cell2vert + static_cast<size_t>(e) * nn;
+      for (int v = 0; v < nvars; ++v) {
+        if (types[v] != MHA_BASIS_HDIV) continue;
+        for (int f = 0; f < 2 * dim; ++f) {
+          bool flip;
+          if (dim == 2) {
+            const int *sn = quad_side[edge_of_dof2[f]];
+            flip = cv[sn[0]] > cv[sn[1]];
+          } else {
+            const int *sn = hex_side[face_of_dof3[f]];
+            int rot = 0;
+            for (int k = 1; k < 4; ++k)
+              if (cv[sn[k]] < cv[sn[rot]]) rot = k;
+            flip = cv[sn[(rot + 1) % 4]] > cv[sn[(rot + 3) % 4]];
+          }
+          const int sigma = (f % 2) ? 1 : -1;  // phi_raw . n_out on its own face
+          o[varptr[v] + f] = static_cast<int8_t>(flip ? -sigma : sigma);
+        }
+      }
+    }
+  }
+}
+
 void build_row_incidence(int nrows, int nelem, int n, const int32_t *lids, std::vector<int32_t> &ptr,
                          std::vector<int32_t> &elem, std::vector<int32_t> &lpos) {
   ptr.assign(static_cast<size_t>(nrows) + 1, 0);

@@ -14,6 +14,14 @@ void mesh_structured(int dim, int order, const int *ncell, const double *lo, con
                      double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
                      uint8_t *boundary_dof);
 
+// Blocks with several variables (HGRAD of orders dividing the largest, HVOL order 0, HDIV order 1): sizes, then the mesh
+// + subcell-major dof map + lowest-order HDIV orientation signs (mesh.cpp).
+void mesh_multi_sizes(int dim, const int *ncell, int nvars, const int *types, const int *orders, int *nverts, int *nelem,
+                      int *n_tot, int64_t *ndof);
+void mesh_structured_multi(int dim, const int *ncell, const double *lo, const double *hi, int nvars, const int *types,
+                           const int *orders, double *verts, int32_t *cell2vert, int32_t *lids, int32_t *offsets,
+                           int8_t *orient, uint8_t *side_mask, int32_t *dof_var);
+
 // Overlapped CRS graph: every dof of an element couples to every dof of that element;
 // columns ascending (reference: src/interfaces/linearAlgebraInterface.cpp:218-229).
 void build_crs_graph(int nrows, int nelem, int n, const int32_t *lids, std::vector<int32_t> &rowptr,
