@@ -273,6 +273,65 @@ def test_navierstokes_32_cubed_jacobian_is_the_derivative_of_the_residual(oracle
     assert float((fd - Jd).abs().max() / Jd.abs().max()) < 1e-7
 
 
+def test_config4_navierstokes_64_cubed(oracle):
+    """navierstokes at BASELINE config 4 as stated: Q2 velocity / Q1 pressure on 64^3 hexes, 6.7e6 rows, 1.42e9 CRS
+    entries (more than 2^30: the guard for the column search's midpoint overflow that killed the first run of this
+    size), 16.6 GB of element matrices through the row gather.
+    (1) constant state: the CRS rows of the dofs of the centre element equal the ORACLE's rows on a 4^3 mesh of the same
+        element size (values, entry by entry: both graphs order a row's columns the same way);
+    (2) random state: the Jacobian times a random direction equals the central difference of the residual (1e-7)."""
+    torch = _torch()
+    import mrhyde_amd
+    H = oracle.HGRAD
+    nc, types, orders = 64, [H] * 4, [2, 1, 2, 2]
+    m = mrhyde_amd.mesh_multi(3, (nc,) * 3, types, orders)
+    m.update(types=np.array(types), orders=np.array(orders))
+    blk = _multi_block(m, "navierstokes", 4)
+    funcs = {"source ux": 0.3, "source uy": -0.1, "source uz": 0.2, "viscosity": 0.05, "density": 1.3}
+    for k, v in funcs.items():
+        blk.set_function(k, v)
+    rowptr, colind = blk.get_graph()
+    n, nnz = m["ndof"], len(colind)
+    assert nnz > 2 ** 30
+    dev = torch.device("cuda")
+    const = np.array([0.3, 0.1, -0.2, 0.15])                      # ux, pr, uy, uz
+    u = torch.tensor(const[m["dof_var"]], device=dev)
+    res = torch.zeros(n, dtype=torch.float64, device=dev)
+    vals = torch.zeros(nnz, dtype=torch.float64, device=dev)
+    blk.assemble_jacres(u, res, vals, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    torch.cuda.synchronize()
+    small = oracle.mesh_multi(3, (4, 4, 4), types, orders, hi=[4.0 / nc] * 3)
+    ref = oracle.assemble_block(small, oracle.PHYS_NAVIERSTOKES, 4, const[small["dof_var"]], funcs=funcs, params=[0, 0, 0])
+    e_big = ((nc // 2) * nc + nc // 2) * nc + nc // 2               # element (32, 32, 32): its corner 0 is the mesh centre
+    e_small = (2 * 4 + 2) * 4 + 2                                   # element (2, 2, 2) of the 4^3 mesh
+    for pos in range(0, m["lids"].shape[1], 7):                     # every 7th dof of the element: all four variables
+        r, r_s = int(m["lids"][e_big, pos]), int(small["lids"][e_small, pos])
+        big = vals[int(rowptr[r]):int(rowptr[r + 1])].cpu().numpy()
+        sm = ref["crs_vals"][ref["rowptr"][r_s]:ref["rowptr"][r_s + 1]]
+        assert len(big) == len(sm), (pos, len(big), len(sm))
+        assert np.abs(big - sm).max() < RTOL * np.abs(ref["crs_vals"]).max(), pos
+    # (2) derivative of the residual
+    g = torch.Generator("cuda").manual_seed(7)
+    u = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    dlt = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    blk.assemble_jacres(u, res, vals, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    eps = 1e-5
+    rp_, rm_ = torch.zeros_like(res), torch.zeros_like(res)
+    blk.assemble_jacres(u + eps * dlt, rp_, None, compute_jacobian=False, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    blk.assemble_jacres(u - eps * dlt, rm_, None, compute_jacobian=False, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True)
+    torch.cuda.synchronize()
+    rp_t, ci_t = torch.tensor(rowptr, device=dev), torch.tensor(colind, device=dev)
+    Jd = torch.zeros(n, dtype=torch.float64, device=dev)
+    for lo in range(0, n, 1 << 20):                                  # row chunks: the index tensors of 1.4e9 entries at once would be 30 GB
+        hi = min(n, lo + (1 << 20))
+        a, b = int(rowptr[lo]), int(rowptr[hi])
+        counts = (rp_t[lo + 1:hi + 1] - rp_t[lo:hi]).to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(hi - lo, device=dev), counts)
+        Jd[lo:hi].index_add_(0, rows, vals[a:b] * dlt[ci_t[a:b].to(torch.int64)])
+    fd = -(rp_ - rm_) / (2 * eps)  # the vector holds -res.val()
+    assert float((fd - Jd).abs().max() / Jd.abs().max()) < 1e-7
+
+
 @pytest.mark.parametrize("roe", [1, 0])
 def test_config5_hdg_256_squared_blocks_are_the_derivative_of_the_residual(oracle, roe):
     """shallowwaterHybridized HDG element at BASELINE config 5 (256^2 quads, Q1 interior + HFACE-1 traces, 36 unknowns
