@@ -350,6 +350,38 @@ int mha_row_partition_get(const mha_row_partition *p, int32_t *row_ptr, int32_t 
                           int32_t *elems);
 void mha_row_partition_destroy(mha_row_partition *p);
 
+/* ---- Export(ADD) of shared-DOF rows between element-block shards (one process per GPU) -----------------------------
+ * Replaces LinearAlgebraInterface::exportMatrixFromOverlapped / exportVectorFromOverlapped
+ * (src/interfaces/linearAlgebraInterface.hpp:296-337: Tpetra::Export, combine mode ADD): every rank assembles its
+ * overlapped CRS values / residual; the ranks that do not own a shared row send its partial values to the owner, which
+ * adds them.  The shared rows are explicit lists agreed at setup (any partition: HGRAD planes between slabs, HDIV face
+ * dofs, HDG trace rows, unequal slabs), CSR-style per neighbour (all *_ptr have num_neighbors + 1 entries, host arrays):
+ *   send_val_index: entries of my value array that go to the neighbour;  send_row_index: entries of my residual;
+ *   recv_val_target: for every value arriving from it, the entry of MY value array it is added to, or -1 (an off-rank
+ *                    column of one of my rows: stays in the receive buffer);  recv_row_target: likewise for the residual.
+ * No indices travel: both sides list a shared row's entries in the same (global id) order.
+ * mha_export_pack / mha_export_unpack_add are the device halves (the caller moves the buffers, e.g. with
+ * torch.distributed P2P, whose "nccl" backend is RCCL); mha_export_add does pack + ncclSend / ncclRecv with every
+ * neighbour in one group + unpack on this library's own RCCL communicator (mha_comm_*; librccl.so is loaded on first
+ * use).  Neighbours are unpacked in the order given: the sum is reproducible.                                        */
+typedef struct mha_export_plan mha_export_plan;
+typedef struct mha_comm mha_comm;
+int mha_export_plan_create(int num_neighbors, const int32_t *neighbor_ranks, const int64_t *send_val_ptr,
+                           const int32_t *send_val_index, const int64_t *send_row_ptr, const int32_t *send_row_index,
+                           const int64_t *recv_val_ptr, const int32_t *recv_val_target, const int64_t *recv_row_ptr,
+                           const int32_t *recv_row_target, mha_export_plan **out);
+void mha_export_plan_destroy(mha_export_plan *p);
+int mha_export_pack(const mha_export_plan *p, const double *vals_dev, const double *res_dev, void *hip_stream);
+int mha_export_unpack_add(const mha_export_plan *p, double *vals_dev, double *res_dev, void *hip_stream);
+/* buffers of neighbour k (device pointers; layout [values | residual entries]) and the bytes one exchange sends */
+int mha_export_buffers(const mha_export_plan *p, int k, double **send_dev, int64_t *send_count, double **recv_dev,
+                       int64_t *recv_count);
+int mha_export_bytes_on_wire(const mha_export_plan *p, int64_t *bytes);
+int mha_comm_unique_id(char id_out[128]);                       /* rank 0; broadcast the 128 bytes to the others */
+int mha_comm_create(int num_ranks, int rank, const char id[128], mha_comm **out); /* collective; current HIP device */
+void mha_comm_destroy(mha_comm *c);
+int mha_export_add(const mha_export_plan *p, mha_comm *c, double *vals_dev, double *res_dev, void *hip_stream);
+
 /* ---- introspection for bench / tests ---------------------------------------------
  * keys: "num_elems","num_rows","nnz","dofs_per_elem","num_ip","workset_size","last_path",
  *       "row_blocks","num_affine_elems","row_block_max_rows","row_block_max_elems",

@@ -19,7 +19,7 @@ EXPORTS = [
     "mha_set_mesh", "mha_set_graph", "mha_get_graph_sizes", "mha_get_graph", "mha_physics_select",
     "mha_set_function", "mha_set_time_integration", "mha_assemble_jacres", "mha_compute_local_jacres",
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
-    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_mesh_multi_sizes", "mha_mesh_structured_multi", "mha_get_info", "mha_set_timing",
+    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_mesh_multi_sizes", "mha_mesh_structured_multi", "mha_export_plan_create", "mha_export_plan_destroy", "mha_export_pack", "mha_export_unpack_add", "mha_export_buffers", "mha_export_bytes_on_wire", "mha_comm_unique_id", "mha_comm_create", "mha_comm_destroy", "mha_export_add", "mha_get_info", "mha_set_timing",
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_scatter_plan_create", "mha_scatter_plan_nnz",
     "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",

@@ -11,9 +11,17 @@
 #include "block_pattern.hpp"
 #include "test_hooks.h"
 #include "scatter_plan.hpp"
+#include "export_plan.hpp"
 
 struct mha_row_partition {
   mha::RowBlocks rb;
+};
+
+struct mha_export_plan {
+  std::unique_ptr<mha::ExportPlan> plan;
+};
+struct mha_comm {
+  std::unique_ptr<mha::Comm> comm;
 };
 
 struct mha_context {
@@ -443,6 +451,78 @@ int mha_test_block_patterns_host_apply(int dim, int num_rows, int num_elems, int
     counts[2] = pl.num_wgs;
     counts[3] = pl.num_parts;
     mha::block_patterns_host_apply(pl, factors, scale_u, scale_t, true, vals);
+  });
+}
+
+int mha_export_plan_create(int num_neighbors, const int32_t *neighbor_ranks, const int64_t *send_val_ptr,
+                           const int32_t *send_val_index, const int64_t *send_row_ptr, const int32_t *send_row_index,
+                           const int64_t *recv_val_ptr, const int32_t *recv_val_target, const int64_t *recv_row_ptr,
+                           const int32_t *recv_row_target, mha_export_plan **out) {
+  return guarded([&] {
+    MHA_REQUIRE(out != nullptr, MHA_ERR_INVALID, "null argument");
+    *out = nullptr;
+    auto p = std::make_unique<mha_export_plan>();
+    p->plan = std::make_unique<mha::ExportPlan>(num_neighbors, neighbor_ranks, send_val_ptr, send_val_index, send_row_ptr,
+                                                send_row_index, recv_val_ptr, recv_val_target, recv_row_ptr, recv_row_target);
+    *out = p.release();
+  });
+}
+
+void mha_export_plan_destroy(mha_export_plan *p) { delete p; }
+
+int mha_export_pack(const mha_export_plan *p, const double *vals_dev, const double *res_dev, void *hip_stream) {
+  return guarded([&] {
+    MHA_REQUIRE(p, MHA_ERR_INVALID, "null plan");
+    p->plan->pack(vals_dev, res_dev, static_cast<hipStream_t>(hip_stream));
+  });
+}
+
+int mha_export_unpack_add(const mha_export_plan *p, double *vals_dev, double *res_dev, void *hip_stream) {
+  return guarded([&] {
+    MHA_REQUIRE(p, MHA_ERR_INVALID, "null plan");
+    p->plan->unpackAdd(vals_dev, res_dev, static_cast<hipStream_t>(hip_stream));
+  });
+}
+
+int mha_export_buffers(const mha_export_plan *p, int k, double **send_dev, int64_t *send_count, double **recv_dev,
+                       int64_t *recv_count) {
+  return guarded([&] {
+    MHA_REQUIRE(p && send_dev && send_count && recv_dev && recv_count, MHA_ERR_INVALID, "null argument");
+    *send_dev = p->plan->sendBuffer(k, send_count);
+    *recv_dev = p->plan->recvBuffer(k, recv_count);
+  });
+}
+
+int mha_export_bytes_on_wire(const mha_export_plan *p, int64_t *bytes) {
+  return guarded([&] {
+    MHA_REQUIRE(p && bytes, MHA_ERR_INVALID, "null argument");
+    *bytes = p->plan->bytesOnWire();
+  });
+}
+
+int mha_comm_unique_id(char id_out[128]) {
+  return guarded([&] {
+    MHA_REQUIRE(id_out != nullptr, MHA_ERR_INVALID, "null argument");
+    mha::Comm::uniqueId(id_out);
+  });
+}
+
+int mha_comm_create(int num_ranks, int rank, const char id[128], mha_comm **out) {
+  return guarded([&] {
+    MHA_REQUIRE(out != nullptr, MHA_ERR_INVALID, "null argument");
+    *out = nullptr;
+    auto c = std::make_unique<mha_comm>();
+    c->comm = std::make_unique<mha::Comm>(num_ranks, rank, id);
+    *out = c.release();
+  });
+}
+
+void mha_comm_destroy(mha_comm *c) { delete c; }
+
+int mha_export_add(const mha_export_plan *p, mha_comm *c, double *vals_dev, double *res_dev, void *hip_stream) {
+  return guarded([&] {
+    MHA_REQUIRE(p && c, MHA_ERR_INVALID, "null plan or communicator");
+    p->plan->exportAdd(*c->comm, vals_dev, res_dev, static_cast<hipStream_t>(hip_stream));
   });
 }
 

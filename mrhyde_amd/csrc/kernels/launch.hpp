@@ -90,6 +90,10 @@ void launch_swhdg_element(const BlockDev &b, const SideTablesDev &st, const SwhE
 void launch_condense(int n_int, int n_trace, int64_t nelem, const double *blocks, const double *res, double *schur,
                      double *gvec, double *du, int *singular, hipStream_t stream);
 
+// export.hip: pack / unpack-add of the shared-row Export(ADD) (export_plan.hpp)
+void launch_export_pack(const double *src, const int32_t *idx, int64_t n, double *dst, hipStream_t stream);
+void launch_export_unpack_add(const double *src, const int32_t *tgt, int64_t n, double *dst, hipStream_t stream);
+
 // point_engine.hip: multi-variable blocks, any physics module stated as a point function
 // slot: element-major CRS slot map (launch_build_elem_slot_map) or null for the column search
 void launch_point_engine(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,

@@ -2,8 +2,10 @@
 
 Mirrors the reference's rank-count independence check (regression/thermal/2D_verification_mpi): the
 2-shard result, after the shared-row exchange, equals the single-domain assembly row by row.
-The per-shard assembly itself comes from the CPU oracle here (no GPU in this test); the exchange code
-is device-agnostic torch and is the same object bench.py drives over RCCL.
+The per-shard assembly itself comes from the CPU oracle here (no GPU in this test); the lists the exchange
+walks (who sends which entries, where every received entry is added) are the ones the library's pack /
+unpack kernels get on a GPU (tests/test_shared_rows_gpu.py runs the same comparison with GPU assembly and
+the C-ABI kernels, two processes on one card).
 """
 import os
 import socket
@@ -57,9 +59,12 @@ def _worker(rank, world, port, dim, order, qdeg, nxy, nz_per, q):
         res = torch.tensor(out["res"])
         ex = SlabExchange(out["rowptr"], out["colind"], P, nrows, rank, world, torch.device("cpu"))
         ex.export_add(res, vals)
-        q.put((rank, out["rowptr"], out["colind"], vals.numpy(), res.numpy(),
-               ex.remote_vals.numpy() if ex.has_upper else None,
-               ex.remote_idx.numpy() if ex.has_upper else None, off, ex.bytes_on_wire()))
+        rv, ri = (None, None)
+        if rank < world - 1:
+            rv, ri = ex.remote_vals(rank + 1)
+            rv = rv.numpy().copy()
+        # bytes a rank sends: its bottom-plane rows (values + residual) when it has a lower neighbour
+        q.put((rank, out["rowptr"], out["colind"], vals.numpy(), res.numpy(), rv, ri, off, ex.bytes_on_wire()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -117,7 +122,7 @@ def test_two_slabs_equal_single_domain(oracle, order, nxy, nz_per):
                 assert abs(remote_vals[k] - g) <= 1e-12 * scale
                 k += 1
             assert k == len(remote_vals)
-            assert wire == (up_rowptr[P] + P) * 8
+            assert got[rank + 1][8] == (up_rowptr[P] + P) * 8
 
 
 def _worker_ns(rank, world, port, nxy, nz_per, q):
@@ -185,3 +190,81 @@ def test_two_slabs_navierstokes_block(oracle):
         for r in owned:
             assert np.abs(Jl[r] - Jg[r + off][off:off + nrows]).max() <= 1e-12 * scale, (rank, r)
             assert abs(res[r] - ref["res"][r + off]) <= 1e-12 * np.abs(ref["res"]).max()
+
+
+def _worker_porous(rank, world, port, nxy, nz, q):
+    """porousMixed (HVOL p + HDIV u): the shared dofs are the z-faces between the slabs -- not a leading / trailing run
+    of rows, so this is the explicit-list case; slabs of different thickness (nz[rank] layers)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import oracle_lib as orc
+    from mrhyde_amd.shared_rows import SharedRowExport
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z0 = float(sum(nz[:rank]))
+        m = orc.mesh_multi(3, (nxy, nxy, nz[rank]), [orc.HVOL, orc.HDIV], [0, 1], lo=[0.0, 0.0, z0], hi=[1.0, 1.0, z0 + nz[rank]])
+        gid = _porous_gids(nxy, nz, rank)
+        rng = np.random.default_rng(55)
+        u_glob = rng.uniform(-1, 1, _porous_ndof(nxy, sum(nz)))
+        u = u_glob[gid]
+        out = orc.assemble_block(m, orc.PHYS_POROUS_MIXED, 2, u, funcs={"source": 0.7, "Kinv_xx": 1.3})
+        vals, res = torch.tensor(out["crs_vals"]), torch.tensor(out["res"])
+        ex = SharedRowExport(gid, out["rowptr"], out["colind"], rank, world, torch.device("cpu"))
+        ex.export_add(res, vals)
+        q.put((rank, gid, out["rowptr"], out["colind"], vals.numpy(), res.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _porous_ndof(nxy, nz):
+    return nxy * nxy * nz + (nxy + 1) * nxy * nz * 2 + nxy * nxy * (nz + 1)
+
+
+def _porous_gids(nxy, nz, rank):
+    """Global ids (numbering of the single-domain mesh_multi: cells, x-faces, y-faces, z-faces) of a slab's dofs."""
+    nzt, k0, nzl = sum(nz), sum(nz[:rank]), nz[rank]
+    ne_g = nxy * nxy * nzt
+    cells = np.arange(nxy * nxy * nzl) + nxy * nxy * k0
+    fx = ne_g + np.arange((nxy + 1) * nxy * nzl) + (nxy + 1) * nxy * k0
+    fy = ne_g + (nxy + 1) * nxy * nzt + np.arange(nxy * (nxy + 1) * nzl) + nxy * (nxy + 1) * k0
+    fz = ne_g + 2 * (nxy + 1) * nxy * nzt + np.arange(nxy * nxy * (nzl + 1)) + nxy * nxy * k0
+    return np.concatenate([cells, fx, fy, fz]).astype(np.int64)
+
+
+def test_two_unequal_slabs_porous_mixed_explicit_lists(oracle):
+    nxy, nz, world = 3, (2, 1), 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_porous, args=(r, world, port, nxy, nz, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=180)
+        got[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mg = oracle.mesh_multi(3, (nxy, nxy, sum(nz)), [oracle.HVOL, oracle.HDIV], [0, 1], hi=[1.0, 1.0, float(sum(nz))])
+    assert mg["ndof"] == _porous_ndof(nxy, sum(nz))
+    u_glob = np.random.default_rng(55).uniform(-1, 1, mg["ndof"])
+    ref = oracle.assemble_block(mg, oracle.PHYS_POROUS_MIXED, 2, u_glob, funcs={"source": 0.7, "Kinv_xx": 1.3})
+    Jg = sp.csr_matrix((ref["crs_vals"], ref["colind"], ref["rowptr"]), shape=(mg["ndof"],) * 2).toarray()
+    scale = np.abs(Jg).max()
+    seen = np.zeros(mg["ndof"], bool)
+    for rank in range(world):
+        _, gid, rowptr, colind, vals, res = got[rank]
+        n = len(gid)
+        Jl = sp.csr_matrix((vals, colind, rowptr), shape=(n, n)).toarray()
+        owned = ~np.isin(gid, got[0][1]) if rank > 0 else np.ones(n, bool)  # the lower slab owns the shared faces
+        for r in np.flatnonzero(owned):
+            assert np.abs(Jl[r] - Jg[gid[r]][gid]).max() <= 1e-12 * scale, (rank, r)
+            assert abs(res[r] - ref["res"][gid[r]]) <= 1e-12 * np.abs(ref["res"]).max()
+            seen[gid[r]] = True
+    assert seen.all()
