@@ -157,6 +157,12 @@ int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int
  * path: MHA_PATH_AUTO picks the fastest valid kernel; the others force one.          */
 #define MHA_ASSEMBLE_JACOBIAN 1
 #define MHA_ASSEMBLE_OVERWRITE 2
+/* scatter options of AssemblyManager::scatter (assemblyManager.cpp:4124-4133), reproduced as the reference has them:
+ * ADJOINT (isAdjoint_): every column of a row receives res(elem,row).fastAccessDx(row); LUMP_MASS (lump_mass_): every
+ * column's value is added to the row's diagonal entry (cols[col] = rowIndex).  Both go through the element matrices +
+ * row gather (MHA_PATH_AUTO picks it; the fused fast paths do not carry the options).                             */
+#define MHA_ASSEMBLE_ADJOINT 4
+#define MHA_ASSEMBLE_LUMP_MASS 8
 #define MHA_PATH_AUTO 0
 #define MHA_PATH_ELEMENT_ATOMIC 1 /* per-element kernel, atomic scatter (reference's
                                      fused "assembly insert Jac" with useAtomics)     */
@@ -200,11 +206,30 @@ int mha_gather(mha_context *ctx, const double *vec_dev, double *elem_vals_dev);
  * names: "basis" (numElem,n,numip,1)  "basis_grad" (numElem,n,numip,dim)
  *        "wts" (numElem,numip)  "x","y","z" (numElem,numip)  "LIDs" (numElem,n) int32
  *        "offsets" (numvars, maxdof) int32
+ * per variable (any block; <var> is the module's variable name, "var<k>" without a module):
+ *   "basis <var>" (numElem,card,numip,ncomp)   getBasis(var)      workset.hpp:241   ncomp = dim for HDIV (Piola
+ *                                              value J phi / detJ, orientation sign applied), 1 for HGRAD / HVOL
+ *   "basis_grad <var>" (numElem,card,numip,dim) getBasisGrad(var) workset.hpp:249   HGRAD
+ *   "basis_div <var>" (numElem,card,numip)      getBasisDiv(var)  workset.hpp:270   HDIV
+ *   (discretizationInterface.cpp:898-1127; "basis"/"basis_grad" without a name: single-variable HGRAD blocks)
+ * mha_workset_compute_solution: Workset::computeSoln on the current workset (workset.cpp:1017-1190) from
+ *   u / u_prev / u_stage with the transient seeding of :589-623; afterwards the solution fields are views
+ *   (numElem,numip) under the reference's names -- getSolutionField (workset.hpp:229): "<var>", "<var>_t",
+ *   "grad(<var>)[x|y|z]" (HGRAD), "<var>[x|y|z]", "<var>_t[x|y|z]", "div(<var>)" (HDIV).  The views hold the
+ *   fields' values; their derivative arrays never leave the chip (d field / d u_j = alpha_u * basis).
+ * mha_workset_compute_residual: resetResidual + volumeResidual on the current workset (what assembleJacRes does
+ *   between updateWorkset and scatter, assemblyManager.cpp:2426-2440); afterwards "res" (numElem,n) = res(e,i).val()
+ *   and, with compute_jacobian, "res.dx" (numElem,n,n) = res(e,i).fastAccessDx(j) -- getResidual (workset.hpp:193),
+ *   i, j = positions in the element's LID list.
  * unknown names: MHA_ERR_UNKNOWN_FIELD (the reference prints and continues,
  * workset.cpp:1576-1577).                                                             */
 int mha_num_worksets(mha_context *ctx);
 int mha_workset_update(mha_context *ctx, int index);
 int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t extents[4], int *rank);
+int mha_workset_compute_solution(mha_context *ctx, const double *u_dev, const double *u_prev_dev,
+                                 const double *u_stage_dev);
+int mha_workset_compute_residual(mha_context *ctx, int compute_jacobian, const double *u_dev,
+                                 const double *u_prev_dev, const double *u_stage_dev);
 
 /* ---- boundary groups -----------------------------------------------------------
  * replaces: BoundaryGroup (src/tools/boundaryGroup.hpp:23-186, boundaryGroup.cpp:25-178), the
@@ -222,9 +247,17 @@ int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t
  * assembly of the same Newton step; MHA_ASSEMBLE_OVERWRITE is rejected).
  * mha_boundary_update / mha_boundary_view expose the side data the reference keeps in the
  * workset: "wts side" (num,numip) "x","y","z" (num,numip) "n[x]","n[y]","n[z]" (num,numip)
- * "basis side" (num,n,numip,1) "basis_grad side" (num,n,numip,dim).                        */
+ * "basis side" (num,n,numip,1) "basis_grad side" (num,n,numip,dim); per variable on any block
+ * (getBasisSide(var) / getBasisGradSide(var), workset.hpp:281-293; getPhysicalBoundaryBasis,
+ * discretizationInterface.cpp:1840-1950): "basis side <var>" (num,card,numip,ncomp), "basis_grad side <var>".
+ * mha_add_flux_group: the generic "Flux" condition of PhysicsInterface::fluxConditions
+ * (src/interfaces/physicsInterface.cpp:1702-1762) for one variable of any block on one side set:
+ * res(elem, off(dof)) += -flux * wts side * basis side(elem,dof,pt,0) with flux = the function
+ * "Flux <var> <sidename>" at the side points (constant, closed form, expression in x,y,z,t,nx,ny,nz, or a dev
+ * array [num_sides][side numip]); no Jacobian contribution.  mha_assemble_boundary runs it with the other groups. */
 #define MHA_BC_NEUMANN 1
 #define MHA_BC_WEAK_DIRICHLET 2
+#define MHA_BC_FLUX 3
 /* shallowwaterHybridized side types (bcs(H_num, side): "interface", "Far-field", "Slip",
  * shallowwaterHybridized.cpp:286-300, 612-620): the group's entries are element sides (all four sides of every
  * element for the HDG interior problem); the trace state comes from the functions "aux H <sidename>",
@@ -236,6 +269,8 @@ int mha_workset_view(mha_context *ctx, const char *name, void **dev_ptr, int64_t
 #define MHA_BC_SWH_SLIP 12
 int mha_add_boundary_group(mha_context *ctx, const char *sidename, int bc_type, int num_sides,
                            const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id);
+int mha_add_flux_group(mha_context *ctx, const char *sidename, const char *varname, int num_sides,
+                       const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id);
 int mha_clear_boundary_groups(mha_context *ctx);
 int mha_num_boundary_groups(mha_context *ctx);
 int mha_assemble_boundary(mha_context *ctx, int flags, const double *u_dev, const double *u_prev_dev,
@@ -244,7 +279,9 @@ int mha_boundary_update(mha_context *ctx, int group_id);
 int mha_boundary_view(mha_context *ctx, int group_id, const char *name, void **dev_ptr, int64_t extents[4],
                       int *rank);
 /* scalar settings of the physics module; thermal: "form_param" (thermal.cpp:35, default 1:
- * symmetric Nitsche; -1 the non-symmetric variant); navierstokes: "useSUPG", "usePSPG"
+ * symmetric Nitsche; -1 the non-symmetric variant), "include advection" (thermal.cpp:39, default 0; 1 adds
+ * (b . grad e, v) with the functions "bx","by","bz", thermal.cpp:59-61, 150-160: the block then assembles on the
+ * point engine, MHA_PATH_ROW_OWNER is refused); navierstokes: "useSUPG", "usePSPG"
  * (navierstokes.cpp:45-46) and "fix_uz_offsets": the reference scatters the 3-D uz momentum
  * block through uy's offsets (navierstokes.cpp:688); 0 (default) reproduces that, 1 uses uz's;
  * shallowwaterHybridized: "g" (shallowwaterHybridized.cpp:72, default 9.81).                     */

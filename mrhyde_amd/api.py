@@ -25,13 +25,14 @@ EXPORTS = [
     "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
     "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense", "mha_set_function_expression", "mha_set_time", "mha_check_expression",
+    "mha_add_flux_group", "mha_workset_compute_solution", "mha_workset_compute_residual",
 ]
 SWH_INTERFACE, SWH_FARFIELD, SWH_SLIP = 0, 1, 2
 BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
 PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3, "shallowwaterHybridized": 4}
 PATH_POINT_ENGINE = 4
 PATH_ROW_GATHER = 5
-BC_NEUMANN, BC_WEAK_DIRICHLET = 1, 2
+BC_NEUMANN, BC_WEAK_DIRICHLET, BC_FLUX = 1, 2, 3
 BC_SWH_INTERFACE, BC_SWH_FARFIELD, BC_SWH_SLIP = 10, 11, 12
 
 
@@ -91,6 +92,9 @@ def load_library():
         _lib.mha_block_destroy.argtypes = [C.c_void_p]
         _lib.mha_add_boundary_group.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_void_p]
+        _lib.mha_add_flux_group.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_workset_compute_solution.argtypes = [C.c_void_p] * 4
+        _lib.mha_workset_compute_residual.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         _lib.mha_clear_boundary_groups.argtypes = [C.c_void_p]
         _lib.mha_num_boundary_groups.argtypes = [C.c_void_p]
         _lib.mha_assemble_boundary.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
@@ -408,8 +412,9 @@ class Block:
 
     # -- assembly -----------------------------------------------------------
     def assemble_jacres(self, u, res, crs_vals=None, compute_jacobian=True, path=PATH_AUTO, u_prev=None,
-                        u_stage=None, overwrite=False):
-        flags = (1 if compute_jacobian else 0) | (2 if overwrite else 0)
+                        u_stage=None, overwrite=False, adjoint=False, lump_mass=False):
+        """adjoint / lump_mass: the scatter options isAdjoint_ / lump_mass_ of the reference (MHA_ASSEMBLE_ADJOINT, _LUMP_MASS)."""
+        flags = (1 if compute_jacobian else 0) | (2 if overwrite else 0) | (4 if adjoint else 0) | (8 if lump_mass else 0)
         _check(load_library().mha_assemble_jacres(self._h, flags, path, _ptr(u), _ptr(u_prev),
                                                   _ptr(u_stage), _ptr(res), _ptr(crs_vals)))
 
@@ -443,6 +448,15 @@ class Block:
         _check(load_library().mha_add_boundary_group(self._h, sidename.encode(), bc_type, len(e),
                                                      e.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p),
                                                      C.byref(gid)))
+        return gid.value
+
+    def add_flux_group(self, sidename, varname, elem_ids, side_ids):
+        """The "Flux" condition of PhysicsInterface::fluxConditions for one variable; data = function "Flux <var> <side>"."""
+        e, s_ = _np(elem_ids, np.int32), _np(side_ids, np.int32)
+        gid = C.c_int()
+        _check(load_library().mha_add_flux_group(self._h, sidename.encode(), varname.encode(), len(e),
+                                                 e.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p),
+                                                 C.byref(gid)))
         return gid.value
 
     def clear_boundary_groups(self):
@@ -482,6 +496,15 @@ class Block:
 
     def workset_update(self, index):
         _check(load_library().mha_workset_update(self._h, index))
+
+    def workset_compute_solution(self, u, u_prev=None, u_stage=None):
+        """Workset::computeSoln on the current workset; the fields become views ("e", "grad(e)[x]", "u[x]", "div(u)", ...)."""
+        _check(load_library().mha_workset_compute_solution(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage)))
+
+    def workset_compute_residual(self, u, compute_jacobian=True, u_prev=None, u_stage=None):
+        """resetResidual + volumeResidual on the current workset; views "res" and "res.dx"."""
+        _check(load_library().mha_workset_compute_residual(self._h, int(compute_jacobian), _ptr(u), _ptr(u_prev),
+                                                           _ptr(u_stage)))
 
     def workset_view(self, name):
         """-> (device pointer, shape tuple)."""

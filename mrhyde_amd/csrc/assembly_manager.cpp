@@ -405,13 +405,19 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
   MHA_REQUIRE(res != nullptr, MHA_ERR_INVALID, "residual vector is null");
   MHA_REQUIRE(!compute_jacobian || crs_vals, MHA_ERR_INVALID, "compute_jacobian set but crs_vals is null");
   bindState(u, u_prev, u_stage);
-  if (physics_id_ != MHA_PHYSICS_THERMAL) {
-    // multi-variable modules run on the point engine
+  if (engineOnly()) {
+    // multi-variable modules (and thermal with its advection term) run on the point engine
     if (path == MHA_PATH_AUTO) path = MHA_PATH_ROW_GATHER;
     if (path == MHA_PATH_ELEMENT_ATOMIC) path = MHA_PATH_POINT_ENGINE;
     MHA_REQUIRE(path == MHA_PATH_POINT_ENGINE || path == MHA_PATH_LOCAL_THEN_SCATTER || path == MHA_PATH_ROW_GATHER,
                 MHA_ERR_INVALID,
                 "assembly path " << path << " is not available for this physics module");
+  }
+  const bool adjoint = (flags & MHA_ASSEMBLE_ADJOINT) != 0, lump_mass = (flags & MHA_ASSEMBLE_LUMP_MASS) != 0;
+  if (adjoint || lump_mass) {  // scatter options: element matrices + row gather
+    MHA_REQUIRE(path == MHA_PATH_AUTO || path == MHA_PATH_ROW_GATHER, MHA_ERR_INVALID,
+                "the adjoint / lumped-mass scatter options need MHA_PATH_AUTO or MHA_PATH_ROW_GATHER");
+    path = MHA_PATH_ROW_GATHER;
   }
   if (path == MHA_PATH_AUTO) {
     if (!ro_.ready && !ro_.failed && thermal_row_owner_supported(dim_, order_, ref_.nq1)) {
@@ -465,7 +471,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
       // thermal: the element matrices come from the specialised general-element kernel (kernels/thermal_general.hip;
       // perturbed config 2: 4.1 ms against 7.7 ms with the point engine); MHA_ROW_GATHER_KERNEL=engine forces the engine
       static const bool use_general = [] { const char *m = std::getenv("MHA_ROW_GATHER_KERNEL"); return !(m && m[0] == 'e'); }();
-      if (physics_id_ == MHA_PHYSICS_THERMAL && use_general && thermal_row_owner_supported(dim_, order_, ref_.nq1)) {
+      if (!engineOnly() && use_general && thermal_row_owner_supported(dim_, order_, ref_.nq1)) {
         wkset_.first_elem = 0;
         wkset_.numElem = nelem_;
         wkset_.res = o;
@@ -487,6 +493,8 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
       g.slot = d_elem_slot_.data();
       g.slot_bytes = elem_slot_bytes_;
       g.max_row = max_row_;
+      g.adjoint = adjoint ? 1 : 0;
+      g.lump_mass = lump_mass ? 1 : 0;
       launch_row_gather(blockDev(), g, o.local_J, o.local_res, res, compute_jacobian ? crs_vals : nullptr,
                         overwrite ? 1 : 0, stream_);
       break;
@@ -517,7 +525,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         wkset_.res.local_J = d_local_J_.data();
         wkset_.res.local_res = d_local_res_.data();
         wkset_.use_general = false;  // this path keeps the baseline element kernel: an independent implementation
-        if (physics_id_ != MHA_PHYSICS_THERMAL) launchPointEngine(compute_jacobian, wkset_.res, e0, ne);
+        if (engineOnly()) launchPointEngine(compute_jacobian, wkset_.res, e0, ne);
         else physics_->volumeResidual();
         BlockDev b = blockDev();
         b.e_begin = e0;
@@ -548,7 +556,7 @@ void AssemblyManager::computeLocalJacRes(int compute_jacobian, const double *u, 
   wkset_.res.local_J = compute_jacobian ? local_J : nullptr;
   wkset_.res.local_res = local_res;
   timedBegin();
-  if (physics_id_ != MHA_PHYSICS_THERMAL) {
+  if (engineOnly()) {
     launchPointEngine(compute_jacobian, wkset_.res, 0, nelem_);
   } else {
     useGeneralKernel(false);
@@ -639,6 +647,195 @@ void AssemblyManager::worksetUpdate(int index) {
   wkset_.first_elem = index * wkset_.maxElem;
   wkset_.numElem = std::min(wkset_.maxElem, nelem_ - wkset_.first_elem);
   wkset_.update_views();
+  ws_fields_first_ = -1;
+  ws_res_first_ = -1;
+  if (!single_hgrad_) {
+    // every variable's basis / basis_grad / basis_div on this workset (Group::computeBasis keeps one set per basis)
+    ws_var_views_.resize(vars_.size());
+    const size_t cap = static_cast<size_t>(std::max(wkset_.maxElem, wkset_.numElem));
+    for (size_t v = 0; v < vars_.size(); ++v) {
+      const VarInfo &vi = vars_[v];
+      VarViews &vv = ws_var_views_[v];
+      vv.basis.resize(cap * vi.card * nq_ * varComps(static_cast<int>(v)));
+      if (vi.type == MHA_BASIS_HGRAD) vv.grad.resize(cap * vi.card * nq_ * dim_);
+      if (vi.type == MHA_BASIS_HDIV) vv.div.resize(cap * vi.card * nq_);
+      VarViewsDev out;
+      out.basis = vv.basis.data();
+      out.grad = vv.grad.data();
+      out.div = vv.div.data();
+      launch_var_views(blockDev(), varPoints(static_cast<int>(v), false), nullptr, nullptr, wkset_.first_elem,
+                       wkset_.numElem, out, stream_);
+    }
+  }
+}
+
+// variable names are the module's myvars (reference: var_list[set][block]); without a module: "var0", "var1", ...
+std::string AssemblyManager::varName(int v) const {
+  if (physics_ && v < static_cast<int>(physics_->myvars.size())) return physics_->myvars[v];
+  return "var" + std::to_string(v);
+}
+
+int AssemblyManager::varIndex(const std::string &name) const {
+  for (int v = 0; v < static_cast<int>(vars_.size()); ++v)
+    if (varName(v) == name) return v;
+  return -1;
+}
+
+// reference values of variable v at the volume points (one set) or at the side points (one set per local side);
+// built on first use, kept for the life of the block
+VarPointsDev AssemblyManager::varPoints(int v, bool side) {
+  std::vector<VarTables> &tabs = side ? var_side_tables_ : var_vol_tables_;
+  if (tabs.size() != vars_.size()) tabs.resize(vars_.size());
+  if (side) prepareSideTables();
+  const VarInfo &vi = vars_[v];
+  const int nsets = side ? side_ref_.nsides : 1, np = side ? side_ref_.nqs : nq_;
+  VarTables &t = tabs[v];
+  if (!t.ready) {
+    std::vector<double> val, grad, div, a, b, c;
+    for (int s = 0; s < nsets; ++s) {
+      const double *pts = side ? side_ref_.ip.data() + static_cast<size_t>(s) * np * dim_ : ref_.ip.data();
+      const int card = ref_basis_var(dim_, vi.type, vi.order, np, pts, a, b, c);
+      MHA_REQUIRE(card == vi.card, MHA_ERR_INVALID, "basis cardinality mismatch");
+      val.insert(val.end(), a.begin(), a.end());
+      grad.insert(grad.end(), b.begin(), b.end());
+      div.insert(div.end(), c.begin(), c.end());
+    }
+    t.val.upload(val);
+    t.grad.upload(grad);
+    t.div.upload(div);
+    t.ready = true;
+  }
+  VarPointsDev d;
+  d.type = vi.type;
+  d.card = vi.card;
+  d.npts = np;
+  d.val = t.val.data();
+  d.grad = t.grad.data();
+  d.div = t.div.data();
+  d.nodegrad = side ? d_side_nodegrad_.data() : d_nodegrad_.data();
+  d.orient = has_orient_ ? d_orient_.data() : nullptr;
+  d.n_tot = n_;
+  d.var_off = layout_.varptr[v];
+  return d;
+}
+
+void AssemblyManager::worksetVarArrays(int v, const double **basis, const double **grad, const double **div) const {
+  if (single_hgrad_) {
+    *basis = static_cast<const double *>(wkset_.get("basis").ptr);
+    *grad = static_cast<const double *>(wkset_.get("basis_grad").ptr);
+    *div = nullptr;
+  } else {
+    MHA_REQUIRE(ws_var_views_.size() == vars_.size(), MHA_ERR_STATE, "workset views requested before mha_workset_update");
+    *basis = ws_var_views_[v].basis.data();
+    *grad = ws_var_views_[v].grad.data();
+    *div = ws_var_views_[v].div.data();
+  }
+}
+
+// reference: Workset::getBasis(var) / getBasisGrad(var) / getBasisDiv(var) (workset.hpp:241-275), getResidual (:193),
+// getSolutionField (:229).  Names: "basis <var>" (numElem,card,numip,ncomp) "basis_grad <var>" (numElem,card,numip,dim)
+// "basis_div <var>" (numElem,card,numip); "res" (numElem,n) "res.dx" (numElem,n,n); field names as the reference
+// spells them: "<var>", "grad(<var>)[x]", "<var>_t", "<var>[x]", "<var>_t[x]", "div(<var>)" (numElem,numip).
+View AssemblyManager::worksetView(const std::string &name) const {
+  View v;
+  const int64_t ne = wkset_.numElem;
+  auto var_of = [&](const std::string &prefix) -> int {
+    if (name.compare(0, prefix.size(), prefix) != 0) return -1;
+    return varIndex(name.substr(prefix.size()));
+  };
+  int k;
+  if ((k = var_of("basis_grad ")) >= 0 || (k = var_of("basis_div ")) >= 0 || (k = var_of("basis ")) >= 0) {
+    const double *b, *g, *d;
+    worksetVarArrays(k, &b, &g, &d);
+    const VarInfo &vi = vars_[k];
+    v.extent[0] = ne; v.extent[1] = vi.card; v.extent[2] = nq_;
+    if (name[5] == ' ') { v.ptr = const_cast<double *>(b); v.rank = 4; v.extent[3] = varComps(k); }
+    else if (name[6] == 'g') { v.ptr = const_cast<double *>(g); v.rank = 4; v.extent[3] = dim_; }
+    else { v.ptr = const_cast<double *>(d); v.rank = 3; }
+    if (!v.ptr) throw Error(MHA_ERR_UNKNOWN_FIELD, "'" + name + "' is not defined for this basis type");
+    return v;
+  }
+  if (name == "res" || name == "res.dx") {
+    MHA_REQUIRE(ws_res_first_ == wkset_.first_elem && ws_res_first_ >= 0, MHA_ERR_STATE,
+                "'" << name << "' requested before mha_workset_compute_residual on this workset");
+    if (name == "res") { v.ptr = ws_res_.data(); v.rank = 2; v.extent[0] = ws_res_num_; v.extent[1] = n_; }
+    else {
+      MHA_REQUIRE(ws_res_has_dx_, MHA_ERR_STATE, "the residual was computed without its derivative array");
+      v.ptr = ws_res_dx_.data(); v.rank = 3; v.extent[0] = ws_res_num_; v.extent[1] = n_; v.extent[2] = n_;
+    }
+    return v;
+  }
+  auto it = ws_fields_.find(name);
+  if (it != ws_fields_.end()) {
+    MHA_REQUIRE(ws_fields_first_ == wkset_.first_elem, MHA_ERR_STATE,
+                "solution field '" << name << "' requested before mha_workset_compute_solution on this workset");
+    v.ptr = it->second.data(); v.rank = 2; v.extent[0] = ne; v.extent[1] = nq_;
+    return v;
+  }
+  return wkset_.get(name);
+}
+
+void AssemblyManager::worksetComputeSolution(const double *u, const double *u_prev, const double *u_stage) {
+  requireReady(false);
+  MHA_REQUIRE(wkset_.get("LIDs").ptr != nullptr, MHA_ERR_STATE, "mha_workset_compute_solution before mha_workset_update");
+  bindState(u, u_prev, u_stage);
+  static const char *xyz[3] = {"[x]", "[y]", "[z]"};
+  const size_t cnt = static_cast<size_t>(std::max(wkset_.maxElem, wkset_.numElem)) * nq_;
+  auto buf = [&](const std::string &nm) {
+    DeviceBuffer<double> &b = ws_fields_[nm];
+    if (b.size() < cnt) b.resize(cnt);
+    return b.data();
+  };
+  for (int v = 0; v < static_cast<int>(vars_.size()); ++v) {
+    const VarInfo &vi = vars_[v];
+    const std::string var = varName(v);
+    const double *b, *g, *d;
+    worksetVarArrays(v, &b, &g, &d);
+    VarFieldsDev out;
+    if (vi.type == MHA_BASIS_HDIV) {
+      for (int c = 0; c < dim_; ++c) { out.val[c] = buf(var + xyz[c]); out.dot[c] = buf(var + "_t" + xyz[c]); }
+      out.div = buf("div(" + var + ")");
+    } else {
+      out.val[0] = buf(var);
+      out.dot[0] = buf(var + "_t");
+      if (vi.type == MHA_BASIS_HGRAD)
+        for (int c = 0; c < dim_; ++c) out.grad[c] = buf("grad(" + var + ")" + xyz[c]);
+    }
+    launch_var_fields(blockDev(), time_, wkset_.first_elem, wkset_.numElem, vi.card, layout_.varptr[v], nq_, varComps(v),
+                      b, vi.type == MHA_BASIS_HGRAD ? g : nullptr, vi.type == MHA_BASIS_HDIV ? d : nullptr, out, stream_);
+  }
+  ws_fields_first_ = wkset_.first_elem;
+}
+
+void AssemblyManager::worksetComputeResidual(int compute_jacobian, const double *u, const double *u_prev,
+                                             const double *u_stage) {
+  requireReady(false);
+  MHA_REQUIRE(physics_ != nullptr, MHA_ERR_STATE, "no physics module: call mha_physics_select first");
+  bindState(u, u_prev, u_stage);
+  const int e0 = wkset_.first_elem, ne = wkset_.numElem;
+  MHA_REQUIRE(ne > 0 && e0 + ne <= nelem_, MHA_ERR_STATE, "mha_workset_compute_residual before mha_workset_update");
+  const size_t cap = static_cast<size_t>(std::max(wkset_.maxElem, ne));
+  if (ws_res_.size() < cap * n_) ws_res_.resize(cap * n_);
+  if (compute_jacobian && ws_res_dx_.size() < cap * n_ * n_) ws_res_dx_.resize(cap * n_ * n_);
+  // Workset::resetResidual (workset.cpp:449-459)
+  MHA_HIP(hipMemsetAsync(ws_res_.data(), 0, sizeof(double) * ne * n_, stream_));
+  if (compute_jacobian) MHA_HIP(hipMemsetAsync(ws_res_dx_.data(), 0, sizeof(double) * ne * n_ * n_, stream_));
+  wkset_.res = ElemOut();
+  wkset_.res.compute_jacobian = compute_jacobian ? 1 : 0;
+  wkset_.res.local_base = e0;
+  wkset_.res.local_J = compute_jacobian ? ws_res_dx_.data() : nullptr;
+  wkset_.res.local_res = ws_res_.data();
+  if (engineOnly()) {
+    launchPointEngine(compute_jacobian, wkset_.res, e0, ne);
+  } else {
+    wkset_.use_general = false;
+    physics_->volumeResidual();
+  }
+  // the element kernels follow updateRes (local_res -= res.val()); the view holds res.val()
+  launch_negate(ws_res_.data(), static_cast<size_t>(ne) * n_, stream_);
+  ws_res_first_ = e0;
+  ws_res_num_ = ne;
+  ws_res_has_dx_ = compute_jacobian != 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -713,6 +910,33 @@ int AssemblyManager::addBoundaryGroup(const std::string &sidename, int bc_type, 
   return static_cast<int>(boundary_groups_.size()) - 1;
 }
 
+// reference: wkset->var_bcs(var, side) == "Flux" for `varname` on this side set (physicsInterface.cpp:1705-1712); the data
+// is the function "Flux <var> <sidename>"
+int AssemblyManager::addFluxGroup(const std::string &sidename, const std::string &varname, int num, const int32_t *elem_ids,
+                                  const int32_t *side_ids) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  const int var = varIndex(varname);
+  MHA_REQUIRE(var >= 0, MHA_ERR_INVALID, "the block has no variable named '" << varname << "'");
+  MHA_REQUIRE(num >= 0 && (num == 0 || (elem_ids && side_ids)), MHA_ERR_INVALID, "bad boundary entry arrays");
+  MHA_REQUIRE(!sidename.empty(), MHA_ERR_INVALID, "side name is empty");
+  prepareSideTables();
+  for (int k = 0; k < num; ++k) {
+    MHA_REQUIRE(elem_ids[k] >= 0 && elem_ids[k] < nelem_, MHA_ERR_INVALID,
+                "boundary entry " << k << ": element id " << elem_ids[k] << " out of range");
+    MHA_REQUIRE(side_ids[k] >= 0 && side_ids[k] < side_ref_.nsides, MHA_ERR_INVALID,
+                "boundary entry " << k << ": local side id " << side_ids[k] << " out of range");
+  }
+  std::unique_ptr<BoundaryGroupData> g(new BoundaryGroupData());
+  g->sidename = sidename;
+  g->bc_type = MHA_BC_FLUX;
+  g->var = var;
+  g->num = num;
+  g->elem.upload(elem_ids, num);
+  g->side.upload(side_ids, num);
+  boundary_groups_.push_back(std::move(g));
+  return static_cast<int>(boundary_groups_.size()) - 1;
+}
+
 // reference: the boundary-group loop of assembleJacRes (assemblyManager.cpp:2518-2638): per group
 // updateWorksetBoundary, performBoundaryGather, physics boundaryResidual, scatter.  Accumulates.
 void AssemblyManager::assembleBoundary(int flags, const double *u, const double *u_prev, const double *u_stage,
@@ -725,7 +949,20 @@ void AssemblyManager::assembleBoundary(int flags, const double *u, const double 
   MHA_REQUIRE(!compute_jacobian || crs_vals, MHA_ERR_INVALID, "compute_jacobian set but crs_vals is null");
   bindState(u, u_prev, u_stage);
   timedBegin();
-  for (const auto &g : boundary_groups_) {
+  for (size_t gi = 0; gi < boundary_groups_.size(); ++gi) {
+    const auto &g = boundary_groups_[gi];
+    if (g->bc_type == MHA_BC_FLUX) {
+      // PhysicsInterface::fluxConditions (physicsInterface.cpp:1702-1762): reads the group's stored side views
+      if (!g->has_views) boundaryUpdate(static_cast<int>(gi));
+      const VarInfo &vi = vars_[g->var];
+      const FuncDesc flux = functions_.evaluate("Flux " + varName(g->var) + " " + g->sidename);
+      const double *basis = single_hgrad_ ? g->basis.data() : g->var_views[g->var].basis.data();
+      const double *xyz[3] = {g->xyz[0].data(), g->xyz[1].data(), g->xyz[2].data()};
+      const double *nrm[3] = {g->nrm[0].data(), g->nrm[1].data(), g->nrm[2].data()};
+      launch_flux_condition(blockDev(), flux, g->elem.data(), g->num, vi.card, layout_.varptr[g->var], side_ref_.nqs,
+                            varComps(g->var), g->wts.data(), xyz, nrm, basis, res, stream_);
+      continue;
+    }
     wkset_.sidename = g->sidename;
     wkset_.current_bc = g->bc_type;
     wkset_.bnd = boundaryDev(*g);
@@ -760,6 +997,21 @@ void AssemblyManager::boundaryUpdate(int group) {
   v.basis = g.basis.data();
   v.basis_grad = g.basis_grad.data();
   launch_boundary_views(blockDev(), sideTablesDev(), boundaryDev(g), v, stream_);
+  if (!single_hgrad_) {
+    // getPhysicalBoundaryBasis for every basis of the block (discretizationInterface.cpp:1840-1950)
+    g.var_views.resize(vars_.size());
+    for (size_t k = 0; k < vars_.size(); ++k) {
+      const VarInfo &vi = vars_[k];
+      VarViews &vv = g.var_views[k];
+      vv.basis.resize(num * vi.card * nqs * varComps(static_cast<int>(k)));
+      if (vi.type == MHA_BASIS_HGRAD) vv.grad.resize(num * vi.card * nqs * dim_);
+      VarViewsDev out;
+      out.basis = vv.basis.data();
+      out.grad = vv.grad.data();
+      launch_var_views(blockDev(), varPoints(static_cast<int>(k), true), g.elem.data(), g.side.data(), 0, g.num, out,
+                       stream_);
+    }
+  }
   g.has_views = true;
 }
 
@@ -780,8 +1032,19 @@ View AssemblyManager::boundaryView(int group, const std::string &name) const {
     v.ptr = g.xyz[comp(name[0])].data(); v.rank = 2; v.extent[0] = num; v.extent[1] = nqs;
   } else if (name == "n[x]" || name == "n[y]" || name == "n[z]") {
     v.ptr = g.nrm[comp(name[2])].data(); v.rank = 2; v.extent[0] = num; v.extent[1] = nqs;
+  } else if (name.compare(0, 11, "basis side ") == 0 || name.compare(0, 16, "basis_grad side ") == 0) {
+    // getBasisSide(var) / getBasisGradSide(var) (workset.hpp:281-293)
+    const bool grad = name[5] == '_';
+    const int k = varIndex(name.substr(grad ? 16 : 11));
+    if (k < 0) throw Error(MHA_ERR_UNKNOWN_FIELD, "unknown variable in boundary view '" + name + "'");
+    const VarInfo &vi = vars_[k];
+    const double *p = single_hgrad_ ? (grad ? g.basis_grad.data() : g.basis.data())
+                                    : (grad ? g.var_views[k].grad.data() : g.var_views[k].basis.data());
+    if (!p) throw Error(MHA_ERR_UNKNOWN_FIELD, "'" + name + "' is not defined for this basis type");
+    v.ptr = const_cast<double *>(p); v.rank = 4; v.extent[0] = num; v.extent[1] = vi.card; v.extent[2] = nqs;
+    v.extent[3] = grad ? dim_ : varComps(k);
   } else if ((name == "basis side" || name == "basis_grad side") && !single_hgrad_) {
-    throw Error(MHA_ERR_UNKNOWN_FIELD, "'" + name + "' is available for single-variable HGRAD blocks");
+    throw Error(MHA_ERR_UNKNOWN_FIELD, "'" + name + "' needs the variable's name on a multi-variable block: '" + name + " <var>'");
   } else if (name == "basis side") {
     v.ptr = g.basis.data(); v.rank = 4; v.extent[0] = num; v.extent[1] = n_; v.extent[2] = nqs; v.extent[3] = 1;
   } else if (name == "basis_grad side") {

@@ -5,6 +5,7 @@
 // owns the block's mesh/map copies on the device, the reference tables, the physics module, the
 // function table and the workset; assembleJacRes drives gather -> residual/Jacobian -> scatter.
 #pragma once
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -24,6 +25,8 @@ class AssemblyManager {
   ~AssemblyManager();
 
   void setStream(hipStream_t s) { stream_ = s; wkset_.stream = s; }
+  // modules whose volume term only exists as a point function (multi-variable blocks; thermal with advection)
+  bool engineOnly() const { return physics_id_ != MHA_PHYSICS_THERMAL || (physics_ && physics_->pointEngineOnly()); }
   void setMesh(int nelem, const double *nodes, const int32_t *lids, const int32_t *offsets, int nrows,
                const uint8_t *fixed);
   void setOrientation(const int8_t *signs);
@@ -46,6 +49,9 @@ class AssemblyManager {
   // boundary groups (reference: src/tools/boundaryGroup.hpp, assemblyManager.cpp:2518-2638)
   int addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,
                        const int32_t *side_ids);
+  // "Flux" condition of one variable on a side set (PhysicsInterface::fluxConditions, physicsInterface.cpp:1702-1762)
+  int addFluxGroup(const std::string &sidename, const std::string &varname, int num, const int32_t *elem_ids,
+                   const int32_t *side_ids);
   void clearBoundaryGroups() { boundary_groups_.clear(); }
   int numBoundaryGroups() const { return static_cast<int>(boundary_groups_.size()); }
   void assembleBoundary(int flags, const double *u, const double *u_prev, const double *u_stage, double *res,
@@ -58,7 +64,11 @@ class AssemblyManager {
 
   int numWorksets() const;
   void worksetUpdate(int index);
-  View worksetView(const std::string &name) const { return wkset_.get(name); }
+  View worksetView(const std::string &name) const;
+  // Workset::computeSoln for the current workset (workset.cpp:1017-1190): fills the solution-field views
+  void worksetComputeSolution(const double *u, const double *u_prev, const double *u_stage);
+  // resetResidual + volumeResidual on the current workset: fills the "res" / "res.dx" views (Workset::getResidual)
+  void worksetComputeResidual(int compute_jacobian, const double *u, const double *u_prev, const double *u_stage);
 
   int64_t info(const std::string &key) const;
   void setTiming(bool on) { timing_ = on; }
@@ -154,12 +164,31 @@ class AssemblyManager {
   } bpat_;
   void prepareBlockPattern();
 
+  // per-variable views (multi-variable blocks): reference tables at the volume / side points, physical basis arrays
+  struct VarTables { DeviceBuffer<double> val, grad, div; bool ready = false; };
+  struct VarViews { DeviceBuffer<double> basis, grad, div; };
+  std::vector<VarTables> var_vol_tables_, var_side_tables_;
+  std::vector<VarViews> ws_var_views_;
+  std::map<std::string, DeviceBuffer<double>> ws_fields_;  // solution fields of the current workset, by reference name
+  int ws_fields_first_ = -1;
+  DeviceBuffer<double> ws_res_, ws_res_dx_;
+  int ws_res_first_ = -1, ws_res_num_ = 0;
+  bool ws_res_has_dx_ = false;
+  int varIndex(const std::string &name) const;
+  std::string varName(int v) const;
+  int varComps(int v) const { return vars_[v].type == MHA_BASIS_HDIV ? dim_ : 1; }
+  VarPointsDev varPoints(int v, bool side);
+  // basis arrays of variable v on the current workset (aliases the single-variable views of the workset)
+  void worksetVarArrays(int v, const double **basis, const double **grad, const double **div) const;
+
   // host mirror of BoundaryGroup: entries + the side views evaluated on request
   struct BoundaryGroupData {
     std::string sidename;
     int bc_type = 0, num = 0;
+    int var = -1;  // MHA_BC_FLUX: the variable the condition is for
     DeviceBuffer<int32_t> elem, side;
     DeviceBuffer<double> wts, xyz[3], nrm[3], basis, basis_grad;
+    std::vector<VarViews> var_views;  // multi-variable blocks: "basis side <var>", "basis_grad side <var>"
     bool has_views = false;
   };
   std::vector<std::unique_ptr<BoundaryGroupData>> boundary_groups_;

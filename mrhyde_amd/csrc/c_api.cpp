@@ -225,6 +225,23 @@ int mha_add_boundary_group(mha_context *ctx, const char *sidename, int bc_type, 
   });
 }
 
+int mha_add_flux_group(mha_context *ctx, const char *sidename, const char *varname, int num_sides,
+                       const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id) {
+  return guarded([&] {
+    MHA_REQUIRE(sidename && varname && group_id, MHA_ERR_INVALID, "null argument");
+    *group_id = mgr(ctx).addFluxGroup(sidename, varname, num_sides, elem_ids_host, local_side_ids_host);
+  });
+}
+
+int mha_workset_compute_solution(mha_context *ctx, const double *u, const double *u_prev, const double *u_stage) {
+  return guarded([&] { mgr(ctx).worksetComputeSolution(u, u_prev, u_stage); });
+}
+
+int mha_workset_compute_residual(mha_context *ctx, int compute_jacobian, const double *u, const double *u_prev,
+                                 const double *u_stage) {
+  return guarded([&] { mgr(ctx).worksetComputeResidual(compute_jacobian, u, u_prev, u_stage); });
+}
+
 int mha_clear_boundary_groups(mha_context *ctx) {
   return guarded([&] { mgr(ctx).clearBoundaryGroups(); });
 }

@@ -158,6 +158,28 @@ struct VarLayoutDev {
   const int8_t *orient = nullptr;       // [E][n_tot] basis signs (modifyBasisByOrientation, lowest order) or null
 };
 
+// Reference values of ONE variable's basis at sets of points (kernels/var_views.hip): the volume integration points
+// (one set) or the side integration points (one set per local side).
+struct VarPointsDev {
+  int type = 0, card = 0, npts = 0;
+  const double *val = nullptr;       // [set][card][npts][ncomp], ncomp = dim for HDIV, 1 otherwise
+  const double *grad = nullptr;      // [set][card][npts][dim]   (HGRAD)
+  const double *div = nullptr;       // [set][card][npts]        (HDIV)
+  const double *nodegrad = nullptr;  // [set][nnodes][npts][dim] geometry basis gradients at the points
+  const int8_t *orient = nullptr;    // [E][n_tot] basis signs or null
+  int n_tot = 0, var_off = 0;        // dofs per element of the block; first dof of the variable
+};
+struct VarViewsDev {
+  double *basis = nullptr;  // [num][card][npts][ncomp]
+  double *grad = nullptr;   // [num][card][npts][dim]
+  double *div = nullptr;    // [num][card][npts]
+};
+// solution fields of one variable at the points ([num][npts] each): value components, time derivative, gradient, divergence
+struct VarFieldsDev {
+  double *val[3] = {nullptr, nullptr, nullptr}, *dot[3] = {nullptr, nullptr, nullptr};
+  double *grad[3] = {nullptr, nullptr, nullptr}, *div = nullptr;
+};
+
 // What a physics module's point function reads besides the fields: its named functions and scalar settings.
 struct PhysParamsDev {
   int physics = 0;
@@ -170,6 +192,9 @@ struct RowGatherDev {
   const int32_t *inc_ptr = nullptr, *inc_elem = nullptr, *inc_pos = nullptr;
   const void *slot = nullptr;
   int slot_bytes = 1, max_row = 0;
+  // scatter options of the reference (assemblyManager.cpp:4124-4133): isAdjoint_ takes res(row).dx(row) for every column
+  // of the row; lump_mass_ sends every column's value to the diagonal entry (cols[col] = rowIndex)
+  int adjoint = 0, lump_mass = 0;
 };
 
 // shallowwaterHybridized side terms at npts side integration points (kernels/swhdg_side.hip); state order H, Hux, Huy

@@ -27,6 +27,18 @@ struct WorksetViewsDev {
 };
 void launch_workset_views(const BlockDev &b, int e0, int ne, const WorksetViewsDev &v, hipStream_t stream);
 
+// var_views.hip: per-variable basis views (volume range e0.. when elem == null, else boundary entries), solution
+// fields of the current workset, PhysicsInterface::fluxConditions, and a[i] = -a[i]
+void launch_var_views(const BlockDev &b, const VarPointsDev &t, const int32_t *elem, const int32_t *side, int e0, int num,
+                      const VarViewsDev &out, hipStream_t stream);
+void launch_var_fields(const BlockDev &b, const TimeDev &tm, int e0, int num, int card, int var_off, int npts, int ncomp,
+                       const double *basis, const double *grad, const double *div, const VarFieldsDev &out,
+                       hipStream_t stream);
+void launch_flux_condition(const BlockDev &b, const FuncDesc &flux, const int32_t *elem, int num, int card, int var_off,
+                           int nqs, int ncomp, const double *wts, const double *const xyz[3], const double *const nrm[3],
+                           const double *basis, double *res, hipStream_t stream);
+void launch_negate(double *a, size_t n, hipStream_t stream);
+
 // thermal_row_owner.hip
 void launch_classify_affine(const BlockDev &b, uint8_t *flags, double tol, hipStream_t stream);
 void launch_build_block_slots(const BlockDev &b, const RowBlocksDev &rb, void *bslot, int slot_bytes,

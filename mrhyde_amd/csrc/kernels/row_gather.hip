@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
           int e = __shfl(e_cur, k & (LPR - 1), LPR), pos = __shfl(p_cur, k & (LPR - 1), LPR);
           if (valid) {
             if (k >= LPR) { e = g.inc_elem[i0 + k]; pos = g.inc_pos[i0 + k]; }
-            const size_t off = ((size_t)e * n + pos) * n + sj;
-            unsafeAtomicAdd(acc + slot[off], local_J[off]);
+            const size_t off = ((size_t)e * n + pos) * n + sj, offd = ((size_t)e * n + pos) * n + pos;
+            // isAdjoint_: vals[col] = res(elem,row).fastAccessDx(row) for every col; lump_mass_: cols[col] = rowIndex
+            unsafeAtomicAdd(acc + slot[g.lump_mass ? offd : off], local_J[g.adjoint ? offd : off]);
           }
         }
         wave_lds_sync();

@@ -51,6 +51,8 @@ class PhysicsBase {
   virtual void faceResidual() { notImplemented("faceResidual"); }
   virtual void computeFlux() { notImplemented("computeFlux"); }
   virtual void setWorkset(Workset *w) { wkset = w; }
+  // true when the current settings need terms only the point-engine form of the module has
+  virtual bool pointEngineOnly() const { return false; }
   // scalar settings a module reads from its parameter list in the reference constructor
   virtual void setParameter(const std::string &name, double) {
     throw Error(MHA_ERR_INVALID, "physics module '" + label + "' has no parameter '" + name + "'");
@@ -79,6 +81,8 @@ class thermal : public PhysicsBase {
   void setParameter(const std::string &name, double value) override;
   ThermalDev device_params() const;
   double formparam = 1.0;  // settings "form_param" (reference: thermal.cpp:35)
+  bool have_advection = false;  // settings "include advection" (reference: thermal.cpp:39): adds (b . grad e, v)
+  bool pointEngineOnly() const override { return have_advection; }
 };
 
 // porousMixed: mixed Darcy, (K mobility)^-1 u + grad p = 0, div u = source

@@ -207,4 +207,48 @@ SideTables make_side_tables(const RefTables &ref) {
   return t;
 }
 
+int ref_basis_var(int dim, int type, int order, int npts, const double *x, std::vector<double> &val,
+                  std::vector<double> &grad, std::vector<double> &div) {
+  val.clear();
+  grad.clear();
+  div.clear();
+  if (type == MHA_BASIS_HVOL) {
+    val.assign(npts, 1.0);
+    return 1;
+  }
+  if (type == MHA_BASIS_HDIV) {
+    const int card = 2 * dim;
+    val.assign(static_cast<size_t>(card) * npts * dim, 0.0);
+    div.assign(static_cast<size_t>(card) * npts, 0.0);
+    for (int c = 0; c < dim; ++c)
+      for (int sd = 0; sd < 2; ++sd)
+        for (int q = 0; q < npts; ++q) {
+          const double xc = x[q * dim + c];
+          val[(static_cast<size_t>(2 * c + sd) * npts + q) * dim + c] = sd ? 0.5 * (1.0 + xc) : 0.5 * (1.0 - xc);
+          div[static_cast<size_t>(2 * c + sd) * npts + q] = sd ? 0.5 : -0.5;
+        }
+    return card;
+  }
+  MHA_REQUIRE(type == MHA_BASIS_HGRAD && order >= 1 && order <= 8, MHA_ERR_INVALID, "unsupported basis (type " << type << ", order " << order << ")");
+  const int m = order + 1, card = ipow(m, dim);
+  val.assign(static_cast<size_t>(card) * npts, 0.0);
+  grad.assign(static_cast<size_t>(card) * npts * dim, 0.0);
+  std::vector<double> bv(3 * m), bd(3 * m);
+  for (int q = 0; q < npts; ++q) {
+    for (int d = 0; d < dim; ++d) lagrange_equispaced(order, x[q * dim + d], &bv[d * m], &bd[d * m]);
+    for (int f = 0; f < card; ++f) {
+      const int fi[3] = {f % m, (f / m) % m, f / (m * m)};
+      double v = 1.0;
+      for (int d = 0; d < dim; ++d) v *= bv[d * m + fi[d]];
+      val[static_cast<size_t>(f) * npts + q] = v;
+      for (int d = 0; d < dim; ++d) {
+        double g = 1.0;
+        for (int e = 0; e < dim; ++e) g *= (e == d) ? bd[e * m + fi[e]] : bv[e * m + fi[e]];
+        grad[(static_cast<size_t>(f) * npts + q) * dim + d] = g;
+      }
+    }
+  }
+  return card;
+}
+
 }  // namespace mha

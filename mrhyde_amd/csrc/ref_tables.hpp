@@ -42,6 +42,13 @@ void gauss_legendre_descending(int n, std::vector<double> &pts, std::vector<doub
 void lagrange_equispaced(int order, double x, double *val, double *der);
 RefTables make_ref_tables(int dim, int order, int quad_degree);
 SideTables make_side_tables(const RefTables &ref);
+// Reference values of one variable's basis at npts points x[npts][dim] of the reference cell (what Basis::getValues
+// returns for OPERATOR_VALUE / GRAD / DIV): type MHA_BASIS_HGRAD (tensor Lagrange of `order`), _HVOL (constant 1),
+// _HDIV (lowest order, raw In_FEM functions: dof 2c = (1-x_c)/2 e_c, dof 2c+1 = (1+x_c)/2 e_c).
+// val[card][npts][ncomp] (ncomp = dim for HDIV, else 1), grad[card][npts][dim] (HGRAD), div[card][npts] (HDIV);
+// arrays a type does not define are left empty.  Returns the cardinality.
+int ref_basis_var(int dim, int type, int order, int npts, const double *x, std::vector<double> &val,
+                  std::vector<double> &grad, std::vector<double> &div);
 // sign (+1/-1) of reference vertex v of the cell topology in direction d (shards order)
 double ref_vertex_sign(int dim, int v, int d);
 

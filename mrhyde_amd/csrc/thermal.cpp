@@ -37,10 +37,13 @@ void thermal::defineFunctions(FunctionManager &fm) {
   if (!fm.has("thermal diffusion")) fm.addFunction("thermal diffusion", constant(1.0));
   if (!fm.has("specific heat")) fm.addFunction("specific heat", constant(1.0));
   if (!fm.has("density")) fm.addFunction("density", constant(1.0));
+  for (const char *k : {"bx", "by", "bz"})  // "advection x|y|z", default 0 (thermal.cpp:59-61)
+    if (!fm.has(k)) fm.addFunction(k, constant(0.0));
 }
 
 void thermal::setParameter(const std::string &name, double value) {
   if (name == "form_param") formparam = value;  // reference: thermal.cpp:35
+  else if (name == "include advection") have_advection = value != 0.0;  // reference: thermal.cpp:39
   else PhysicsBase::setParameter(name, value);
 }
 
@@ -69,7 +72,15 @@ void thermal::volumeResidual() {
     pp.f[1] = functionManager->evaluate("thermal diffusion");
     pp.f[2] = functionManager->evaluate("specific heat");
     pp.f[3] = functionManager->evaluate("density");
+    // (b . grad e, v) with b = ("bx","by","bz") at the points (thermal.cpp:150-160)
+    pp.p[0] = have_advection ? 1.0 : 0.0;
+    if (have_advection) {
+      const char *bn[3] = {"bx", "by", "bz"};
+      for (int d = 0; d < w.dimension; ++d) pp.f[4 + d] = functionManager->evaluate(bn[d]);
+    }
     launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
+  } else if (have_advection) {
+    throw Error(MHA_ERR_INVALID, "thermal with 'include advection' runs on the point engine (MHA_PATH_AUTO / _ROW_GATHER / _POINT_ENGINE)");
   } else if (w.use_general)
     launch_thermal_general(w.dimension, w.order, w.nq1, b, device_params(), w.tables, w.elem_slot, w.elem_slot_bytes,
                            w.res, w.stream);

@@ -463,6 +463,13 @@ int orc_assemble_thermal(const orc_thermal_args *a) {
               const double bg = a->basis_grad[((e * n + dof) * nq + pt) * dim + d];
               for (int k = 0; k < W1; ++k) r[k] += kap * g[k] * w * bg;
             }
+            if (a->have_advection) { /* thermal.cpp:150-160 */
+              for (int d = 0; d < dim; ++d) {
+                const double *g = fld + (size_t)(2 + d) * ws * nq * W1 + ((size_t)el * nq + pt) * W1;
+                const double b = a->adv_ip ? a->adv_ip[(e * nq + pt) * dim + d] : a->adv[d];
+                for (int k = 0; k < W1; ++k) r[k] += b * g[k] * w * bv;
+              }
+            }
           }
         }
       }

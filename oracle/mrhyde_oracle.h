@@ -106,6 +106,12 @@ typedef struct orc_thermal_args {
   double *res;                  /* [nrows], receives -res.val(); may be NULL */
   double *local_J;              /* [E][n][n] updateJac convention, or NULL   */
   double *local_res;            /* [E][n]   updateRes convention, or NULL    */
+  /* settings "include advection" (thermal.cpp:39): (b . grad e, v) with the
+   * functions "bx","by","bz" (thermal.cpp:59-61, 150-160); adv_ip != NULL
+   * overrides the constants                                                  */
+  int have_advection;
+  double adv[3];
+  const double *adv_ip;         /* [E][q][dim] or NULL                       */
 } orc_thermal_args;
 
 int orc_ad_width(int n);
@@ -300,6 +306,12 @@ void orc_swh_interface_flux(int dim, int side_type, int roe, const double *S, co
  * Uses dim (2), qdeg, orders, nelem, nodes, lids, offsets, u, the time-integration data and params {g, Roe} of `a`. */
 int orc_swh_hdg_element(const orc_block_args *a, const double *lambda, const unsigned char *side_types,
                         const double *farfield, double *blocks, double *res);
+/* PhysicsInterface::fluxConditions (physicsInterface.cpp:1702-1762) + scatterRes for one variable of a boundary group:
+ * res[LIDs(elem, off(dof))] -= sum_pt -flux(k,pt) wts(k,pt) basis(k,dof,pt,0); flux[nb][nqs], wts[nb][nqs],
+ * basis[nb][card][nqs][ncomp], off[card], fixed rows skipped                                                  */
+int orc_flux_condition(int nb, int card, int nqs, int ncomp, const int *belem, const int *lids, int n_tot,
+                       const int *off, const unsigned char *fixed, const double *flux, const double *wts,
+                       const double *basis, double *res);
 
 #ifdef __cplusplus
 }

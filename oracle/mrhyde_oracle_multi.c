@@ -1046,3 +1046,30 @@ int orc_swh_hdg_element(const orc_block_args *a, const double *lambda, const uns
   ctx_free(&c);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* PhysicsInterface::fluxConditions (physicsInterface.cpp:1702-1762)         */
+/* ------------------------------------------------------------------------ */
+
+/* One variable with bctype "Flux" on the sides of a boundary group:
+ *   res(elem, off(dof)) += -fluxvals(elem,pt) * wts(elem,pt) * basis(elem,dof,pt,0)      (:1727-1733)
+ * followed by scatterRes (assemblyManager.cpp:3943-3978): the global vector receives -res.val() at
+ * LIDs(elem, off(dof)), fixed rows skipped.  flux[nb][nqs], wts[nb][nqs], basis[nb][card][nqs][ncomp] are the
+ * group's stored side views (wts_side, getBasisSide(var)); off[card] = offsets of the variable.          */
+int orc_flux_condition(int nb, int card, int nqs, int ncomp, const int *belem, const int *lids, int n_tot,
+                       const int *off, const unsigned char *fixed, const double *flux, const double *wts,
+                       const double *basis, double *res) {
+  if (nb < 0 || card <= 0 || nqs <= 0 || ncomp <= 0) return -1;
+  for (int k = 0; k < nb; ++k) {
+    const int *L = lids + (size_t)belem[k] * n_tot;
+    for (int dof = 0; dof < card; ++dof) {
+      double r = 0.0; /* res(elem, off(dof)).val() */
+      for (int pt = 0; pt < nqs; ++pt)
+        r += -flux[(size_t)k * nqs + pt] * wts[(size_t)k * nqs + pt] * basis[(((size_t)k * card + dof) * nqs + pt) * ncomp];
+      const int row = L[off[dof]];
+      if (fixed && fixed[row]) continue;
+      res[row] -= r;
+    }
+  }
+  return 0;
+}

@@ -34,6 +34,7 @@ class ThermalArgs(C.Structure):
         ("compute_jacobian", C.c_int), ("num_threads", C.c_int),
         ("rowptr", _ip), ("colind", _ip),
         ("crs_vals", _dp), ("res", _dp), ("local_J", _dp), ("local_res", _dp),
+        ("have_advection", C.c_int), ("adv", C.c_double * 3), ("adv_ip", _dp),
     ]
 
 
@@ -139,7 +140,7 @@ def ad_width(n):
 def assemble_thermal(dim, order, qdeg, nodes, lids, offsets, u, *, nrows=None, fixed=None, pb=None,
                      workset_size=100, transient=None, diff=1.0, rho=1.0, cp=1.0, diff_ip=None,
                      source=("const", 0.0), compute_jacobian=True, num_threads=1,
-                     rowptr=None, colind=None, want_crs=True, want_res=True, want_local=False):
+                     rowptr=None, colind=None, want_crs=True, want_res=True, want_local=False, advection=None):
     """Run the oracle's assembleJacRes restatement.  Returns dict with crs_vals/res/local_J/local_res."""
     nodes = np.ascontiguousarray(nodes, dtype=np.float64)
     lids = np.ascontiguousarray(lids, dtype=np.int32)
@@ -187,6 +188,15 @@ def assemble_thermal(dim, order, qdeg, nodes, lids, offsets, u, *, nrows=None, f
     else:
         raise ValueError(kind)
     a.compute_jacobian, a.num_threads = int(compute_jacobian), num_threads
+    if advection is not None:      # "include advection": constants (bx, by, bz) or an [E][q][dim] array
+        a.have_advection = 1
+        if isinstance(advection, np.ndarray) and advection.ndim == 3:
+            adv = np.ascontiguousarray(advection, dtype=np.float64)
+            keep.append(adv)
+            a.adv_ip = _d(adv)
+        else:
+            bb = list(advection) + [0.0] * (3 - len(advection))
+            a.adv = (C.c_double * 3)(*bb)
     out = {}
     if want_crs or want_res:
         if rowptr is None:
@@ -583,6 +593,20 @@ def physical_side_basis_hdiv(dim, qdeg, nodes, belem, bside, orient=None):
                                             _d(out))
     assert rc == 0, rc
     return out
+
+
+def flux_condition(belem, lids, off, flux, wts, basis, res, fixed=None):
+    """PhysicsInterface::fluxConditions + scatterRes for one variable; basis[nb][card][nqs][ncomp]; accumulates into res."""
+    belem = np.ascontiguousarray(belem, dtype=np.int32)
+    lids = np.ascontiguousarray(lids, dtype=np.int32)
+    off = np.ascontiguousarray(off, dtype=np.int32)
+    flux, wts = np.ascontiguousarray(flux, dtype=np.float64), np.ascontiguousarray(wts, dtype=np.float64)
+    basis = np.ascontiguousarray(basis, dtype=np.float64)
+    nb, card, nqs, ncomp = basis.shape
+    fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8)
+    rc = lib().orc_flux_condition(nb, card, nqs, ncomp, _i(belem), _i(lids), lids.shape[1], _i(off),
+                                  None if fx is None else _u(fx), _d(flux), _d(wts), _d(basis), _d(res))
+    assert rc == 0, rc
 
 
 # ---- shallowwaterHybridized, point level ---------------------------------------------------------------------------

@@ -257,6 +257,61 @@ def affine_mesh(oracle, dim, order, ncell, shear=True):
     return m
 
 
+@pytest.mark.parametrize("adjoint,lump", [(True, False), (False, True), (True, True)])
+def test_scatter_options_adjoint_and_lumped_mass(oracle, adjoint, lump):
+    """The scatter options of AssemblyManager::scatter (assemblyManager.cpp:4124-4133), as the reference has them:
+    isAdjoint_ -> every column of a row gets res(elem,row).fastAccessDx(row); lump_mass_ -> cols[col] = rowIndex (all of
+    a row's element contributions land on its diagonal).  Reference: the ORACLE's element Jacobians scattered with that
+    rule in numpy; fixed rows skipped."""
+    torch = _torch()
+    import mrhyde_amd
+    dim, order, qdeg, ncell = 3, 2, 4, (3, 2, 2)
+    m = perturbed(oracle, dim, order, ncell, seed=21)
+    rng = np.random.default_rng(8)
+    nd = m["ndof"]
+    u = rng.uniform(-1, 1, nd)
+    fixed = m["boundary"]
+    # transient: lumping a pure stiffness matrix gives row sums of zero (roundoff only); the mass term is what gets lumped
+    nsteps, nstages, stage = 1, 1, 0
+    A, b, bdf = np.array([[1.0]]), np.array([1.0]), np.array([1.0, -1.0])
+    tr = dict(u_prev=rng.uniform(-1, 1, (nd, nsteps)), u_stage=rng.uniform(-1, 1, (nd, nstages)), stage=stage,
+              butcher_A=A, butcher_b=b, bdf=bdf, dt=0.05)
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed, transient=tr,
+                                  rho=1.3, cp=0.7, source=("const", 0.5), diff=1.1, want_local=True)
+    rowptr, colind = ref["rowptr"], ref["colind"]
+    expect = np.zeros(len(colind))
+    n = m["lids"].shape[1]
+    for e, L in enumerate(m["lids"]):
+        Je = ref["local_J"][e]                      # [n][n] in LID-position order (updateJac convention)
+        for i in range(n):
+            r = L[i]
+            if fixed[r]:
+                continue
+            lo, hi = rowptr[r], rowptr[r + 1]
+            for j in range(n):
+                v = Je[i, i] if adjoint else Je[i, j]
+                c = r if lump else L[j]
+                expect[lo + np.searchsorted(colind[lo:hi], c)] += v
+    blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(rowptr, colind))
+    blk.set_function("thermal source", 0.5)
+    blk.set_function("thermal diffusion", 1.1)
+    blk.set_function("density", 1.3)
+    blk.set_function("specific heat", 0.7)
+    blk.set_time_integration(True, nsteps, nstages, stage, 0.05, A, b, bdf)
+    t = lambda a: torch.tensor(a, device="cuda")
+    res = torch.zeros(nd, dtype=torch.float64, device="cuda")
+    vals = torch.full((len(colind),), 9.0, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(t(u), res, vals, u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]), overwrite=True, adjoint=adjoint,
+                        lump_mass=lump)
+    torch.cuda.synchronize()
+    assert blk.info("last_path") == mrhyde_amd.PATH_ROW_GATHER
+    assert rel_err(vals.cpu().numpy(), expect) < RTOL
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL      # the residual does not depend on the options
+    with pytest.raises(mrhyde_amd.MhaError):
+        blk.assemble_jacres(t(u), res, vals, u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]),
+                            path=mrhyde_amd.PATH_ELEMENT_ATOMIC, adjoint=True)
+
+
 def test_caller_graph_is_validated(oracle):
     """A caller-supplied CRS graph that lacks an element coupling (or is unsorted) is an input error at mha_set_graph /
     mha_scatter_plan_create: the device slot maps are built by a column search and a missing column has no slot."""
