@@ -180,3 +180,54 @@ def test_navierstokes_jacobian_is_derivative_of_residual(oracle):
             assert np.all(q["res"][uz_rows] == 0.0)
             f = oracle.assemble_block(m, oracle.PHYS_NAVIERSTOKES, 4, u, funcs=funcs, params=[0, 0, 1])
             assert np.abs(f["res"][uz_rows]).max() > 0
+
+
+def test_thermal_advection_term_of_the_oracle(oracle):
+    """Pins the advection restatement (thermal.cpp:150-160) without the GPU: the added matrix is the one of
+    (b . grad e, v) -- it is linear in u, so J u reproduces the residual difference exactly, its row sums vanish (grad of
+    a constant) and for constant b on a uniform mesh it is skew plus a boundary term, i.e. NOT symmetric."""
+    rng = np.random.default_rng(4)
+    for dim, order, qdeg, nc in ((2, 2, 4, (4, 3)), (3, 1, 2, (3, 2, 2))):
+        m = oracle.mesh_structured(dim, order, nc)
+        u = rng.uniform(-1, 1, m["ndof"])
+        b = [0.7, -1.1, 0.4][:dim]
+        kw = dict(diff=0.9, source=("const", 0.3))
+        base = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, **kw)
+        adv = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, advection=b, **kw)
+        n = m["ndof"]
+        A = sp.csr_matrix((adv["crs_vals"] - base["crs_vals"], adv["colind"], adv["rowptr"]), shape=(n, n))
+        assert abs(A).max() > 1e-3
+        assert np.abs(A @ np.ones(n)).max() < 1e-13
+        assert np.abs((adv["res"] - base["res"]) + A @ u).max() < 1e-12 * max(1.0, np.abs(adv["res"]).max())
+        assert abs(A - A.T).max() > 1e-3
+        # the same b given per integration point
+        pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+        E, nq = pb["wts"].shape
+        arr = np.broadcast_to(np.asarray(b), (E, nq, dim)).copy()
+        adv2 = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, advection=arr, **kw)
+        assert np.array_equal(adv2["crs_vals"], adv["crs_vals"]) and np.array_equal(adv2["res"], adv["res"])
+
+
+def test_flux_condition_of_the_oracle(oracle):
+    """fluxConditions restated (physicsInterface.cpp:1702-1762): against a numpy einsum, fixed rows skipped, and a unit
+    flux on a closed boundary integrates the HGRAD partition of unity to the boundary measure."""
+    rng = np.random.default_rng(5)
+    dim, order, qdeg, nc = 2, 2, 4, (4, 3)
+    m = oracle.mesh_structured(dim, order, nc)
+    total = 0.0
+    for side in ("bottom", "right", "top", "left"):
+        belem, bside = oracle.boundary_sides(dim, nc, side)
+        sb = oracle.physical_side_basis(dim, order, qdeg, m["nodes"], belem, bside)
+        flux = rng.uniform(-1, 1, sb["wts"].shape)
+        fixed = np.zeros(m["ndof"], np.uint8)
+        fixed[m["lids"][belem[1], 0]] = 1
+        got = np.zeros(m["ndof"])
+        oracle.flux_condition(belem, m["lids"], m["offsets"], flux, sb["wts"], sb["basis"][..., None], got, fixed=fixed)
+        want = np.zeros(m["ndof"])
+        np.add.at(want, m["lids"][belem][:, m["offsets"]], np.einsum("kq,kq,kfq->kf", flux, sb["wts"], sb["basis"]))
+        want[fixed != 0] = 0.0
+        assert np.abs(got - want).max() < 1e-14
+        one = np.zeros(m["ndof"])
+        oracle.flux_condition(belem, m["lids"], m["offsets"], np.ones_like(flux), sb["wts"], sb["basis"][..., None], one)
+        total += one.sum()
+    assert abs(total - 4.0) < 1e-13
