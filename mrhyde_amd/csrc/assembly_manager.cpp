@@ -243,6 +243,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   has_graph_ = true;
   ro_ = RowOwnerData();
   bpat_ = BlockPatternData();
+  gro_ = GeneralRowOwnerData();
   has_elem_slot_ = false;
   has_incidence_ = false;
 }
@@ -428,25 +429,48 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         ro_.failed = true;
       }
     }
-    // affine elements with constant coefficients: fused row-owner kernels; otherwise dense element matrices + the
-    // atomic-free row gather (4.1 ms against 7.4 ms for the atomic scatter on the perturbed config-2 mesh)
-    path = rowOwnerUsable(nullptr) ? MHA_PATH_ROW_OWNER : MHA_PATH_ROW_GATHER;
+    // affine elements with constant coefficients: the fused affine row-owner kernels; general elements / variable
+    // coefficients: the general row-owner kernel; what neither covers: dense element matrices + the row gather
+    static const bool no_general = [] { const char *m = std::getenv("MHA_GENERAL"); return m && m[0] == 'g'; }();  // "gather"
+    if (rowOwnerUsable(nullptr)) {
+      path = MHA_PATH_ROW_OWNER;
+    } else {
+      if (!no_general) prepareGeneralRowOwner();
+      path = (!no_general && gro_.usable) ? MHA_PATH_ROW_OWNER : MHA_PATH_ROW_GATHER;
+    }
   }
+  int row_owner_kind = 0;  // 1: affine pair of kernels, 2: general-element kernel
   if (path == MHA_PATH_ROW_OWNER) {
-    if (!ro_.ready) prepareRowOwner();
     std::string why;
-    MHA_REQUIRE(rowOwnerUsable(&why), MHA_ERR_INVALID, "row-owner path not available: " << why);
+    if (!ro_.ready && !ro_.failed && thermal_row_owner_supported(dim_, order_, ref_.nq1)) {
+      try {
+        prepareRowOwner();
+      } catch (const Error &) {
+        ro_ = RowOwnerData();
+        ro_.failed = true;
+      }
+    }
+    if (rowOwnerUsable(&why)) {
+      row_owner_kind = 1;
+    } else {
+      prepareGeneralRowOwner();
+      MHA_REQUIRE(gro_.usable, MHA_ERR_INVALID,
+                  "row-owner path not available: affine kernels: " << why << "; general kernel: " << gro_.why);
+      row_owner_kind = 2;
+    }
   }
+  const bool ro_all_rows = row_owner_kind == 2 ? gro_.all_rows_covered : ro_.all_rows_covered;
   if (path == MHA_PATH_ROW_GATHER) prepareRowGather(compute_jacobian != 0);
   timedBegin();
-  if (overwrite && path != MHA_PATH_ROW_GATHER && !(path == MHA_PATH_ROW_OWNER && ro_.all_rows_covered)) {
+  if (overwrite && path != MHA_PATH_ROW_GATHER && !(path == MHA_PATH_ROW_OWNER && ro_all_rows)) {
     // the accumulate-only kernels get the fused zeroing as an explicit memset on the same stream
     MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
     if (compute_jacobian) MHA_HIP(hipMemsetAsync(crs_vals, 0, sizeof(double) * h_rowptr_[nrows_], stream_));
   }
   switch (path) {
     case MHA_PATH_ROW_OWNER:
-      launchRowOwner(compute_jacobian != 0, overwrite && ro_.all_rows_covered, res, crs_vals);
+      if (row_owner_kind == 2) launchGeneralRowOwner(compute_jacobian != 0, overwrite && ro_all_rows, res, crs_vals);
+      else launchRowOwner(compute_jacobian != 0, overwrite && ro_all_rows, res, crs_vals);
       break;
     case MHA_PATH_ELEMENT_ATOMIC: {
       // one launch over the whole block: the worksets of the reference are an execution detail
@@ -540,6 +564,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
   }
   timedEnd();
   last_path_ = path;
+  last_row_owner_kind_ = row_owner_kind;
 }
 
 // reference: updateJac / updateRes on the whole block (assemblyManager.cpp:7412-7455, 7115-7152)
@@ -1351,6 +1376,131 @@ bool AssemblyManager::rowOwnerUsable(std::string *why) const {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// general-element row-owner kernel
+// ---------------------------------------------------------------------------------------------
+
+RowBlocksDev AssemblyManager::generalRowBlocksDev() const {
+  RowBlocksDev rb;
+  rb.num_blocks = gro_.rb.num_blocks;
+  rb.row_ptr = gro_.row_ptr.data();
+  rb.rows = gro_.rows.data();
+  rb.elem_ptr = gro_.elem_ptr.data();
+  rb.elems = gro_.elems.data();
+  rb.pair_ptr = gro_.pair_ptr.data();
+  rb.pairs = gro_.pairs.data();
+  rb.pair_off = gro_.pair_off.data();
+  rb.row_len = gro_.row_len.data();
+  rb.slot_ptr = gro_.slot_ptr.data();
+  rb.seg_ptr = gro_.seg_ptr.data();
+  rb.seg_acc = gro_.seg_acc.data();
+  rb.seg_base = gro_.seg_base.data();
+  rb.seg_len = gro_.seg_len.data();
+  rb.lds_rows = gro_.rb.max_rows;
+  rb.lds_elems = gro_.rb.max_elems;
+  rb.lds_acc = gro_.rb.max_acc;
+  rb.lds_pairs = gro_.rb.max_pairs;
+  rb.lds_segs = gro_.rb.max_segs;
+  return rb;
+}
+
+// Row blocks for the general row-owner kernel: Morton chunks of 2x2x2 (4x4) elements, at most 27 (25) touched elements,
+// 256 pairs (16 matrix-core tiles) and an accumulator that leaves room for the per-element point data in LDS.  Any
+// failure (a row beyond the caps, rows longer than 256 entries, LDS) leaves usable == false: AUTO keeps the element
+// matrices + row gather, an explicit MHA_PATH_ROW_OWNER reports `why`.
+void AssemblyManager::prepareGeneralRowOwner() {
+  if (gro_.tried) return;
+  gro_.tried = true;
+  auto fail = [&](const std::string &m) { gro_.why = m; gro_.usable = false; };
+  if (!single_hgrad_ || !thermal_general_row_owner_supported(dim_, order_, ref_.nq1))
+    return fail("unsupported (dim, order, points/dir) for the general row-owner kernel");
+  int max_row = 0;
+  for (int r = 0; r < nrows_; ++r) max_row = std::max(max_row, h_rowptr_[r + 1] - h_rowptr_[r]);
+  if (max_row > 256) return fail("CRS rows longer than 256 entries");
+  RowBlockCaps caps = default_caps(dim_, n_);
+  caps.max_elems = (dim_ == 3) ? 27 : 25;
+  caps.max_rows = 128;
+  caps.max_pairs = 256;
+  caps.max_acc = 4352;
+  if (const char *e = std::getenv("MHA_GRO_CHUNK")) caps.chunk_elems = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("MHA_GRO_MAXACC")) caps.max_acc = std::max(2 * max_row, std::atoi(e));
+  std::vector<double> nodes(static_cast<size_t>(nelem_) * nnodes_ * dim_);
+  d_nodes_.download(nodes.data());
+  try {
+    gro_.rb = build_row_blocks(dim_, nnodes_, nelem_, n_, nrows_, nodes.data(), h_lids_.data(), h_rowptr_.data(), caps,
+                               has_fixed_ ? h_fixed_.data() : nullptr, 1);
+  } catch (const Error &e) {
+    return fail(e.what());
+  }
+  const RowBlocks &rb = gro_.rb;
+  gro_.row_ptr.upload(rb.row_ptr);
+  gro_.rows.upload(rb.rows);
+  gro_.elem_ptr.upload(rb.elem_ptr);
+  gro_.elems.upload(rb.elems);
+  gro_.pair_ptr.upload(rb.pair_ptr);
+  gro_.pairs.upload(rb.pairs);
+  gro_.pair_off.upload(rb.pair_off);
+  gro_.row_len.upload(rb.row_len);
+  gro_.slot_ptr.upload(rb.slot_ptr);
+  gro_.seg_ptr.upload(rb.seg_ptr);
+  gro_.seg_acc.upload(rb.seg_acc);
+  gro_.seg_base.upload(rb.seg_base);
+  gro_.seg_len.upload(rb.seg_len);
+  gro_.all_rows_covered = static_cast<int>(rb.rows.size()) == nrows_;
+  gro_.lds_bytes = thermal_general_row_owner_lds(dim_, order_, ref_.nq1, generalRowBlocksDev());
+  if (gro_.lds_bytes > size_t(160) * 1024) return fail("row blocks do not fit the LDS of the general row-owner kernel");
+  gro_.slot.resize(std::max<size_t>(16, static_cast<size_t>(rb.slot_ptr.back())));
+  launch_build_block_slots(blockDev(), generalRowBlocksDev(), gro_.slot.data(), 1, stream_);
+  {  // block-major row ids of the touched elements' dofs (dof order): the kernel's gather is then two loads deep
+    std::vector<int32_t> offs(n_), br(rb.elems.size() * static_cast<size_t>(n_));
+    d_offsets_.download(offs.data());
+    for (size_t k = 0; k < rb.elems.size(); ++k)
+      for (int j = 0; j < n_; ++j) br[k * n_ + j] = h_lids_[static_cast<size_t>(rb.elems[k]) * n_ + offs[j]];
+    gro_.blk_rows.upload(br);
+    // block headers, 12 ints each: first touched element, T, first pair, NP, first row, NR, first run, NS,
+    // slot-table offset / 16, slot-table uint4s
+    std::vector<int32_t> hdr(static_cast<size_t>(rb.num_blocks) * 12, 0);
+    for (int k = 0; k < rb.num_blocks; ++k) {
+      int32_t *h = hdr.data() + static_cast<size_t>(k) * 12;
+      h[0] = rb.elem_ptr[k]; h[1] = rb.elem_ptr[k + 1] - rb.elem_ptr[k];
+      h[2] = rb.pair_ptr[k]; h[3] = rb.pair_ptr[k + 1] - rb.pair_ptr[k];
+      h[4] = rb.row_ptr[k]; h[5] = rb.row_ptr[k + 1] - rb.row_ptr[k];
+      h[6] = rb.seg_ptr[k]; h[7] = rb.seg_ptr[k + 1] - rb.seg_ptr[k];
+      h[8] = static_cast<int32_t>(rb.slot_ptr[k] / 16); h[9] = static_cast<int32_t>((rb.slot_ptr[k + 1] - rb.slot_ptr[k]) / 16);
+    }
+    gro_.blk_hdr.upload(hdr);
+  }
+  gro_.usable = true;
+  if (std::getenv("MHA_VERBOSE"))
+    fprintf(stderr, "[mha] general row-owner: %d blocks, max rows %d elems %d pairs %d acc %d segs %d, LDS %zu B\n",
+            rb.num_blocks, rb.max_rows, rb.max_elems, rb.max_pairs, rb.max_acc, rb.max_segs, gro_.lds_bytes);
+}
+
+void AssemblyManager::launchGeneralRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals) {
+  thermal *th = dynamic_cast<thermal *>(physics_.get());
+  MHA_REQUIRE(th != nullptr, MHA_ERR_INVALID, "row-owner path: physics module is not thermal");
+  const ThermalDev ph = th->device_params();
+  RowOut out;
+  out.res = res;
+  out.vals = compute_jacobian ? crs_vals : nullptr;
+  out.overwrite = overwrite ? 1 : 0;
+  out.compute_jacobian = compute_jacobian ? 1 : 0;
+  static const int wgs = [] { const char *m = std::getenv("MHA_GRO_WGS"); return m ? std::atoi(m) : 0; }();
+  const int nwg = wgs > 0 ? wgs : current_device_num_cus();
+  // profiling aid (env MHA_GRO_TIMING=<file>): cycles every wavefront spent in each phase of the last launch
+  static const char *timing_file = std::getenv("MHA_GRO_TIMING");
+  if (timing_file && gro_.timing.size() != static_cast<size_t>(nwg) * 8 * 8) gro_.timing.resize(static_cast<size_t>(nwg) * 8 * 8);
+  launch_thermal_general_row_owner(dim_, order_, ref_.nq1, blockDev(), ph, generalRowBlocksDev(), gro_.slot.data(),
+                                   gro_.blk_rows.data(), d_gp1d_.data(), gro_.blk_hdr.data(),
+                                   timing_file ? gro_.timing.data() : nullptr, out, nwg, stream_);
+  if (timing_file) {
+    MHA_HIP(hipStreamSynchronize(stream_));
+    std::vector<long long> t(gro_.timing.size());
+    gro_.timing.download(t.data());
+    if (FILE *f = fopen(timing_file, "wb")) { fwrite(t.data(), sizeof(long long), t.size(), f); fclose(f); }
+  }
+}
+
 RowBlocksDev AssemblyManager::rowBlocksDev() const {
   RowBlocksDev rb;
   rb.num_blocks = ro_.rb.num_blocks;
@@ -1454,6 +1604,9 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "last_path") return last_path_;
   if (key == "workset_size") return wkset_.maxElem;
   if (key == "row_blocks") return ro_.ready ? ro_.rb.num_blocks : 0;
+  if (key == "row_owner_kind") return last_row_owner_kind_;  // of the last assembly: 1 affine kernels, 2 general-element kernel
+  if (key == "general_row_blocks") return gro_.usable ? gro_.rb.num_blocks : 0;
+  if (key == "general_row_owner_lds_bytes") return gro_.usable ? static_cast<int64_t>(gro_.lds_bytes) : 0;
   if (key == "block_patterns") return bpat_.usable ? bpat_.num_patterns : 0;
   if (key == "block_pattern_roles") return bpat_.usable ? bpat_.num_roles : 0;
   if (key == "block_pattern_blocks") return bpat_.usable ? bpat_.num_blocks : 0;

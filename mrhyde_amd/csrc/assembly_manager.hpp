@@ -111,6 +111,7 @@ class AssemblyManager {
   int nelem_ = 0, nrows_ = 0, workset_size_ = 0;
   bool has_mesh_ = false, has_graph_ = false;
   int last_path_ = 0;
+  int last_row_owner_kind_ = 0;
   hipStream_t stream_ = nullptr;
   int device_ = 0;  // the context's device (mha_block_desc.device): every C-ABI entry runs under a DeviceGuard for it
 
@@ -151,6 +152,25 @@ class AssemblyManager {
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
     bool all_rows_covered = false;
   } ro_;
+  // general-element row-owner kernel (kernels/thermal_general_row_owner.hip): its own row blocks (2x2x2 / 4x4 chunks,
+  // caps sized to that kernel's LDS) and block-major slot table
+  struct GeneralRowOwnerData {
+    bool tried = false, usable = false;
+    std::string why;
+    RowBlocks rb;
+    DeviceBuffer<int32_t> row_ptr, rows, elem_ptr, elems, pair_ptr, pair_off, row_len, seg_ptr, seg_acc, seg_base, seg_len;
+    DeviceBuffer<int32_t> blk_rows;  // [touched element of every block][n]: global row of dof j
+    DeviceBuffer<int32_t> blk_hdr;   // [block][12] counts and offsets of the block's tables
+    DeviceBuffer<long long> timing;  // profiling aid (MHA_GRO_TIMING)
+    DeviceBuffer<int64_t> slot_ptr;
+    DeviceBuffer<uint32_t> pairs;
+    DeviceBuffer<uint8_t> slot;
+    bool all_rows_covered = false;
+    size_t lds_bytes = 0;
+  } gro_;
+  void prepareGeneralRowOwner();
+  RowBlocksDev generalRowBlocksDev() const;
+  void launchGeneralRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals);
   // row blocks keyed by assembly pattern: the matrix-core form of K2 (block_pattern.hpp); !usable -> the row-block kernel
   struct BlockPatternData {
     bool tried = false, usable = false;

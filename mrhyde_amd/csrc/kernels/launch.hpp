@@ -27,6 +27,14 @@ struct WorksetViewsDev {
 };
 void launch_workset_views(const BlockDev &b, int e0, int ne, const WorksetViewsDev &v, hipStream_t stream);
 
+// thermal_general_row_owner.hip: residual + Jacobian of general thermal elements in row-owner form (one launch)
+bool thermal_general_row_owner_supported(int dim, int order, int nq1);
+size_t thermal_general_row_owner_lds(int dim, int order, int nq1, const RowBlocksDev &rb);
+void launch_thermal_general_row_owner(int dim, int order, int nq1, const BlockDev &b, const ThermalDev &ph,
+                                      const RowBlocksDev &rb, const uint8_t *slot8, const int32_t *blk_rows,
+                                      const double *gp1d, const int32_t *blk_hdr, long long *timing, const RowOut &out,
+                                      int num_cus, hipStream_t stream);
+
 // var_views.hip: per-variable basis views (volume range e0.. when elem == null, else boundary entries), solution
 // fields of the current workset, PhysicsInterface::fluxConditions, and a[i] = -a[i]
 void launch_var_views(const BlockDev &b, const VarPointsDev &t, const int32_t *elem, const int32_t *side, int e0, int num,

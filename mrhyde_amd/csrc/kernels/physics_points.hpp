@@ -32,9 +32,12 @@ __device__ __forceinline__ void thermal_point(const PointArgs<DIM> &a, Dual *F) 
   F[0] = a.Ud[0] * (rho * cp) - f;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) F[1 + d] = a.U[1 + d] * kap;
-  if (pp.p[0] != 0.0) {  // have_advection: (b . grad e) against the value of the test function (thermal.cpp:150-160)
+  // have_advection: (b . grad e) against the value of the test function (thermal.cpp:150-160).  Not in the deck-string
+  // instantiation: with the interpreter inlined the kernel is at the scratch it may use (the host refuses that mix)
+  if constexpr (!EXPR)
+  if (pp.p[0] != 0.0) {
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) F[0] = F[0] + a.U[1 + d] * eval_func<DIM, EXPR>(pp.f[4 + d], a.e, a.q, a.nq, a.x);
+    for (int d = 0; d < DIM; ++d) F[0] = F[0] + a.U[1 + d] * eval_func<DIM, false>(pp.f[4 + d], a.e, a.q, a.nq, a.x);  // (no deck strings: host checks)
   }
 }
 

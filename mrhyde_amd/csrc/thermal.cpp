@@ -76,7 +76,15 @@ void thermal::volumeResidual() {
     pp.p[0] = have_advection ? 1.0 : 0.0;
     if (have_advection) {
       const char *bn[3] = {"bx", "by", "bz"};
-      for (int d = 0; d < w.dimension; ++d) pp.f[4 + d] = functionManager->evaluate(bn[d]);
+      for (int d = 0; d < w.dimension; ++d) {
+        pp.f[4 + d] = functionManager->evaluate(bn[d]);
+      }
+      // the deck-string instantiation of the engine is at the scratch it may use (common.hpp: require_modest_scratch)
+      // and does not carry the advection term
+      for (int k = 0; k < 7; ++k)
+        MHA_REQUIRE(pp.f[k].kind != MHA_FUNC_EXPRESSION, MHA_ERR_INVALID,
+                    "thermal with 'include advection': give the functions as constants, closed forms or per-point arrays "
+                    "(deck strings are evaluated by the caller into an ip array)");
     }
     launch_point_engine(b, w.layout, pp, w.time_dev, w.res, w.elem_slot, w.elem_slot_bytes, w.stream);
   } else if (have_advection) {

@@ -356,7 +356,7 @@ def test_baseline_kernel_knob_on_the_row_gather_path(oracle, monkeypatch):
     res = torch.full((m["ndof"],), 3.0, dtype=torch.float64, device="cuda")
     vals = torch.full((len(ref["colind"]),), 3.0, dtype=torch.float64, device="cuda")
     for _ in range(2):
-        blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True)
+        blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True, path=mrhyde_amd.PATH_ROW_GATHER)
         torch.cuda.synchronize()
         assert blk.info("last_path") == mrhyde_amd.PATH_ROW_GATHER
         assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
@@ -462,13 +462,15 @@ def test_row_owner_transient_and_source_array(oracle, monkeypatch, k2):
 
 
 def test_auto_path_selection(oracle):
-    """AUTO = row-owner on affine meshes with constant coefficients, element matrices + row gather otherwise; both
-    correct (the row-gather path also with accumulate semantics, fixed rows and a residual-only pass)."""
+    """AUTO = the row-owner family wherever it exists: the fused affine kernels on affine meshes with constant
+    coefficients (kind 1), the general-element row-owner kernel otherwise (kind 2); both correct, the general one also
+    with accumulate semantics, fixed rows and a residual-only pass; the element-matrix + row-gather path stays
+    selectable and agrees."""
     torch = _torch()
     import mrhyde_amd
     dim, order, qdeg, ncell = 3, 2, 4, (3, 3, 3)
-    for mesh_fn, expect in ((lambda: affine_mesh(oracle, dim, order, ncell), mrhyde_amd.PATH_ROW_OWNER),
-                            (lambda: perturbed(oracle, dim, order, ncell, seed=2), mrhyde_amd.PATH_ROW_GATHER)):
+    for mesh_fn, kind in ((lambda: affine_mesh(oracle, dim, order, ncell), 1),
+                          (lambda: perturbed(oracle, dim, order, ncell, seed=2), 2)):
         m = mesh_fn()
         u = np.random.default_rng(5).uniform(-1, 1, m["ndof"])
         ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, source=("const", 1.0))
@@ -478,12 +480,11 @@ def test_auto_path_selection(oracle):
         vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
         blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True)
         torch.cuda.synchronize()
-        assert blk.info("last_path") == expect
+        assert blk.info("last_path") == mrhyde_amd.PATH_ROW_OWNER and blk.info("row_owner_kind") == kind
         assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
         assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
-        if expect == mrhyde_amd.PATH_ROW_GATHER:
-            with pytest.raises(mrhyde_amd.MhaError):
-                blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, path=mrhyde_amd.PATH_ROW_OWNER)
+        if kind == 2:
+            assert blk.info("general_row_blocks") > 0
             # accumulate on top of the first result, then a residual-only overwrite
             blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals)
             torch.cuda.synchronize()
@@ -491,7 +492,16 @@ def test_auto_path_selection(oracle):
             blk.assemble_jacres(torch.tensor(u, device="cuda"), res, None, compute_jacobian=False, overwrite=True)
             torch.cuda.synchronize()
             assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
-            # fixed rows: skipped by the gather, zeroed by the overwrite
+            assert rel_err(vals.cpu().numpy(), 2 * ref["crs_vals"]) < RTOL      # the matrix was left alone
+            # the explicit row-owner request lands on the same kernel; the dense path is still there
+            for path in (mrhyde_amd.PATH_ROW_OWNER, mrhyde_amd.PATH_ROW_GATHER):
+                res.fill_(4.0)
+                vals.fill_(4.0)
+                blk.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True, path=path)
+                torch.cuda.synchronize()
+                assert blk.info("last_path") == path
+                assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL and rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+            # fixed rows: skipped by the owner, zeroed by the overwrite
             fixed = m["boundary"]
             reff = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed,
                                            source=("const", 1.0))
@@ -501,8 +511,73 @@ def test_auto_path_selection(oracle):
             vals.fill_(5.0)
             blk2.assemble_jacres(torch.tensor(u, device="cuda"), res, vals, overwrite=True)
             torch.cuda.synchronize()
-            assert blk2.info("last_path") == mrhyde_amd.PATH_ROW_GATHER
+            assert blk2.info("row_owner_kind") == 2
             assert rel_err(vals.cpu().numpy(), reff["crs_vals"]) < RTOL and rel_err(res.cpu().numpy(), reff["res"]) < RTOL
+            # ... and left untouched when accumulating
+            blk2.assemble_jacres(torch.tensor(u, device="cuda"), res, vals)
+            torch.cuda.synchronize()
+            assert rel_err(vals.cpu().numpy(), 2 * reff["crs_vals"]) < RTOL and rel_err(res.cpu().numpy(), 2 * reff["res"]) < RTOL
+
+
+GENERAL_RO_CASES = [  # dim, order, qdeg, ncell: every instantiation of kernels/thermal_general_row_owner.hip
+    (2, 1, 2, (7, 6)), (2, 2, 4, (6, 5)), (2, 3, 6, (4, 3)), (2, 4, 8, (4, 3)), (3, 1, 2, (4, 3, 3)), (3, 2, 4, (4, 3, 2)),
+]
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell", GENERAL_RO_CASES)
+@pytest.mark.parametrize("mode", ["steady-sinprod", "transient-arrays", "expression"])
+def test_general_row_owner_matches_oracle(oracle, dim, order, qdeg, ncell, mode):
+    """The general-element row-owner kernel against the oracle: perturbed (non-affine) meshes, coefficient functions
+    given as constants / closed forms / per-point arrays / deck expressions, steady and transient (3-stage DIRK, BDF-2),
+    fixed rows, overwrite on garbage.  Residual and Jacobian come out of ONE launch with no atomics on global memory."""
+    torch = _torch()
+    import mrhyde_amd
+    m = perturbed(oracle, dim, order, ncell, seed=31)
+    rng = np.random.default_rng(17)
+    nd = m["ndof"]
+    u = rng.uniform(-1, 1, nd)
+    fixed = m["boundary"]
+    pb = oracle.physical_basis(dim, order, qdeg, m["nodes"])
+    E, nq = pb["wts"].shape
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+    kw, okw, tr = {}, {}, None
+    funcs = {}
+    if mode == "steady-sinprod":
+        fr = [2.0, 1.0, 1.5][:dim]
+        okw = dict(source=("sinprod", 3.0, fr), diff=1.7)
+        funcs = {"thermal source": ("sinprod", 3.0, fr), "thermal diffusion": 1.7}
+    elif mode == "transient-arrays":
+        A = np.array([[0.4358665215, 0, 0], [0.2820667392, 0.4358665215, 0], [1.208496649, -0.644363171, 0.4358665215]])
+        bb = np.array([1.208496649, -0.644363171, 0.4358665215])
+        tr = dict(u_prev=rng.uniform(-1, 1, (nd, 2)), u_stage=rng.uniform(-1, 1, (nd, 3)), stage=2, butcher_A=A,
+                  butcher_b=bb, bdf=np.array([1.5, -2.0, 0.5]), dt=0.013)
+        kap, src = rng.uniform(0.5, 2.0, (E, nq)), rng.uniform(-1, 1, (E, nq))
+        okw = dict(source=("array", src), diff_ip=kap, rho=1.3, cp=0.7, transient=tr)
+        funcs = {"thermal source": t(src), "thermal diffusion": t(kap), "density": 1.3, "specific heat": 0.7}
+        kw = dict(u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]))
+    else:
+        expr = "1.0+0.5*x*y" if dim == 2 else "1.0+0.5*x*y+0.25*z"
+        kap = 1.0 + 0.5 * pb["ip"][..., 0] * pb["ip"][..., 1] + (0.25 * pb["ip"][..., 2] if dim == 3 else 0.0)
+        okw = dict(source=("const", 0.8), diff_ip=kap)
+        funcs = {"thermal source": 0.8, "thermal diffusion": expr}
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed, pb=pb, **okw)
+    blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+    for k, v in funcs.items():
+        blk.set_function(k, v)
+    if tr is not None:
+        blk.set_time_integration(True, 2, 3, 2, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+    res = torch.full((nd,), 7.0, dtype=torch.float64, device="cuda")
+    vals = torch.full((len(ref["colind"]),), -3.0, dtype=torch.float64, device="cuda")
+    blk.assemble_jacres(t(u), res, vals, overwrite=True, path=mrhyde_amd.PATH_ROW_OWNER, **kw)
+    torch.cuda.synchronize()
+    assert blk.info("row_owner_kind") == 2
+    assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+    # run twice: bit-identical up to the order of LDS adds within one entry -- in practice identical to roundoff
+    res2, vals2 = torch.zeros_like(res), torch.zeros_like(vals)
+    blk.assemble_jacres(t(u), res2, vals2, overwrite=True, path=mrhyde_amd.PATH_ROW_OWNER, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(vals2.cpu().numpy(), vals.cpu().numpy()) < 1e-14 and rel_err(res2.cpu().numpy(), res.cpu().numpy()) < 1e-14
 
 
 def test_error_behaviour_on_device():
