@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -82,29 +83,29 @@ struct RG {
 
 // LDS carve (bytes).  A "table buffer" holds one block's small tables; there are two (current / next).
 struct RgLds {
-  size_t d, m, f, s, racc, acc, scratch, ids, slot, tab[2], total;
-  size_t t_pairs, t_segs, t_rows, t_elems, t_pairoff, tab_bytes;  // offsets inside a table buffer
+  int d, m, f, s, racc, acc, scratch, ids, slot, tab[2], total;
+  int t_pairs, t_segs, t_rows, t_elems, t_pairoff, tab_bytes;  // offsets inside a table buffer
 };
 template <int DIM, int P, int NQ1, bool TR>
 __host__ __device__ inline RgLds rg_layout(int T, int rows, int acc, int pairs, int segs) {
   using S = RG<DIM, P, NQ1, TR>;
   RgLds l;
-  size_t o = (size_t)S::SHARED * 8;
-  l.d = o; o += (size_t)T * S::E_D * 8;
-  l.m = o; o += TR ? (size_t)T * S::E_M * 8 : 0;
-  l.f = o; o += (size_t)T * S::E_F * 8;
-  l.s = o; o += (size_t)T * S::E_S * 8;
-  l.racc = o; o += (size_t)((rows + 1) / 2 * 2) * 8;
-  l.acc = o; o += (size_t)((acc + 1) / 2 * 2) * 8;
-  l.scratch = o; o += (size_t)T * S::SCRATCH_PER_ELEM * 8;
-  l.ids = o; o += ((size_t)T * S::N * 4 + 15) / 16 * 16;
-  l.slot = o; o += ((size_t)pairs * S::N + 15) / 16 * 16;
-  size_t t = 0;
-  l.t_pairs = t; t += (size_t)pairs * 4;
-  l.t_segs = t; t += (size_t)segs * 12;
-  l.t_rows = t; t += (size_t)rows * 4;
-  l.t_elems = t; t += (size_t)T * 4;
-  l.t_pairoff = t; t += (size_t)pairs * 2;
+  int o = S::SHARED * 8;
+  l.d = o; o += T * S::E_D * 8;
+  l.m = o; o += TR ? T * S::E_M * 8 : 0;
+  l.f = o; o += T * S::E_F * 8;
+  l.s = o; o += T * S::E_S * 8;
+  l.racc = o; o += ((rows + 1) / 2 * 2) * 8;
+  l.acc = o; o += ((acc + 1) / 2 * 2) * 8;
+  l.scratch = o; o += T * S::SCRATCH_PER_ELEM * 8;
+  l.ids = o; o += (T * S::N * 4 + 15) / 16 * 16;
+  l.slot = o; o += (pairs * S::N + 15) / 16 * 16;
+  int t = 0;
+  l.t_pairs = t; t += pairs * 4;
+  l.t_segs = t; t += segs * 12;
+  l.t_rows = t; t += rows * 4;
+  l.t_elems = t; t += T * 4;
+  l.t_pairoff = t; t += pairs * 2;
   l.tab_bytes = (t + 15) / 16 * 16;
   l.tab[0] = o; o += l.tab_bytes;
   l.tab[1] = o; o += l.tab_bytes;
@@ -116,13 +117,14 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int kRgSlotRegs = 2;  // uint4 per fetching thread: pairs * n <= 2 * 256 * 16 bytes
 
-template <int DIM, int P, int NQ1, bool TR, bool EXPR>
+template <int DIM, int P, int NQ1, bool TR, bool EXPR, bool TIMING>
 __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev b, ThermalDev ph, RowBlocksDev rb,
                                                                         const uint8_t *__restrict__ slot8,
                                                                         const int32_t *__restrict__ blk_rows,
                                                                         const double *__restrict__ gp1d,
                                                                         const int32_t *__restrict__ blk_hdr, RowOut out,
-                                                                        int dbg, long long *timing) {
+                                                                        int dbg_arg, long long *timing) {
+  const int dbg = TIMING ? dbg_arg : 0;  // the ablation switches exist in the profiling build only
   // dbg (env MHA_GRO_DBG, profiling only -- results are wrong): 1 no field / geometry phases, 2 no residual sums,
   // 4 no products, 8 no LDS adds of the tiles, 16 no CRS stores, 32 no fetch of the next block (stale data)
   using S = RG<DIM, P, NQ1, TR>;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
   const TimeDev &tm = ph.time;
 
   // ---- once per workgroup: zero the LDS (padding entries must stay finite), reference tables ----
-  for (size_t i = tid; i < L.total / 8; i += NT) smem[i] = 0.0;
+  for (int i = tid; i < L.total / 8; i += NT) smem[i] = 0.0;
   __syncthreads();
   auto gidx = [](int a, int q, int j) { return ((a * QG + (q >> 2)) * 64 + (q & 3) * 16 + (j & 15)) * CT + (j >> 4); };
   for (int i = tid; i < N * NQ * DIM; i += NT) {
@@ -281,10 +283,10 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
   }
   lds_barrier();
   long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define MHA_RG_STAMP(k_) if (timing) { const long long now = __builtin_readcyclecounter(); tacc[k_] += now - tprev; tprev = now; }
+#define MHA_RG_STAMP(k_) if constexpr (TIMING) { const long long now = __builtin_readcyclecounter(); tacc[k_] += now - tprev; tprev = now; }
 
   for (int blk = blockIdx.x; blk < rb.num_blocks; blk += gridDim.x) {
-    if (timing) tprev = __builtin_readcyclecounter();
+    if constexpr (TIMING) tprev = __builtin_readcyclecounter();
     int hc[HW], hn[HW];
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -422,13 +424,14 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
       MHA_RG_STAGE_B(hn, tbnext)
     }
     MHA_RG_STAMP(2)
-    {
+    auto tiles = [&](auto jac_c) {
+      constexpr bool JAC = decltype(jac_c)::value;
       // B[k = lane>>4 (+4s)][col = lane&15] of k-step s = (b, four points) is read from the Ghat table for every product (one
       // 16-byte read per lane covers both column tiles): held in registers for the whole tile loop (84 VGPRs) it left no
       // room to request a point group's operands ahead of the previous group's products.  The mass columns (N_j(q)) are
       // few enough to stay in registers.
       double Bm[KSM > 0 ? KSM : 1][CT];
-      if (jac) {
+      if constexpr (JAC) {
 #pragma unroll
         for (int s = 0; s < KSM; ++s)
 #pragma unroll
@@ -461,13 +464,13 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
 #define MHA_RG_LOAD(qg_, s_)                                                                 \
   {                                                                                          \
     _Pragma("unroll") for (int aa = 0; aa < DIM; ++aa) G3[s_][aa] = aG[(aa * QG + (qg_)) * 64 * CT]; \
-    if (jac) { _Pragma("unroll") for (int bb = 0; bb < DIM; ++bb) {                           \
+    if constexpr (JAC) { _Pragma("unroll") for (int bb = 0; bb < DIM; ++bb) {                           \
       if constexpr (CT == 2) { const v2d bv = *reinterpret_cast<const v2d *>(bB + (bb * QG + (qg_)) * 64 * CT); BB[s_][bb][0] = bv[0]; BB[s_][bb][1] = bv[1]; } \
       else BB[s_][bb][0] = bB[(bb * QG + (qg_)) * 64 * CT]; } }                               \
     NV[s_] = aN[4 * (qg_)];                                                                  \
     S1[s_] = aS[4 * (qg_)];                                                                  \
     _Pragma("unroll") for (int aa = 0; aa < DIM; ++aa) F3[s_][aa] = aF[aa * NQ4 + 4 * (qg_)]; \
-    if (jac) {                                                                               \
+    if constexpr (JAC) {                                                                               \
       _Pragma("unroll") for (int c = 0; c < NSYM; ++c) D6[s_][c] = aD[c * NQ4 + 4 * (qg_)];  \
       if constexpr (TR) M1[s_] = aM[4 * (qg_)];                                              \
     }                                                                                        \
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
 #pragma unroll
               for (int aa = 0; aa < DIM; ++aa) rp += F3[sb][aa] * G3[sb][aa];
             }
-            if (jac) {
+            if constexpr (JAC) {
 #pragma unroll
               for (int bb = 0; bb < DIM; ++bb) {
                 double a = 0.0;
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
         rp += __shfl_xor(rp, 32);
         if (g4 == 0 && pmine < NP && !(dbg & 2)) atomicAdd(&racc[o], -rp);
         // D register u: row (lane>>4) + 4u, column lane&15 -> entry slot[pair][LID position of column dof]
-        if (jac) {
+        if constexpr (JAC) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int pp = tile * 16 + g4 + 4 * u;
@@ -522,7 +525,8 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
           }
         }
       }
-    }
+    };
+    if (jac) tiles(std::true_type()); else tiles(std::false_type());
     MHA_RG_STAMP(3)
     lds_barrier();
     MHA_RG_STAMP(4)
@@ -570,8 +574,9 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
     MHA_RG_STAMP(5)
     cur ^= 1;
   }
-  if (timing && lane == 0)
-    for (int k = 0; k < 6; ++k) timing[((size_t)blockIdx.x * NW + wave) * 8 + k] = tacc[k];
+  if constexpr (TIMING)
+    if (lane == 0)
+      for (int k = 0; k < 6; ++k) timing[((size_t)blockIdx.x * NW + wave) * 8 + k] = tacc[k];
 #undef MHA_RG_STAMP
 #undef MHA_RG_STAGE_A_LOAD
 #undef MHA_RG_STAGE_A_STORE
@@ -595,14 +600,19 @@ void launch_rg(const BlockDev &b, const ThermalDev &ph, RowBlocksDev rb, const u
     static const int dbg = [] { const char *m = std::getenv("MHA_GRO_DBG"); return m ? std::atoi(m) : 0; }();
     hipLaunchKernelGGL(kern, dim3(std::min(rb.num_blocks, num_cus)), dim3(512), lds, stream, b, ph, rb, slot8, blk_rows, gp1d, blk_hdr, out, dbg, timing);
   };
-  if (tr) {
+  if (timing) {  // profiling build of the two plain-coefficient variants only
+    if (tr) go(thermal_general_row_owner_kernel<DIM, P, NQ1, true, false, true>,
+               rg_layout<DIM, P, NQ1, true>(rb.lds_elems, rb.lds_rows, rb.lds_acc, rb.lds_pairs, rb.lds_segs).total);
+    else go(thermal_general_row_owner_kernel<DIM, P, NQ1, false, false, true>,
+            rg_layout<DIM, P, NQ1, false>(rb.lds_elems, rb.lds_rows, rb.lds_acc, rb.lds_pairs, rb.lds_segs).total);
+  } else if (tr) {
     const size_t lds = rg_layout<DIM, P, NQ1, true>(rb.lds_elems, rb.lds_rows, rb.lds_acc, rb.lds_pairs, rb.lds_segs).total;
-    if (expr) go(thermal_general_row_owner_kernel<DIM, P, NQ1, true, true>, lds);
-    else go(thermal_general_row_owner_kernel<DIM, P, NQ1, true, false>, lds);
+    if (expr) go(thermal_general_row_owner_kernel<DIM, P, NQ1, true, true, false>, lds);
+    else go(thermal_general_row_owner_kernel<DIM, P, NQ1, true, false, false>, lds);
   } else {
     const size_t lds = rg_layout<DIM, P, NQ1, false>(rb.lds_elems, rb.lds_rows, rb.lds_acc, rb.lds_pairs, rb.lds_segs).total;
-    if (expr) go(thermal_general_row_owner_kernel<DIM, P, NQ1, false, true>, lds);
-    else go(thermal_general_row_owner_kernel<DIM, P, NQ1, false, false>, lds);
+    if (expr) go(thermal_general_row_owner_kernel<DIM, P, NQ1, false, true, false>, lds);
+    else go(thermal_general_row_owner_kernel<DIM, P, NQ1, false, false, false>, lds);
   }
   MHA_HIP(hipGetLastError());
 }
