@@ -264,11 +264,14 @@ def setup_thermal(args, torch, mrhyde_amd, rank, world, dev):
 
     def info():
         pname = {1: "element_atomic", 2: "row_owner", 3: "local_then_scatter", 4: "point_engine", 5: "row_gather"}.get(blk.info("last_path"))
-        kern = {"row_owner": ("thermal_affine_residual_kernel + block_pattern_jacobian_kernel" if blk.info("block_patterns") > 0
+        kind = blk.info("row_owner_kind")
+        kern = {"row_owner": ("thermal_general_row_owner_kernel (residual + Jacobian, one launch)" if kind == 2
+                              else "thermal_affine_residual_kernel + block_pattern_jacobian_kernel" if blk.info("block_patterns") > 0
                               else "thermal_affine_element/residual kernel + row_owner_jacobian_persistent_kernel"),
                 "row_gather": "thermal_general_element_kernel (dense element matrices) + row_gather_kernel"}.get(pname, "element kernel + scatter")
         return pname, kern, {"affine_elements": blk.info("num_affine_elems"), "block_patterns": blk.info("block_patterns"),
-                             "row_blocks": blk.info("row_blocks")}
+                             "row_blocks": blk.info("general_row_blocks") if kind == 2 else blk.info("row_blocks"),
+                             "row_owner_kind": kind}
 
     def cpu():
         threads = host_threads()

@@ -163,6 +163,15 @@ int mha_set_time_integration(mha_context *ctx, int transient, int num_steps, int
  * row gather (MHA_PATH_AUTO picks it; the fused fast paths do not carry the options).                             */
 #define MHA_ASSEMBLE_ADJOINT 4
 #define MHA_ASSEMBLE_LUMP_MASS 8
+/* DETERMINISTIC: results do not depend on scheduling -- two calls with the same inputs give bit-identical res / crs_vals.
+ * (The reference sums element contributions in element order on one thread, or with atomics in any order on a device
+ * build, assemblyManager.cpp:4058-4061; the default fast paths here add a row's contributions in an order that depends
+ * on wavefront timing, which moves the last bits.)  Available on the affine row-owner path (MHA_PATH_AUTO /
+ * MHA_PATH_ROW_OWNER on affine elements with constant coefficients): the Jacobian rows are register sums in a fixed order
+ * (kernels/block_pattern.hip) and the residual entries are summed pair by pair in pair order by the row's owner
+ * (kernels/thermal_general_row_owner.hip, residual-only, ordered) instead of the thread-per-element kernel's atomics;
+ * MHA_ERR_INVALID where that combination does not exist.  Slower: the residual costs ~1 ms more at config 2.          */
+#define MHA_ASSEMBLE_DETERMINISTIC 16
 #define MHA_PATH_AUTO 0
 #define MHA_PATH_ELEMENT_ATOMIC 1 /* per-element kernel, atomic scatter (reference's
                                      fused "assembly insert Jac" with useAtomics)     */

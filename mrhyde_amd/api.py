@@ -412,9 +412,11 @@ class Block:
 
     # -- assembly -----------------------------------------------------------
     def assemble_jacres(self, u, res, crs_vals=None, compute_jacobian=True, path=PATH_AUTO, u_prev=None,
-                        u_stage=None, overwrite=False, adjoint=False, lump_mass=False):
-        """adjoint / lump_mass: the scatter options isAdjoint_ / lump_mass_ of the reference (MHA_ASSEMBLE_ADJOINT, _LUMP_MASS)."""
-        flags = (1 if compute_jacobian else 0) | (2 if overwrite else 0) | (4 if adjoint else 0) | (8 if lump_mass else 0)
+                        u_stage=None, overwrite=False, adjoint=False, lump_mass=False, deterministic=False):
+        """adjoint / lump_mass: the scatter options isAdjoint_ / lump_mass_ of the reference (MHA_ASSEMBLE_ADJOINT, _LUMP_MASS);
+        deterministic: MHA_ASSEMBLE_DETERMINISTIC (bit-reproducible results on the affine row-owner path)."""
+        flags = ((1 if compute_jacobian else 0) | (2 if overwrite else 0) | (4 if adjoint else 0) | (8 if lump_mass else 0) |
+                 (16 if deterministic else 0))
         _check(load_library().mha_assemble_jacres(self._h, flags, path, _ptr(u), _ptr(u_prev),
                                                   _ptr(u_stage), _ptr(res), _ptr(crs_vals)))
 

@@ -460,6 +460,10 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
     }
   }
   const bool ro_all_rows = row_owner_kind == 2 ? gro_.all_rows_covered : ro_.all_rows_covered;
+  const bool deterministic = (flags & MHA_ASSEMBLE_DETERMINISTIC) != 0;
+  MHA_REQUIRE(!deterministic || row_owner_kind == 1, MHA_ERR_INVALID,
+              "MHA_ASSEMBLE_DETERMINISTIC is available on the affine row-owner path (thermal, affine elements, constant "
+              "coefficients; MHA_PATH_AUTO or MHA_PATH_ROW_OWNER)");
   if (path == MHA_PATH_ROW_GATHER) prepareRowGather(compute_jacobian != 0);
   timedBegin();
   if (overwrite && path != MHA_PATH_ROW_GATHER && !(path == MHA_PATH_ROW_OWNER && ro_all_rows)) {
@@ -470,7 +474,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
   switch (path) {
     case MHA_PATH_ROW_OWNER:
       if (row_owner_kind == 2) launchGeneralRowOwner(compute_jacobian != 0, overwrite && ro_all_rows, res, crs_vals);
-      else launchRowOwner(compute_jacobian != 0, overwrite && ro_all_rows, res, crs_vals);
+      else launchRowOwner(compute_jacobian != 0, overwrite && ro_all_rows, res, crs_vals, deterministic);
       break;
     case MHA_PATH_ELEMENT_ATOMIC: {
       // one launch over the whole block: the worksets of the reference are an execution detail
@@ -1476,7 +1480,7 @@ void AssemblyManager::prepareGeneralRowOwner() {
             rb.num_blocks, rb.max_rows, rb.max_elems, rb.max_pairs, rb.max_acc, rb.max_segs, gro_.lds_bytes);
 }
 
-void AssemblyManager::launchGeneralRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals) {
+void AssemblyManager::launchGeneralRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals, bool ordered) {
   thermal *th = dynamic_cast<thermal *>(physics_.get());
   MHA_REQUIRE(th != nullptr, MHA_ERR_INVALID, "row-owner path: physics module is not thermal");
   const ThermalDev ph = th->device_params();
@@ -1485,6 +1489,8 @@ void AssemblyManager::launchGeneralRowOwner(bool compute_jacobian, bool overwrit
   out.vals = compute_jacobian ? crs_vals : nullptr;
   out.overwrite = overwrite ? 1 : 0;
   out.compute_jacobian = compute_jacobian ? 1 : 0;
+  out.ordered = ordered ? 1 : 0;
+  MHA_REQUIRE(!ordered || !compute_jacobian, MHA_ERR_INVALID, "the ordered residual sums exist in the residual-only pass");
   static const int wgs = [] { const char *m = std::getenv("MHA_GRO_WGS"); return m ? std::atoi(m) : 0; }();
   const int nwg = wgs > 0 ? wgs : current_device_num_cus();
   // profiling aid (env MHA_GRO_TIMING=<file>): cycles every wavefront spent in each phase of the last launch
@@ -1530,7 +1536,7 @@ RowBlocksDev AssemblyManager::rowBlocksDev() const {
   return rb;
 }
 
-void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals) {
+void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals, bool deterministic) {
   const RowBlocksDev rb = rowBlocksDev();
   AffineDev af;
   af.khat = ro_.khat.data();
@@ -1552,6 +1558,18 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   thermal *th = dynamic_cast<thermal *>(physics_.get());
   MHA_REQUIRE(th != nullptr, MHA_ERR_INVALID, "row-owner path: physics module is not thermal");
   const ThermalDev ph = th->device_params();
+  if (deterministic) {
+    // MHA_ASSEMBLE_DETERMINISTIC: Jacobian rows as fixed-order register sums, residual entries summed in pair order by
+    // their owner (the general row-owner kernel, residual only) -- no atomics anywhere, one stream
+    MHA_REQUIRE(!compute_jacobian || bpat_.usable, MHA_ERR_INVALID,
+                "deterministic mode needs the block-pattern Jacobian kernel (" << bpat_.why << ")");
+    prepareGeneralRowOwner();
+    MHA_REQUIRE(gro_.usable, MHA_ERR_INVALID, "deterministic mode needs the general row-owner kernel: " << gro_.why);
+    if (overwrite && !gro_.all_rows_covered) MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
+    launchGeneralRowOwner(false, overwrite, res, nullptr, true);
+    if (compute_jacobian) launch_block_pattern_jacobian(bpat_.dev, out, ph.time.alpha_u * ph.diff.amp, ph.time.alpha_t * ph.rho.amp * ph.cp.amp, stream_);
+    return;
+  }
   // K1 accumulates the residual with atomics: the fused zeroing becomes a (small) memset
   if (overwrite) MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
   // K1 (residual, VALU-bound) and K2 (Jacobian, latency-bound) write different arrays: K2 goes first on the

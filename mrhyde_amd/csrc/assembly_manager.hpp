@@ -83,7 +83,7 @@ class AssemblyManager {
   void requireReady(bool need_graph) const;
   void prepareRowOwner();
   bool rowOwnerUsable(std::string *why) const;
-  void launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals);
+  void launchRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals, bool deterministic = false);
   RowBlocksDev rowBlocksDev() const;
   BlockDev blockDev() const;
   void bindState(const double *u, const double *u_prev, const double *u_stage);
@@ -170,7 +170,7 @@ class AssemblyManager {
   } gro_;
   void prepareGeneralRowOwner();
   RowBlocksDev generalRowBlocksDev() const;
-  void launchGeneralRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals);
+  void launchGeneralRowOwner(bool compute_jacobian, bool overwrite, double *res, double *crs_vals, bool ordered = false);
   // row blocks keyed by assembly pattern: the matrix-core form of K2 (block_pattern.hpp); !usable -> the row-block kernel
   struct BlockPatternData {
     bool tried = false, usable = false;

@@ -248,6 +248,7 @@ struct RowOut {
   double *vals = nullptr;
   int overwrite = 0;         // 1: store (fuses the caller's zeroing), 0: accumulate
   int compute_jacobian = 1;
+  int ordered = 0;           // general row-owner kernel, residual-only: pair sums in pair order (deterministic mode)
 };
 
 }  // namespace mha

@@ -508,7 +508,10 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
         // residual entry of the pair: sum over the four lane groups; the global vector receives -res.val() (scatterRes)
         rp += __shfl_xor(rp, 16);
         rp += __shfl_xor(rp, 32);
-        if (g4 == 0 && pmine < NP && !(dbg & 2)) atomicAdd(&racc[o], -rp);
+        if (g4 == 0 && pmine < NP && !(dbg & 2)) {
+          if (!JAC && out.ordered) acc[pmine] = -rp;  // deterministic mode: the row's owner sums its pairs in pair order below
+          else atomicAdd(&racc[o], -rp);
+        }
         // D register u: row (lane>>4) + 4u, column lane&15 -> entry slot[pair][LID position of column dof]
         if constexpr (JAC) {
 #pragma unroll
@@ -564,8 +567,13 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
     }
     for (int i = tid - NT / 2; i >= 0 && i < NR; i += NT / 2) {
       const int rr = s_rows[i];
-      const double v = racc[i];
+      double v = racc[i];
       racc[i] = 0.0;
+      if (!jac && out.ordered) {  // pair order is fixed by the host partition: the sum is bit-reproducible
+        v = 0.0;
+        for (int p = 0; p < NP; ++p)
+          if ((int)(s_pairs[p] >> 16) == i) v += acc[p];
+      }
       if (rr < 0) { if (out.overwrite) out.res[~rr] = 0.0; }  // fixed rows are skipped by the scatter
       else out.res[rr] = out.overwrite ? v : out.res[rr] + v;
     }

@@ -19,11 +19,11 @@ SRC = os.path.join(ROOT, "gpurun_out", "r2_traffic")
 ASSEMBLY_KERNELS = ("thermal_affine_residual_kernel", "block_pattern_jacobian_kernel", "thermal_general_row_owner_kernel",
                     "row_owner_jacobian", "thermal_affine_element", "thermal_general_element_kernel", "row_gather_kernel",
                     "point_engine_kernel", "porous_element_kernel", "fillBufferAligned")
-CASES = {  # case -> (dominant kernel, algorithmic bytes per element, elements, label)
-    "config2": ("block_pattern_jacobian_kernel", 6564, 64 ** 3, "config 2, affine 64^3 thermal Q2: thermal_affine_residual + block_pattern_jacobian"),
-    "config2_perturbed": ("thermal_general_row_owner_kernel", 6564, 64 ** 3, "config 2 mesh perturbed: thermal_general_row_owner (one launch)"),
-    "config3": ("row_gather_kernel", None, 128 ** 3, "config 3, 128^3 porousMixed: porous_element + row_gather"),
-    "config4": ("row_gather_kernel", None, 64 ** 3, "config 4, 64^3 navierstokes Q2/Q1: point_engine + row_gather"),
+CASES = {  # case -> (dominant kernel, algorithmic bytes per element, elements, label, key and path of bench.py)
+    "config2": ("block_pattern_jacobian_kernel", 6564, 64 ** 3, "config 2, affine 64^3 thermal Q2: thermal_affine_residual + block_pattern_jacobian", "config2_affine", "row_owner"),
+    "config2_perturbed": ("thermal_general_row_owner_kernel", 6564, 64 ** 3, "config 2 mesh perturbed: thermal_general_row_owner (one launch)", "config2_perturbed", "row_owner"),
+    "config3": ("row_gather_kernel", 724, 128 ** 3, "config 3, 128^3 porousMixed: porous_element + row_gather", "config3_affine", "row_gather"),
+    "config4": ("row_gather_kernel", 65340, 64 ** 3, "config 4, 64^3 navierstokes Q2/Q1: point_engine + row_gather", "config4_affine", "row_gather"),
 }
 
 
@@ -45,7 +45,7 @@ def counter_sum(case, counter):
 
 def main():
     out = {"_doc": __doc__.strip().split("\n\n")[1].replace("\n", " ")}
-    for case, (dom, bpe, nelem, label) in CASES.items():
+    for case, (dom, bpe, nelem, label, key, path) in CASES.items():
         try:
             f_tot, f_k, f_c = counter_sum(case, "FETCH_SIZE")
             w_tot, w_k, w_c = counter_sum(case, "WRITE_SIZE")
@@ -55,14 +55,14 @@ def main():
         n = w_c[dom]
         assert f_c[dom] == n, (case, f_c, w_c)
         fetch, write = f_tot * 1024.0 / n, w_tot * 1024.0 / n
-        rec = {"path": label, "assemblies_profiled": n, "fetch_bytes_raw": fetch, "write_bytes": write,
+        rec = {"path": path, "kernels": label, "assemblies_profiled": n, "fetch_bytes_raw": fetch, "write_bytes": write,
                "hbm_bytes_low": fetch + write, "hbm_bytes_per_assembly": 2.0 * fetch + write,
                "per_kernel_kb_per_assembly": {k: {"FETCH_SIZE": f_k.get(k, 0.0) / n, "WRITE_SIZE": w_k.get(k, 0.0) / n}
                                               for k in sorted(set(f_k) | set(w_k))}}
         if bpe:
             rec["algorithmic_bytes"] = bpe * nelem
             rec["real_over_algorithmic"] = [rec["hbm_bytes_low"] / (bpe * nelem), rec["hbm_bytes_per_assembly"] / (bpe * nelem)]
-        out[case] = rec
+        out[key] = rec
     json.dump(out, open(os.path.join(ROOT, "profiles", "r2_traffic.json"), "w"), indent=1, sort_keys=True)
     for name in ("config2", "config2_perturbed"):
         fs = glob.glob(os.path.join(SRC, "stats_" + name, "*", "*kernel_stats.csv"))

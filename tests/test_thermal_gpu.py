@@ -725,3 +725,64 @@ def test_mixed_bcs_deck_strings(oracle):
 
     err = solve_mixed_bcs(assemble, oracle)
     assert "%.6g" % err == "%.6g" % _gold_l2("thermal_2D_mixed_bcs.gold") == "0.00102733"
+
+
+@pytest.mark.parametrize("transient", [False, True])
+def test_deterministic_mode_is_bit_reproducible(oracle, transient):
+    """MHA_ASSEMBLE_DETERMINISTIC: two assemblies of the same state give bit-identical residual and Jacobian (fixed-order
+    register sums for the CRS rows, pair-ordered sums by the row's owner for the residual: no atomics anywhere), and the
+    result is the oracle's to 1e-12.  A second, different state in between guards against a cached result.  Where the
+    combination of kernels does not exist (non-affine elements) the flag is refused."""
+    torch = _torch()
+    import mrhyde_amd
+    dim, order, qdeg, ncell = 3, 2, 4, (10, 9, 7)
+    m = affine_mesh(oracle, dim, order, ncell)
+    rng = np.random.default_rng(41)
+    nd = m["ndof"]
+    u = rng.uniform(-1, 1, nd)
+    fixed = m["boundary"]
+    tr, kw, okw = None, {}, {}
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+    if transient:
+        A, bb, bdf = np.array([[0.5, 0.0], [0.3, 0.7]]), np.array([0.4, 0.6]), np.array([1.5, -2.0, 0.5])
+        tr = dict(u_prev=rng.uniform(-1, 1, (nd, 2)), u_stage=rng.uniform(-1, 1, (nd, 2)), stage=1, butcher_A=A, butcher_b=bb,
+                  bdf=bdf, dt=0.05)
+        okw = dict(transient=tr, rho=1.3, cp=0.7)
+        kw = dict(u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]))
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed, diff=1.7,
+                                  source=("sinprod", 3.0, [2.0, 1.0, 1.5]), **okw)
+    blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+    blk.set_function("thermal source", ("sinprod", 3.0, [2.0, 1.0, 1.5]))
+    blk.set_function("thermal diffusion", 1.7)
+    if transient:
+        blk.set_function("density", 1.3)
+        blk.set_function("specific heat", 0.7)
+        blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+    runs = []
+    for k in range(3):
+        uu = u if k != 1 else rng.uniform(-1, 1, nd)
+        res = torch.full((nd,), float(k), dtype=torch.float64, device="cuda")
+        vals = torch.full((len(ref["colind"]),), -float(k), dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(t(uu), res, vals, overwrite=True, deterministic=True, **kw)
+        torch.cuda.synchronize()
+        runs.append((res.clone(), vals.clone()))
+    assert blk.info("last_path") == mrhyde_amd.PATH_ROW_OWNER and blk.info("row_owner_kind") == 1
+    assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][1], runs[2][1])
+    assert not torch.equal(runs[0][0], runs[1][0])
+    assert rel_err(runs[0][1].cpu().numpy(), ref["crs_vals"]) < RTOL
+    assert rel_err(runs[0][0].cpu().numpy(), ref["res"]) < RTOL
+    # residual-only, accumulate on top
+    res = runs[0][0].clone()
+    blk.assemble_jacres(t(u), res, None, compute_jacobian=False, deterministic=True, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(res.cpu().numpy(), 2 * ref["res"]) < RTOL
+    # the default mode agrees to rounding
+    res2, vals2 = torch.zeros_like(res), torch.zeros_like(runs[0][1])
+    blk.assemble_jacres(t(u), res2, vals2, overwrite=True, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(res2.cpu().numpy(), runs[0][0].cpu().numpy()) < 1e-13
+    mp = perturbed(oracle, dim, order, (3, 3, 3), seed=2)
+    blk2 = make_block(mp, dim, order, qdeg)
+    with pytest.raises(mrhyde_amd.MhaError):
+        blk2.assemble_jacres(t(np.zeros(mp["ndof"])), torch.zeros(mp["ndof"], dtype=torch.float64, device="cuda"),
+                             torch.zeros(blk2.get_graph()[1].shape[0], dtype=torch.float64, device="cuda"), deterministic=True)
