@@ -197,6 +197,38 @@ int mha_compute_local_jacres(mha_context *ctx, int compute_jacobian, const doubl
  * every variable of the block (HGRAD / HVOL values, HDIV vector values); masswts_host[num_vars] or NULL (= 1).
  * mha_scatter_local turns them into CRS values.                                                          */
 int mha_get_mass(mha_context *ctx, const double *masswts_host, double *local_mass_dev);
+/* ---- mass storage and the matrix-free mass apply ----------------------------------------------------------------
+ * Sparse3DView (src/tools/sparse3DView.hpp:21-161): compressed storage of dense element matrices dense_dev[E][n][n]:
+ * the entries with |a| / max|a| > tol, row by row in column order.  Device-resident; mha_sparse3d_views returns
+ * values_dev[E][n][maxent] (f64), columns_dev[E][n][maxent] (int32, local column = position in the element's LID list)
+ * and nnz_row_dev[E][n] (int32) -- getValues / getColumns / getNNZPerRow; mha_sparse3d_size = size().  Stateless.   */
+typedef struct mha_sparse3d mha_sparse3d;
+int mha_sparse3d_create(int64_t num_elems, int n, const double *dense_dev, double tol, void *hip_stream, mha_sparse3d **out);
+int mha_sparse3d_views(mha_sparse3d *s, int *maxent, double **values_dev, int32_t **columns_dev, int32_t **nnz_row_dev);
+int mha_sparse3d_size(mha_sparse3d *s, int64_t *total_nnz);
+void mha_sparse3d_destroy(mha_sparse3d *s);
+/* The basis database (AssemblyManager::identifyVolumetricDatabase, assemblyManager.cpp:4314-4467): elements that share
+ * their geometry share one set of stored data (basis, mass).  The reference scans earlier representatives and accepts
+ * relative differences below "database TOL" (1e-10) in measure and Jacobians; here the match is EXACT -- bit-identical
+ * vertex offsets from the element's first vertex and identical orientation signs (found by hashing: O(E), not O(E U)),
+ * which is the subset of the reference's matches that substitutes nothing: results are unchanged to rounding.
+ * Representatives are numbered in order of first appearance, as in the reference.  index_host[E] (basis_index),
+ * first_users_host[num_unique] (element id of every representative); either may be NULL.                          */
+int mha_database_build(mha_context *ctx, int *num_unique);
+int mha_database_get(mha_context *ctx, int32_t *index_host, int32_t *first_users_host);
+/* AssemblyManager::applyMassMatrixFree (assemblyManager.cpp:1582-1778): y_dev += M x_dev with M block diagonal by
+ * variable, never assembled.  masswts_host[num_vars] or NULL (= 1; physics->mass_wts).  mode:
+ *   MHA_MASS_ON_THE_FLY   basis and weights recomputed per element (the !storeMass branch :1607-1672); mass_dev, sparse NULL
+ *   MHA_MASS_LOCAL        mass_dev[E][n][n], e.g. from mha_get_mass (:1760-1772)
+ *   MHA_MASS_DATABASE     mass_dev[num_unique][n][n] of the database representatives + basis_index (:1730-1755)
+ *   MHA_MASS_DATABASE_SPARSE  the same in Sparse3DView storage (:1690-1726; "sparse mass format")
+ * masswts applies to MHA_MASS_ON_THE_FLY only (stored masses carry their weights, as in the reference).            */
+#define MHA_MASS_ON_THE_FLY 0
+#define MHA_MASS_LOCAL 1
+#define MHA_MASS_DATABASE 2
+#define MHA_MASS_DATABASE_SPARSE 3
+int mha_apply_mass_matrix_free(mha_context *ctx, int mode, const double *masswts_host, const double *mass_dev,
+                               mha_sparse3d *sparse, const double *x_dev, double *y_dev);
 /* replaces: scatterJac / scatterRes  assemblyManager.cpp:3882-3935, 3943-3978          */
 int mha_scatter_local(mha_context *ctx, const double *local_J_dev, const double *local_res_dev,
                       double *res_dev, double *crs_vals_dev);

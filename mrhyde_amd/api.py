@@ -26,7 +26,10 @@ EXPORTS = [
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
     "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense", "mha_set_function_expression", "mha_set_time", "mha_check_expression",
     "mha_add_flux_group", "mha_workset_compute_solution", "mha_workset_compute_residual",
+    "mha_sparse3d_create", "mha_sparse3d_views", "mha_sparse3d_size", "mha_sparse3d_destroy", "mha_database_build",
+    "mha_database_get", "mha_apply_mass_matrix_free",
 ]
+MASS_ON_THE_FLY, MASS_LOCAL, MASS_DATABASE, MASS_DATABASE_SPARSE = 0, 1, 2, 3
 SWH_INTERFACE, SWH_FARFIELD, SWH_SLIP = 0, 1, 2
 BASIS_HGRAD, BASIS_HVOL, BASIS_HDIV = 0, 1, 2
 PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3, "shallowwaterHybridized": 4}
@@ -96,6 +99,14 @@ def load_library():
         _lib.mha_workset_compute_solution.argtypes = [C.c_void_p] * 4
         _lib.mha_workset_compute_residual.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         _lib.mha_clear_boundary_groups.argtypes = [C.c_void_p]
+        _lib.mha_sparse3d_create.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        _lib.mha_sparse3d_views.argtypes = [C.c_void_p] * 5
+        _lib.mha_sparse3d_size.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_sparse3d_destroy.argtypes = [C.c_void_p]
+        _lib.mha_sparse3d_destroy.restype = None
+        _lib.mha_database_build.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_database_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_apply_mass_matrix_free.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         _lib.mha_num_boundary_groups.argtypes = [C.c_void_p]
         _lib.mha_assemble_boundary.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         _lib.mha_boundary_update.argtypes = [C.c_void_p, C.c_int]
@@ -204,6 +215,46 @@ class ScatterPlan:
             lib.mha_scatter_plan_destroy.argtypes = [C.c_void_p]
             lib.mha_scatter_plan_destroy.restype = None
             lib.mha_scatter_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sparse3D:
+    """Sparse3DView (src/tools/sparse3DView.hpp) of a CUDA tensor dense[E][n][n]; device-resident."""
+
+    def __init__(self, dense, tol):
+        E, n, n2 = dense.shape
+        assert n == n2 and dense.is_contiguous()
+        self._h = C.c_void_p()
+        self.num_elems, self.n = E, n
+        _check(load_library().mha_sparse3d_create(E, n, _ptr(dense), float(tol), None, C.byref(self._h)))
+        me, v, c, z = C.c_int(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(load_library().mha_sparse3d_views(self._h, C.byref(me), C.byref(v), C.byref(c), C.byref(z)))
+        self.maxent, self._values, self._columns, self._nnz = me.value, v.value, c.value, z.value
+
+    def size(self):
+        t = C.c_int64()
+        _check(load_library().mha_sparse3d_size(self._h, C.byref(t)))
+        return t.value
+
+    def numpy(self):
+        """(values[E][n][maxent], columns[E][n][maxent], nnz_row[E][n]) copied to the host."""
+        import torch
+        torch.cuda.synchronize()
+        E, n, me = self.num_elems, self.n, max(self.maxent, 1)
+        vals, cols, nnz = np.zeros((E, n, me)), np.zeros((E, n, me), np.int32), np.zeros((E, n), np.int32)
+        for arr, ptr in ((vals, self._values), (cols, self._columns), (nnz, self._nnz)):
+            assert _hip_memcpy_dtoh(arr.ctypes.data, ptr, arr.size * arr.itemsize) == 0
+        return vals[:, :, :self.maxent], cols[:, :, :self.maxent], nnz
+
+    def close(self):
+        if self._h:
+            load_library().mha_sparse3d_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -433,6 +484,21 @@ class Block:
         _check(load_library().mha_swhdg_element_blocks(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(lam),
                                                        _ptr(side_types), None if ff is None else ff.ctypes.data_as(C.c_void_p),
                                                        _ptr(res), _ptr(blocks)))
+
+    def database_build(self):
+        """identifyVolumetricDatabase with exact matching -> (basis_index[E], first_users[U])."""
+        nu = C.c_int()
+        _check(load_library().mha_database_build(self._h, C.byref(nu)))
+        ne = self.info("num_elems")
+        idx, fu = np.zeros(ne, np.int32), np.zeros(nu.value, np.int32)
+        _check(load_library().mha_database_get(self._h, idx.ctypes.data_as(C.c_void_p), fu.ctypes.data_as(C.c_void_p)))
+        return idx, fu
+
+    def apply_mass_matrix_free(self, x, y, mode=MASS_ON_THE_FLY, masswts=None, mass=None, sparse=None):
+        """y += M x (AssemblyManager::applyMassMatrixFree); mass: CUDA tensor of dense element / database masses, sparse: Sparse3D."""
+        w = None if masswts is None else _np(masswts, np.float64)
+        _check(load_library().mha_apply_mass_matrix_free(self._h, mode, None if w is None else w.ctypes.data_as(C.c_void_p),
+                                                         _ptr(mass), None if sparse is None else sparse._h, _ptr(x), _ptr(y)))
 
     def scatter_local(self, local_J, local_res, res, crs_vals):
         _check(load_library().mha_scatter_local(self._h, _ptr(local_J), _ptr(local_res), _ptr(res), _ptr(crs_vals)))

@@ -1,5 +1,8 @@
 #include "assembly_manager.hpp"
 
+#include <cstring>
+#include <unordered_map>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -183,11 +186,13 @@ void AssemblyManager::buildVarLayout() {
 void AssemblyManager::setOrientation(const int8_t *signs) {
   MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "mha_set_orientation before mha_set_mesh");
   has_orient_ = signs != nullptr;
-  if (!signs) { d_orient_.resize(0); return; }
+  if (!signs) { d_orient_.resize(0); h_orient_.clear(); db_index_.clear(); return; }
   const size_t cnt = static_cast<size_t>(nelem_) * n_;
   for (size_t k = 0; k < cnt; ++k)
     MHA_REQUIRE(signs[k] == 1 || signs[k] == -1, MHA_ERR_INVALID, "orientation signs must be +1 or -1");
   d_orient_.upload(signs, cnt);
+  h_orient_.assign(signs, signs + cnt);
+  db_index_.clear();
 }
 
 void AssemblyManager::prepareRowGather(bool need_jacobian) {
@@ -592,6 +597,81 @@ void AssemblyManager::computeLocalJacRes(int compute_jacobian, const double *u, 
     physics_->volumeResidual();
   }
   timedEnd();
+}
+
+// reference: identifyVolumetricDatabase (assemblyManager.cpp:4314-4467) with exact matching: key = the vertex offsets
+// from the element's first vertex (bit patterns) + the orientation signs; representatives in order of first appearance
+int AssemblyManager::databaseBuild() {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  std::vector<double> nodes(static_cast<size_t>(nelem_) * nnodes_ * dim_);
+  d_nodes_.download(nodes.data());
+  const size_t kd = static_cast<size_t>(nnodes_ - 1) * dim_, ko = has_orient_ ? static_cast<size_t>(n_) : 0;
+  const size_t kb = kd * sizeof(double) + ko;
+  std::unordered_map<std::string, int32_t> seen;
+  seen.reserve(1024);
+  db_index_.assign(nelem_, 0);
+  db_first_users_.clear();
+  std::string key(kb, '\0');
+  std::vector<double> rel(kd);
+  for (int e = 0; e < nelem_; ++e) {
+    const double *xn = nodes.data() + static_cast<size_t>(e) * nnodes_ * dim_;
+    for (int v = 1; v < nnodes_; ++v)
+      for (int d = 0; d < dim_; ++d) {
+        double r = xn[v * dim_ + d] - xn[d];
+        if (r == 0.0) r = 0.0;  // -0.0 and +0.0 are the same offset
+        rel[static_cast<size_t>(v - 1) * dim_ + d] = r;
+      }
+    std::memcpy(&key[0], rel.data(), kd * sizeof(double));
+    if (ko) std::memcpy(&key[kd * sizeof(double)], h_orient_.data() + static_cast<size_t>(e) * n_, ko);
+    auto it = seen.find(key);
+    if (it == seen.end()) {
+      it = seen.emplace(key, static_cast<int32_t>(db_first_users_.size())).first;
+      db_first_users_.push_back(e);
+    }
+    db_index_[e] = it->second;
+  }
+  d_db_index_.upload(db_index_);
+  return static_cast<int>(db_first_users_.size());
+}
+
+void AssemblyManager::databaseGet(int32_t *index, int32_t *first_users) const {
+  MHA_REQUIRE(!db_index_.empty(), MHA_ERR_STATE, "no database: call mha_database_build first");
+  if (index) std::copy(db_index_.begin(), db_index_.end(), index);
+  if (first_users) std::copy(db_first_users_.begin(), db_first_users_.end(), first_users);
+}
+
+// reference: AssemblyManager::applyMassMatrixFree (assemblyManager.cpp:1582-1778)
+void AssemblyManager::applyMassMatrixFree(int mode, const double *masswts, const double *mass, int maxent,
+                                          const int32_t *nnz_row, const double *values, const int32_t *columns,
+                                          const double *x, double *y) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  MHA_REQUIRE(x && y, MHA_ERR_INVALID, "null vector");
+  BlockDev b = blockDev();
+  b.e_begin = 0;
+  b.e_count = nelem_;
+  VarLayoutDev vl = layout_;
+  vl.orient = has_orient_ ? d_orient_.data() : nullptr;
+  if (mode == MHA_MASS_ON_THE_FLY) {
+    launch_mass_apply_free(b, vl, masswts, x, y, stream_);
+    return;
+  }
+  const bool db = mode == MHA_MASS_DATABASE || mode == MHA_MASS_DATABASE_SPARSE;
+  MHA_REQUIRE(mode == MHA_MASS_LOCAL || db, MHA_ERR_INVALID, "unknown mass mode " << mode);
+  MHA_REQUIRE(!db || !db_index_.empty(), MHA_ERR_STATE, "database mass needs mha_database_build first");
+  if (mode == MHA_MASS_DATABASE_SPARSE) {
+    MHA_REQUIRE(values && columns && nnz_row, MHA_ERR_INVALID, "sparse mass format needs a Sparse3DView");
+    if (d_pos_var_.size() != static_cast<size_t>(n_)) {  // variable of every LID position (Sparse3DView::setLocalColumns)
+      std::vector<int32_t> offs(n_), pv(n_, 0);
+      d_offsets_.download(offs.data());
+      for (int v = 0; v < layout_.nvars; ++v)
+        for (int j = layout_.varptr[v]; j < layout_.varptr[v + 1]; ++j) pv[offs[j]] = v;
+      d_pos_var_.upload(pv);
+    }
+  } else {
+    MHA_REQUIRE(mass != nullptr, MHA_ERR_INVALID, "stored mass is null");
+  }
+  launch_mass_apply_stored(b, vl, db ? d_db_index_.data() : nullptr, mode == MHA_MASS_DATABASE_SPARSE ? nullptr : mass,
+                           maxent, nnz_row, values, columns, d_pos_var_.data(), x, y, stream_);
 }
 
 // reference: AssemblyManager::getMass / getWeightedMass (assemblyManager.cpp:7776-7925): dense element mass matrices,

@@ -43,6 +43,11 @@ class AssemblyManager {
   void computeLocalJacRes(int compute_jacobian, const double *u, const double *u_prev, const double *u_stage,
                           double *local_J, double *local_res);
   void getMass(const double *masswts, double *local_mass);
+  // basis database with exact-geometry matching, matrix-free mass apply (assemblyManager.cpp:4314-4467, 1582-1778)
+  int databaseBuild();
+  void databaseGet(int32_t *index, int32_t *first_users) const;
+  void applyMassMatrixFree(int mode, const double *masswts, const double *mass, int maxent, const int32_t *nnz_row,
+                           const double *values, const int32_t *columns, const double *x, double *y);
   void swhdgElementBlocks(const double *u, const double *u_prev, const double *u_stage, const double *lambda,
                           const uint8_t *side_types, const double *farfield, double *res, double *blocks);
   void scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals);
@@ -184,6 +189,9 @@ class AssemblyManager {
   } bpat_;
   void prepareBlockPattern();
 
+  std::vector<int32_t> db_index_, db_first_users_;  // basis database: representative of every element, their element ids
+  DeviceBuffer<int32_t> d_db_index_, d_pos_var_;
+  std::vector<int8_t> h_orient_;
   // per-variable views (multi-variable blocks): reference tables at the volume / side points, physical basis arrays
   struct VarTables { DeviceBuffer<double> val, grad, div; bool ready = false; };
   struct VarViews { DeviceBuffer<double> basis, grad, div; };

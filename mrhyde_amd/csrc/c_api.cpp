@@ -387,6 +387,90 @@ struct mha_scatter_plan {
   std::unique_ptr<mha::ScatterPlan> plan;
 };
 
+// ---- Sparse3DView, database, matrix-free mass apply -------------------------------------------------------------
+struct mha_sparse3d {
+  int64_t num_elems = 0;
+  int n = 0, maxent = 0;
+  mha::DeviceBuffer<double> values;
+  mha::DeviceBuffer<int32_t> columns, nnz_row;
+};
+
+int mha_sparse3d_create(int64_t num_elems, int n, const double *dense_dev, double tol, void *hip_stream, mha_sparse3d **out) {
+  return guarded([&] {
+    MHA_REQUIRE(out && dense_dev && num_elems > 0 && n > 0, MHA_ERR_INVALID, "bad Sparse3DView input");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    std::unique_ptr<mha_sparse3d> s(new mha_sparse3d());
+    s->num_elems = num_elems;
+    s->n = n;
+    const size_t rows = static_cast<size_t>(num_elems) * n;
+    mha::DeviceBuffer<unsigned long long> maxbits(1);
+    mha::DeviceBuffer<int> maxent(1);
+    MHA_HIP(hipMemsetAsync(maxbits.data(), 0, sizeof(unsigned long long), st));
+    MHA_HIP(hipMemsetAsync(maxent.data(), 0, sizeof(int), st));
+    s->nnz_row.resize(rows);
+    mha::launch_sparse3d_max(dense_dev, rows * n, maxbits.data(), st);
+    mha::launch_sparse3d_count(dense_dev, rows, n, tol, maxbits.data(), s->nnz_row.data(), maxent.data(), st);
+    MHA_HIP(hipStreamSynchronize(st));
+    maxent.download(&s->maxent);
+    const size_t cnt = std::max<size_t>(1, rows * static_cast<size_t>(s->maxent));
+    s->values.resize(cnt);
+    s->columns.resize(cnt);
+    MHA_HIP(hipMemsetAsync(s->values.data(), 0, cnt * sizeof(double), st));
+    MHA_HIP(hipMemsetAsync(s->columns.data(), 0, cnt * sizeof(int32_t), st));
+    if (s->maxent > 0) mha::launch_sparse3d_fill(dense_dev, rows, n, tol, maxbits.data(), s->maxent, s->values.data(), s->columns.data(), st);
+    MHA_HIP(hipStreamSynchronize(st));
+    *out = s.release();
+  });
+}
+
+int mha_sparse3d_views(mha_sparse3d *s, int *maxent, double **values_dev, int32_t **columns_dev, int32_t **nnz_row_dev) {
+  return guarded([&] {
+    MHA_REQUIRE(s != nullptr, MHA_ERR_INVALID, "null Sparse3DView");
+    if (maxent) *maxent = s->maxent;
+    if (values_dev) *values_dev = s->values.data();
+    if (columns_dev) *columns_dev = s->columns.data();
+    if (nnz_row_dev) *nnz_row_dev = s->nnz_row.data();
+  });
+}
+
+int mha_sparse3d_size(mha_sparse3d *s, int64_t *total_nnz) {
+  return guarded([&] {
+    MHA_REQUIRE(s && total_nnz, MHA_ERR_INVALID, "null argument");
+    std::vector<int32_t> h(s->nnz_row.size());
+    s->nnz_row.download(h.data());
+    int64_t t = 0;
+    for (int32_t v : h) t += v;
+    *total_nnz = t;
+  });
+}
+
+void mha_sparse3d_destroy(mha_sparse3d *s) { delete s; }
+
+int mha_database_build(mha_context *ctx, int *num_unique) {
+  return guarded([&] {
+    const int nu = mgr(ctx).databaseBuild();
+    if (num_unique) *num_unique = nu;
+  });
+}
+
+int mha_database_get(mha_context *ctx, int32_t *index_host, int32_t *first_users_host) {
+  return guarded([&] { mgr(ctx).databaseGet(index_host, first_users_host); });
+}
+
+int mha_apply_mass_matrix_free(mha_context *ctx, int mode, const double *masswts_host, const double *mass_dev,
+                               mha_sparse3d *sparse, const double *x_dev, double *y_dev) {
+  return guarded([&] {
+    mha::AssemblyManager &m = mgr(ctx);
+    if (mode == MHA_MASS_DATABASE_SPARSE) {
+      MHA_REQUIRE(sparse != nullptr, MHA_ERR_INVALID, "sparse mass format needs a Sparse3DView");
+      m.applyMassMatrixFree(mode, masswts_host, nullptr, sparse->maxent, sparse->nnz_row.data(), sparse->values.data(),
+                            sparse->columns.data(), x_dev, y_dev);
+    } else {
+      m.applyMassMatrixFree(mode, masswts_host, mass_dev, 0, nullptr, nullptr, nullptr, x_dev, y_dev);
+    }
+  });
+}
+
 int mha_scatter_plan_create(int n, int64_t num_elems, int64_t num_rows, const int32_t *lids_host,
                             const int32_t *rowptr_host, const int32_t *colind_host, const uint8_t *fixed_host,
                             mha_scatter_plan **out) {

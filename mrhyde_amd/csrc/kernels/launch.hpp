@@ -35,6 +35,18 @@ void launch_thermal_general_row_owner(int dim, int order, int nq1, const BlockDe
                                       const double *gp1d, const int32_t *blk_hdr, long long *timing, const RowOut &out,
                                       int num_cus, hipStream_t stream);
 
+// mass_apply.hip: applyMassMatrixFree (on the fly / stored dense / database / Sparse3DView) and Sparse3DView's constructor
+void launch_mass_apply_free(const BlockDev &b, const VarLayoutDev &vl, const double *masswts, const double *x, double *y,
+                            hipStream_t stream);
+void launch_mass_apply_stored(const BlockDev &b, const VarLayoutDev &vl, const int32_t *index, const double *mass, int maxent,
+                              const int32_t *nnz_row, const double *values, const int32_t *columns, const int32_t *pos_var,
+                              const double *x, double *y, hipStream_t stream);
+void launch_sparse3d_max(const double *dense, size_t total, unsigned long long *maxbits, hipStream_t stream);
+void launch_sparse3d_count(const double *dense, size_t rows, int n, double tol, const unsigned long long *maxbits,
+                           int32_t *nnz_row, int *maxent, hipStream_t stream);
+void launch_sparse3d_fill(const double *dense, size_t rows, int n, double tol, const unsigned long long *maxbits, int maxent,
+                          double *values, int32_t *columns, hipStream_t stream);
+
 // var_views.hip: per-variable basis views (volume range e0.. when elem == null, else boundary entries), solution
 // fields of the current workset, PhysicsInterface::fluxConditions, and a[i] = -a[i]
 void launch_var_views(const BlockDev &b, const VarPointsDev &t, const int32_t *elem, const int32_t *side, int e0, int num,

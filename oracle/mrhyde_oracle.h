@@ -306,6 +306,21 @@ void orc_swh_interface_flux(int dim, int side_type, int roe, const double *S, co
  * Uses dim (2), qdeg, orders, nelem, nodes, lids, offsets, u, the time-integration data and params {g, Roe} of `a`. */
 int orc_swh_hdg_element(const orc_block_args *a, const double *lambda, const unsigned char *side_types,
                         const double *farfield, double *blocks, double *res);
+/* AssemblyManager::applyMassMatrixFree (assemblyManager.cpp:1582-1778): y += M x, M block diagonal by variable.
+ * _free: basis recomputed per element (the !storeMass branch); _stored: dense element mass, optionally of the
+ * element's database representative (index[e]); _sparse: the same through Sparse3DView storage.                     */
+int orc_apply_mass_matrix_free(const orc_block_args *a, const double *masswts, const double *x, double *y);
+int orc_apply_mass_stored(int nelem, int n_tot, int nvars, const int *varptr, const int *offsets, const int *lids,
+                          const int *index, const double *mass, const double *x, double *y);
+/* Sparse3DView(denseview, tol) (src/tools/sparse3DView.hpp:32-92); call with values == NULL to size (maxent)        */
+int orc_sparse3d(int nelem, int n, const double *dense, double tol, int *maxent, int *nnz_row, double *values, int *columns);
+int orc_apply_mass_sparse(int nelem, int n_tot, int nvars, const int *varptr, const int *offsets, const int *lids,
+                          const int *index, int maxent, const int *nnz_row, const double *values, const int *columns,
+                          const double *x, double *y);
+/* identifyVolumetricDatabase (assemblyManager.cpp:4314-4467): first-match scan with orientation / measure / Jacobian
+ * checks at tolerance tol; returns the number of representatives                                                    */
+int orc_identify_database(const orc_block_args *a, double tol, int *index, int *first_users);
+
 /* PhysicsInterface::fluxConditions (physicsInterface.cpp:1702-1762) + scatterRes for one variable of a boundary group:
  * res[LIDs(elem, off(dof))] -= sum_pt -flux(k,pt) wts(k,pt) basis(k,dof,pt,0); flux[nb][nqs], wts[nb][nqs],
  * basis[nb][card][nqs][ncomp], off[card], fixed rows skipped                                                  */

@@ -1073,3 +1073,165 @@ int orc_flux_condition(int nb, int card, int nqs, int ncomp, const int *belem, c
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* applyMassMatrixFree, Sparse3DView, the basis database                     */
+/* ------------------------------------------------------------------------ */
+
+/* AssemblyManager::applyMassMatrixFree, the !storeMass branch (assemblyManager.cpp:1607-1672): per element and variable
+ * massval(i,j) = sum_k basis(e,i,k,:) . basis(e,j,k,:) wts(e,k) mwt, y(LIDs(e,off(i))) += massval x(LIDs(e,off(j))) --
+ * the basis recomputed per element (getPhysicalVolumetricBasis), sequential (no atomics).  y is accumulated into.     */
+int orc_apply_mass_matrix_free(const orc_block_args *a, const double *masswts, const double *x, double *y) {
+  blk_ctx c;
+  if (ctx_init(&c, a)) return -1;
+  const int n = c.n_tot, nq = c.nq, dim = a->dim;
+  for (size_t e = 0; e < (size_t)a->nelem; ++e) {
+    const double *xn = a->nodes + e * c.nn * dim;
+    const int *L = a->lids + e * n;
+    for (int v = 0; v < a->nvars; ++v)
+      orc_physical_basis_var(dim, a->types[v], a->orders[v], a->qdeg, 1, xn, a->orient ? a->orient + e * n : NULL, 0,
+                             c.varptr[v], c.basis[v], c.grad[v], c.div[v], v == 0 ? c.wts : NULL, NULL);
+    for (int v = 0; v < a->nvars; ++v) {
+      const int card = c.varptr[v + 1] - c.varptr[v], nc = ncomp_of(dim, a->types[v]);
+      const double mwt = masswts ? masswts[v] : 1.0;
+      const int *off = a->offsets + c.varptr[v];
+      for (int i = 0; i < card; ++i)
+        for (int j = 0; j < card; ++j) {
+          double massval = 0.0;
+          for (int k = 0; k < nq; ++k)
+            for (int d = 0; d < nc; ++d)
+              massval += c.basis[v][((size_t)i * nq + k) * nc + d] * c.basis[v][((size_t)j * nq + k) * nc + d] * c.wts[k] * mwt;
+          y[L[off[i]]] += massval * x[L[off[j]]];
+        }
+    }
+  }
+  ctx_free(&c);
+  return 0;
+}
+
+/* The stored-mass branches (assemblyManager.cpp:1674-1772): dense per-element mass (index == NULL) or the database mass
+ * of the element's representative (index[e]), only the (var, var) blocks:
+ *   y(LIDs(e,off(var,i))) += mass(eindex, off(var,i), off(var,j)) x(LIDs(e,off(var,j))).                            */
+int orc_apply_mass_stored(int nelem, int n_tot, int nvars, const int *varptr, const int *offsets, const int *lids,
+                          const int *index, const double *mass, const double *x, double *y) {
+  for (size_t e = 0; e < (size_t)nelem; ++e) {
+    const int *L = lids + e * n_tot;
+    const double *M = mass + (size_t)(index ? index[e] : (int)e) * n_tot * n_tot;
+    for (int v = 0; v < nvars; ++v)
+      for (int i = varptr[v]; i < varptr[v + 1]; ++i)
+        for (int j = varptr[v]; j < varptr[v + 1]; ++j)
+          y[L[offsets[i]]] += M[(size_t)offsets[i] * n_tot + offsets[j]] * x[L[offsets[j]]];
+  }
+  return 0;
+}
+
+/* Sparse3DView(denseview, tol) (src/tools/sparse3DView.hpp:32-92): entries with |a|/max|a| > tol are kept, row by row,
+ * in column order.  First call with values == NULL returns maxent; nnz_row[E][n], values / columns [E][n][maxent].  */
+int orc_sparse3d(int nelem, int n, const double *dense, double tol, int *maxent, int *nnz_row, double *values, int *columns) {
+  double maxval = 0.0;
+  const size_t tot = (size_t)nelem * n * n;
+  for (size_t k = 0; k < tot; ++k)
+    if (fabs(dense[k]) > maxval) maxval = fabs(dense[k]);
+  int me = 0;
+  for (size_t r = 0; r < (size_t)nelem * n; ++r) {
+    int nnz = 0;
+    for (int j = 0; j < n; ++j)
+      if (fabs(dense[r * n + j]) / maxval > tol) ++nnz;
+    if (nnz_row) nnz_row[r] = nnz;
+    if (nnz > me) me = nnz;
+  }
+  *maxent = me;
+  if (!values || !columns) return 0;
+  for (size_t r = 0; r < (size_t)nelem * n; ++r) {
+    int prog = 0;
+    for (int j = 0; j < n; ++j)
+      if (fabs(dense[r * n + j]) / maxval > tol) {
+        columns[r * me + prog] = j;
+        values[r * me + prog] = dense[r * n + j];
+        ++prog;
+      }
+  }
+  return 0;
+}
+
+/* Sparse3DView::setLocalColumns + the sparse branch of applyMassMatrixFree (sparse3DView.hpp:128-146,
+ * assemblyManager.cpp:1690-1726): local_columns(e,row,k) = j with offsets(var,j) == columns(e,row,k);
+ * y(LIDs(elem,localrow)) += values(eindex,localrow,k) x(LIDs(elem, offsets(var, local_columns(eindex,localrow,k)))). */
+int orc_apply_mass_sparse(int nelem, int n_tot, int nvars, const int *varptr, const int *offsets, const int *lids,
+                          const int *index, int maxent, const int *nnz_row, const double *values, const int *columns,
+                          const double *x, double *y) {
+  for (size_t e = 0; e < (size_t)nelem; ++e) {
+    const int *L = lids + e * n_tot;
+    const size_t ei = (size_t)(index ? index[e] : (int)e);
+    for (int v = 0; v < nvars; ++v)
+      for (int i = varptr[v]; i < varptr[v + 1]; ++i) {
+        const int localrow = offsets[i];
+        for (int k = 0; k < nnz_row[ei * n_tot + localrow]; ++k) {
+          const int col = columns[(ei * n_tot + localrow) * maxent + k];
+          int lc = -1; /* setLocalColumns: only columns of the same variable are found */
+          for (int j = varptr[v]; j < varptr[v + 1]; ++j)
+            if (offsets[j] == col) lc = j;
+          if (lc < 0) continue; /* the reference leaves local_columns 0 there; with block-diagonal mass it never happens */
+          y[L[localrow]] += values[(ei * n_tot + localrow) * maxent + k] * x[L[offsets[lc]]];
+        }
+      }
+  }
+  return 0;
+}
+
+/* AssemblyManager::identifyVolumetricDatabase (assemblyManager.cpp:4314-4467): elements in order; an element joins the
+ * first earlier representative with (1) the same orientation, (2) |measure - ref| / ref < tol, (3) at every
+ * integration point ||J - J_ref||_F / ||J||_F <= tol; otherwise it becomes a representative.  index[E]; returns the
+ * number of representatives (first_users[] receives their element ids, capacity nelem).                            */
+int orc_identify_database(const orc_block_args *a, double tol, int *index, int *first_users) {
+  int n1, nq, nn;
+  if (orc_ref_sizes(a->dim, 1, a->qdeg, &n1, &nq, &nn)) return -1;
+  const int dim = a->dim;
+  int n_tot = 0;
+  for (int v = 0; v < a->nvars; ++v) n_tot += orc_basis_card(dim, a->types[v], a->orders[v]);
+  double *rip = malloc(sizeof(double) * nq * dim), *rw = malloc(sizeof(double) * nq);
+  double *rb1 = malloc(sizeof(double) * n1 * nq), *rg1 = malloc(sizeof(double) * n1 * nq * dim);
+  double *nv = malloc(sizeof(double) * nn * nq), *ng = malloc(sizeof(double) * nn * nq * dim);
+  orc_ref_tables(dim, 1, a->qdeg, rip, rw, rb1, rg1, nv, ng);
+  const size_t js = (size_t)nq * dim * dim;
+  double *jac = malloc(sizeof(double) * (size_t)a->nelem * js), *meas = malloc(sizeof(double) * a->nelem);
+  for (size_t e = 0; e < (size_t)a->nelem; ++e) {
+    const double *xn = a->nodes + e * nn * dim;
+    meas[e] = 0.0;
+    for (int q = 0; q < nq; ++q) {
+      double *J = jac + e * js + (size_t)q * dim * dim, Ji[9], det;
+      for (int r = 0; r < dim; ++r)
+        for (int c2 = 0; c2 < dim; ++c2) {
+          double s = 0.0;
+          for (int v = 0; v < nn; ++v) s += xn[v * dim + r] * ng[(v * nq + q) * dim + c2];
+          J[r * dim + c2] = s;
+        }
+      jac_inv_det(dim, J, Ji, &det);
+      meas[e] += rw[q] * det;
+    }
+  }
+  int nu = 0;
+  for (int e = 0; e < a->nelem; ++e) {
+    int found = -1;
+    for (int p = 0; p < nu && found < 0; ++p) {
+      const int r = first_users[p];
+      if (a->orient && memcmp(a->orient + (size_t)e * n_tot, a->orient + (size_t)r * n_tot, n_tot)) continue;
+      if (!(fabs((meas[e] - meas[r]) / meas[r]) < tol)) continue;
+      int ruled_out = 0;
+      for (int q = 0; q < nq && !ruled_out; ++q) {
+        double fronorm = 0.0, frodiff = 0.0;
+        for (int k = 0; k < dim * dim; ++k) {
+          const double je = jac[(size_t)e * js + (size_t)q * dim * dim + k], d = je - jac[(size_t)r * js + (size_t)q * dim * dim + k];
+          frodiff += d * d;
+          fronorm += je * je;
+        }
+        if (sqrt(frodiff) / sqrt(fronorm) > tol) ruled_out = 1;
+      }
+      if (!ruled_out) found = p;
+    }
+    if (found < 0) { found = nu; first_users[nu++] = e; }
+    index[e] = found;
+  }
+  free(rip); free(rw); free(rb1); free(rg1); free(nv); free(ng); free(jac); free(meas);
+  return nu;
+}

@@ -557,6 +557,78 @@ def get_mass(m, qdeg, masswts=None):
     return mass
 
 
+def _geom_args(m, qdeg, keep):
+    a = BlockArgs()
+    a.dim, a.qdeg, a.nvars = m["dim"], qdeg, len(m["types"])
+    for v, (t, o) in enumerate(zip(m["types"], m["orders"])):
+        a.types[v], a.orders[v] = int(t), int(o)
+    nodes = np.ascontiguousarray(m["nodes"], dtype=np.float64)
+    lids = np.ascontiguousarray(m["lids"], dtype=np.int32)
+    offsets = np.ascontiguousarray(m["offsets"], dtype=np.int32)
+    orient = np.ascontiguousarray(m["orient"], dtype=np.int8)
+    keep += [nodes, lids, offsets, orient]
+    a.nelem, a.nodes, a.lids, a.offsets = nodes.shape[0], _d(nodes), _i(lids), _i(offsets)
+    a.orient = orient.ctypes.data_as(_sp)
+    return a
+
+
+def apply_mass_matrix_free(m, qdeg, x, y, masswts=None):
+    """applyMassMatrixFree, !storeMass branch: y += M x with the basis recomputed per element."""
+    keep = []
+    a = _geom_args(m, qdeg, keep)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    w = None if masswts is None else np.ascontiguousarray(masswts, dtype=np.float64)
+    assert lib().orc_apply_mass_matrix_free(C.byref(a), _d(w), _d(x), _d(y)) == 0
+
+
+def apply_mass_stored(m, mass, x, y, index=None):
+    lids = np.ascontiguousarray(m["lids"], dtype=np.int32)
+    offsets = np.ascontiguousarray(m["offsets"], dtype=np.int32)
+    varptr = np.ascontiguousarray(m["varptr"], dtype=np.int32)
+    mass, x = np.ascontiguousarray(mass, dtype=np.float64), np.ascontiguousarray(x, dtype=np.float64)
+    idx = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+    E, n = lids.shape
+    assert lib().orc_apply_mass_stored(E, n, len(varptr) - 1, _i(varptr), _i(offsets), _i(lids),
+                                       None if idx is None else _i(idx), _d(mass), _d(x), _d(y)) == 0
+
+
+def sparse3d(dense, tol):
+    """Sparse3DView(denseview, tol) -> (values, columns, nnz_row, maxent)."""
+    dense = np.ascontiguousarray(dense, dtype=np.float64)
+    E, n, _ = dense.shape
+    me = C.c_int()
+    nnz = np.zeros((E, n), np.int32)
+    assert lib().orc_sparse3d(E, n, _d(dense), C.c_double(tol), C.byref(me), _i(nnz), None, None) == 0
+    vals, cols = np.zeros((E, n, max(me.value, 1))), np.zeros((E, n, max(me.value, 1)), np.int32)
+    if me.value:
+        assert lib().orc_sparse3d(E, n, _d(dense), C.c_double(tol), C.byref(me), _i(nnz), _d(vals), _i(cols)) == 0
+    return vals[:, :, :me.value], cols[:, :, :me.value], nnz, me.value
+
+
+def apply_mass_sparse(m, values, columns, nnz_row, x, y, index=None):
+    lids = np.ascontiguousarray(m["lids"], dtype=np.int32)
+    offsets = np.ascontiguousarray(m["offsets"], dtype=np.int32)
+    varptr = np.ascontiguousarray(m["varptr"], dtype=np.int32)
+    values, columns = np.ascontiguousarray(values, dtype=np.float64), np.ascontiguousarray(columns, dtype=np.int32)
+    nnz_row, x = np.ascontiguousarray(nnz_row, dtype=np.int32), np.ascontiguousarray(x, dtype=np.float64)
+    idx = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+    E, n = lids.shape
+    assert lib().orc_apply_mass_sparse(E, n, len(varptr) - 1, _i(varptr), _i(offsets), _i(lids),
+                                       None if idx is None else _i(idx), values.shape[2], _i(nnz_row), _d(values), _i(columns),
+                                       _d(x), _d(y)) == 0
+
+
+def identify_database(m, qdeg, tol=1e-10):
+    """identifyVolumetricDatabase: (basis_index[E], first_users[U]) by the reference's first-match scan."""
+    keep = []
+    a = _geom_args(m, qdeg, keep)
+    E = a.nelem
+    idx, fu = np.zeros(E, np.int32), np.zeros(E, np.int32)
+    nu = lib().orc_identify_database(C.byref(a), C.c_double(tol), _i(idx), _i(fu))
+    assert nu > 0
+    return idx, fu[:nu].copy()
+
+
 def assemble_block_boundary(m, physics, qdeg, u, belem, bside, bc_type, data, *, rowptr, colind, crs_vals, res,
                             funcs=None, params=None, fixed=None, transient=None, compute_jacobian=True, aux=None,
                             farfield=None):

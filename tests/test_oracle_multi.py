@@ -231,3 +231,50 @@ def test_flux_condition_of_the_oracle(oracle):
         oracle.flux_condition(belem, m["lids"], m["offsets"], np.ones_like(flux), sb["wts"], sb["basis"][..., None], one)
         total += one.sum()
     assert abs(total - 4.0) < 1e-13
+
+
+def test_mass_storage_and_database_restatements(oracle):
+    """Pins the oracle's restatements of Sparse3DView, identifyVolumetricDatabase and applyMassMatrixFree against each
+    other and against plain linear algebra (no GPU): the four ways of applying M agree, M x equals the assembled
+    (scipy) block mass matrix, the compressed storage reproduces the dense one above the threshold, and the database
+    of a mesh made of two element shapes has two representatives in order of first appearance."""
+    rng = np.random.default_rng(6)
+    H, V, D = oracle.HGRAD, oracle.HVOL, oracle.HDIV
+    for types, orders, dim, nc, qdeg in (([H], [2], 2, (4, 4), 4), ([V, D], [0, 1], 3, (4, 2, 2), 2)):
+        m = oracle.mesh_multi(dim, nc, types, orders)
+        # two element shapes, bitwise repeated: stretch the right half of the mesh in x by 1.5
+        v = m["verts"].copy()
+        right = v[:, 0] > 0.5
+        v[right, 0] = 0.5 + 1.5 * (v[right, 0] - 0.5)
+        m["verts"] = v
+        m["nodes"] = np.ascontiguousarray(v[m["cell2vert"]])
+        n, E = m["n_tot"], m["nelem"]
+        x = rng.uniform(-1, 1, m["ndof"])
+        w = [1.7, 0.6][:len(types)]
+        mass = oracle.get_mass(m, qdeg, w)
+        y0 = np.zeros(m["ndof"])
+        oracle.apply_mass_matrix_free(m, qdeg, x, y0, w)
+        rows = np.repeat(m["lids"], n, axis=1).ravel()
+        cols = np.tile(m["lids"], (1, n)).ravel()
+        M = sp.coo_matrix((mass.ravel(), (rows, cols)), shape=(m["ndof"],) * 2).tocsr()
+        assert np.abs(y0 - M @ x).max() < 1e-13 * np.abs(y0).max()
+        y1 = np.zeros(m["ndof"])
+        oracle.apply_mass_stored(m, mass, x, y1)
+        assert np.abs(y1 - y0).max() < 1e-13 * np.abs(y0).max()
+        idx, fu = oracle.identify_database(m, qdeg)
+        assert len(fu) == 2 and fu[0] == 0 and np.array_equal(np.unique(idx), [0, 1]) and idx[fu[1]] == 1
+        if D not in types:   # (orientation signs differ between HDIV elements of the same shape: more representatives)
+            assert np.all(np.abs(mass - mass[fu][idx]) < 1e-14)
+        y2 = np.zeros(m["ndof"])
+        oracle.apply_mass_stored(m, mass[fu], x, y2, index=idx)
+        assert np.abs(y2 - y0).max() < 1e-12 * np.abs(y0).max()
+        vals, cls, nnz, me = oracle.sparse3d(mass[fu], 1e-12)
+        assert me <= n and nnz.max() == me
+        dense = np.zeros_like(mass[fu])
+        for e in range(len(fu)):
+            for i in range(n):
+                dense[e, i, cls[e, i, :nnz[e, i]]] = vals[e, i, :nnz[e, i]]
+        assert np.abs(dense - mass[fu]).max() <= 1e-12 * np.abs(mass).max()
+        y3 = np.zeros(m["ndof"])
+        oracle.apply_mass_sparse(m, vals, cls, nnz, x, y3, index=idx)
+        assert np.abs(y3 - y0).max() < 1e-12 * np.abs(y0).max()

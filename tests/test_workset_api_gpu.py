@@ -289,3 +289,90 @@ def test_thermal_advection(oracle, dim, order, qdeg, ncell, transient):
     vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
     blk.assemble_jacres(t(u), res, vals, **kw)
     assert rel_err(vals.cpu().numpy(), plain["crs_vals"]) < RTOL
+
+
+MASS_CASES = [  # variable types, orders, dim, ncell, quadrature, physics
+    (["HGRAD"], [2], 2, (6, 4), 4, "thermal"),
+    (["HVOL", "HDIV"], [0, 1], 3, (4, 2, 3), 2, "porousMixed"),
+    (["HGRAD"] * 3, [2, 1, 2], 2, (4, 2), 4, "navierstokes"),
+]
+
+
+@pytest.mark.parametrize("tnames,orders,dim,ncell,qdeg,physics", MASS_CASES)
+def test_mass_matrix_free_database_and_sparse3d(oracle, tnames, orders, dim, ncell, qdeg, physics):
+    """AssemblyManager::applyMassMatrixFree in its four forms (assemblyManager.cpp:1582-1778), Sparse3DView
+    (sparse3DView.hpp:21-161) and the basis database (identifyVolumetricDatabase :4314-4467, exact matching) against the
+    oracle's restatements: a warped mesh for the on-the-fly / stored forms (HDIV with flipped signs), a mesh of two
+    bitwise-repeated element shapes for the database forms."""
+    torch = _torch()
+    import mrhyde_amd
+    rng = np.random.default_rng(81)
+    types = [getattr(oracle, t) for t in tnames]
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+    w = [1.7, 0.6, 1.2][:len(types)]
+
+    def block(m):
+        blk = mrhyde_amd.Block(dim, quadrature=qdeg, physics=physics, variables=list(zip([int(x) for x in types], orders)))
+        blk.set_mesh(m["nodes"], m["lids"], m["offsets"], m["ndof"])
+        blk.set_orientation(m["orient"])
+        return blk
+
+    # --- warped mesh: on the fly and stored element masses
+    m = warp(oracle.mesh_multi(dim, ncell, types, orders))
+    if oracle.HDIV in types:
+        flip_some_faces(m, rng, types.index(oracle.HDIV))
+    nd, n, E = m["ndof"], m["n_tot"], m["nelem"]
+    x, y0 = rng.uniform(-1, 1, nd), rng.uniform(-1, 1, nd)
+    want = y0.copy()
+    oracle.apply_mass_matrix_free(m, qdeg, x, want, w)
+    blk = block(m)
+    y = t(y0)
+    blk.apply_mass_matrix_free(t(x), y, mrhyde_amd.MASS_ON_THE_FLY, masswts=w)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), want) < RTOL
+    mass = torch.zeros((E, n, n), dtype=torch.float64, device="cuda")
+    blk.get_mass(mass, w)
+    y = t(y0)
+    blk.apply_mass_matrix_free(t(x), y, mrhyde_amd.MASS_LOCAL, mass=mass)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), want) < RTOL
+    with pytest.raises(mrhyde_amd.MhaError):       # database forms need the database
+        blk.apply_mass_matrix_free(t(x), y, mrhyde_amd.MASS_DATABASE, mass=mass)
+
+    # --- two element shapes, bitwise repeated (+ one perturbed element): database, dense and sparse.  Exact matching
+    # wants bitwise repeats: a mesh width that is a power of two (offsets like 1/6 differ in their last bits from
+    # element to element; the reference's 1e-10 tolerance would merge those, the exact database keeps them apart)
+    m = oracle.mesh_multi(dim, (8, 4) if dim == 2 else (4, 2, 2), types, orders)
+    nd, n, E = m["ndof"], m["n_tot"], m["nelem"]
+    x, y0 = rng.uniform(-1, 1, nd), rng.uniform(-1, 1, nd)
+    v = m["verts"].copy()
+    right = v[:, 0] > 0.5
+    v[right, 0] = 0.5 + 1.5 * (v[right, 0] - 0.5)
+    v[m["cell2vert"][E - 1][-1]] += 0.03           # the last vertex of the last element: one more shape
+    m["verts"] = v
+    m["nodes"] = np.ascontiguousarray(v[m["cell2vert"]])
+    blk = block(m)
+    idx, fu = blk.database_build()
+    oidx, ofu = oracle.identify_database(m, qdeg, 1e-10)
+    assert np.array_equal(idx, oidx) and np.array_equal(fu, ofu) and 2 < len(fu) <= 8
+    want = y0.copy()
+    oracle.apply_mass_matrix_free(m, qdeg, x, want, w)
+    mass = torch.zeros((E, n, n), dtype=torch.float64, device="cuda")
+    blk.get_mass(mass, w)
+    dbmass = mass[torch.tensor(fu.astype(np.int64), device="cuda")].contiguous()
+    y = t(y0)
+    blk.apply_mass_matrix_free(t(x), y, mrhyde_amd.MASS_DATABASE, mass=dbmass)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), want) < RTOL
+    s3 = mrhyde_amd.Sparse3D(dbmass, 1e-12)
+    ovals, ocols, onnz, ome = oracle.sparse3d(dbmass.cpu().numpy(), 1e-12)
+    vals, cols, nnz = s3.numpy()
+    assert s3.maxent == ome and np.array_equal(nnz, onnz) and s3.size() == int(onnz.sum())
+    keep = np.arange(ome)[None, None, :] < onnz[:, :, None]
+    assert np.array_equal(cols[keep], ocols[keep]) and np.array_equal(vals[keep], ovals[keep])
+    assert ome < n or len(types) == 1            # block-diagonal masses compress
+    y = t(y0)
+    blk.apply_mass_matrix_free(t(x), y, mrhyde_amd.MASS_DATABASE_SPARSE, sparse=s3)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), want) < RTOL
+    s3.close()
