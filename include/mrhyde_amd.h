@@ -359,6 +359,23 @@ int mha_swhdg_side_terms(int side_type, int roe_stabilization, double g, int64_t
 int mha_swhdg_element_blocks(mha_context *ctx, const double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
                              const double *lambda_dev, const uint8_t *side_types_dev, const double *farfield_host,
                              double *res_dev, double *blocks_dev);
+/* The subgrid sub-iteration loop: SubGridDtN_Solver::nonlinearSolver (src/subgrid/subgridDtN_solver.cpp:909-1041) with
+ * its assembleJacobianResidual (:681-903) and element-local direct solve, for a shallowwaterHybridized block whose interior
+ * unknowns are element-local (one HDG element per subgrid: every LID belongs to one element -- checked).  Per element,
+ * with the trace lambda held fixed: pass 0 records resnorm_initial = |res_u|_inf and sets the scaled norm to 1 (0 if the
+ * residual vanishes); while scaled > tol (sub_NLtol) and passes < max_iter (sub_maxNLiter): du = A_uu^-1 r_u,
+ * u += du, reassemble, scaled = |res_u|_inf / resnorm_initial.  u_dev is updated in place.  Outputs: iters_dev[E] =
+ * assemblies the element's loop performed (the reference's `iter`), resnorm_scaled_dev[E], and -- from one closing
+ * assembly at the final state -- schur_dev[E][24][24], gvec_dev[E][24] as mha_batched_condense defines them (either may
+ * be NULL: no closing pass), *num_singular_dev = singular interior blocks met.  Everything is enqueued on the context's
+ * stream: NO host synchronisation and NO allocation inside (workspace_dev of mha_swhdg_subgrid_workspace_bytes bytes is
+ * the caller's; side tables are built on the first call).  Elements that have converged are still swept by the remaining
+ * passes and ignored: the uniform schedule is what keeps the host out of the loop.                                   */
+int mha_swhdg_subgrid_workspace_bytes(mha_context *ctx, int64_t *bytes);
+int mha_swhdg_subgrid_solve(mha_context *ctx, double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
+                            const double *lambda_dev, const uint8_t *side_types_dev, const double *farfield_host,
+                            int max_iter, double tol, void *workspace_dev, int64_t workspace_bytes, double *schur_dev,
+                            double *gvec_dev, int32_t *iters_dev, double *resnorm_scaled_dev, int32_t *num_singular_dev);
 /* Batched static condensation of element blocks: eliminates the n_int interior unknowns of every element.
  * replaces: the element-local direct solve of the subgrid solver and its forward sensitivities d u / d lambda
  * (SubGridDtN_Solver, src/subgrid/subgridDtN_solver.cpp:681-903, 1542-1616) in Schur-complement form.

@@ -27,7 +27,7 @@ EXPORTS = [
     "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense", "mha_set_function_expression", "mha_set_time", "mha_check_expression",
     "mha_add_flux_group", "mha_workset_compute_solution", "mha_workset_compute_residual",
     "mha_sparse3d_create", "mha_sparse3d_views", "mha_sparse3d_size", "mha_sparse3d_destroy", "mha_database_build",
-    "mha_database_get", "mha_apply_mass_matrix_free",
+    "mha_database_get", "mha_apply_mass_matrix_free", "mha_swhdg_subgrid_workspace_bytes", "mha_swhdg_subgrid_solve",
 ]
 MASS_ON_THE_FLY, MASS_LOCAL, MASS_DATABASE, MASS_DATABASE_SPARSE = 0, 1, 2, 3
 SWH_INTERFACE, SWH_FARFIELD, SWH_SLIP = 0, 1, 2
@@ -105,6 +105,8 @@ def load_library():
         _lib.mha_sparse3d_destroy.argtypes = [C.c_void_p]
         _lib.mha_sparse3d_destroy.restype = None
         _lib.mha_database_build.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_swhdg_subgrid_workspace_bytes.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_swhdg_subgrid_solve.argtypes = ([C.c_void_p] * 7 + [C.c_int, C.c_double, C.c_void_p, C.c_int64] + [C.c_void_p] * 5)
         _lib.mha_database_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.mha_apply_mass_matrix_free.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         _lib.mha_num_boundary_groups.argtypes = [C.c_void_p]
@@ -499,6 +501,28 @@ class Block:
         w = None if masswts is None else _np(masswts, np.float64)
         _check(load_library().mha_apply_mass_matrix_free(self._h, mode, None if w is None else w.ctypes.data_as(C.c_void_p),
                                                          _ptr(mass), None if sparse is None else sparse._h, _ptr(x), _ptr(y)))
+
+    def swhdg_subgrid_solve(self, u, lam, max_iter, tol, side_types=None, farfield=None, u_prev=None, u_stage=None,
+                            want_condensed=True):
+        """SubGridDtN_Solver::nonlinearSolver on the device (u updated in place) -> dict(iters, resnorm, schur, gvec, num_singular).
+        No host synchronisation happens inside the call; the tensors are ready once the stream is."""
+        import torch
+        nb = C.c_int64()
+        _check(load_library().mha_swhdg_subgrid_workspace_bytes(self._h, C.byref(nb)))
+        E = lam.shape[0]
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=u.device)
+        out = dict(iters=torch.zeros(E, dtype=torch.int32, device=u.device), resnorm=torch.zeros(E, dtype=torch.float64, device=u.device),
+                   num_singular=torch.zeros(1, dtype=torch.int32, device=u.device))
+        if want_condensed:
+            out["schur"] = torch.zeros((E, 24, 24), dtype=torch.float64, device=u.device)
+            out["gvec"] = torch.zeros((E, 24), dtype=torch.float64, device=u.device)
+        ff = None if farfield is None else _np(farfield, np.float64)
+        _check(load_library().mha_swhdg_subgrid_solve(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(lam), _ptr(side_types),
+                                                      None if ff is None else ff.ctypes.data_as(C.c_void_p), int(max_iter),
+                                                      float(tol), _ptr(ws), nb.value, _ptr(out.get("schur")), _ptr(out.get("gvec")),
+                                                      _ptr(out["iters"]), _ptr(out["resnorm"]), _ptr(out["num_singular"])))
+        self._keep.append(ws)
+        return out
 
     def scatter_local(self, local_J, local_res, res, crs_vals):
         _check(load_library().mha_scatter_local(self._h, _ptr(local_J), _ptr(local_res), _ptr(res), _ptr(crs_vals)))

@@ -121,6 +121,7 @@ void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lid
   if (fixed) d_fixed_.upload(fixed, nrows);
   else d_fixed_.resize(0);
   has_mesh_ = true;
+  subgrid_checked_ = false;
   has_graph_ = false;
   // workset size <= 0 or larger than the block => one workset (reference: assemblyManager.cpp:326-332)
   const int ws = (workset_size_ <= 0 || workset_size_ > nelem_) ? nelem_ : workset_size_;
@@ -721,6 +722,64 @@ void AssemblyManager::swhdgElementBlocks(const double *u, const double *u_prev, 
   timedBegin();
   launch_swhdg_element(blockDev(), sideTablesDev(), a, time_, stream_);
   timedEnd();
+}
+
+// Workspace of subgridSolve (doubles unless noted): blocks [E][36][36], res [E][36], local_J [E][12][12], local_res
+// [E][12], du [E][12], rn0 [E], then int32 active [E].
+size_t AssemblyManager::subgridWorkspaceBytes() const {
+  const size_t E = static_cast<size_t>(nelem_), ni = static_cast<size_t>(n_), n = ni + 24;
+  return sizeof(double) * E * (n * n + n + ni * ni + ni + ni + 1) + sizeof(int32_t) * E + 64;
+}
+
+// The sub-iteration loop of the subgrid solver on the device: max_iter passes of
+//   side blocks (mha_swhdg_element_blocks) + volume block (mha_compute_local_jacres) -> combine + loop bookkeeping ->
+//   element-local solve (the condensation kernel's du = A_uu^-1 r_u) -> sol += du for the elements still iterating,
+// then one closing assembly + condensation at the final state for the Schur complement / condensed right-hand side the
+// macro trace system takes (updateFlux's sensitivities, :1542-1616).  Everything is enqueued on the context's stream:
+// no host synchronisation, no allocation (the caller provides the workspace).  An element leaves its loop when its
+// scaled residual norm drops to tol, exactly as the reference's while condition; the passes it no longer needs are
+// still computed for it and ignored (a uniform schedule is what keeps the host out of the loop).
+void AssemblyManager::subgridSolve(double *u, const double *u_prev, const double *u_stage, const double *lambda,
+                                   const uint8_t *side_types, const double *farfield, int max_iter, double tol,
+                                   void *workspace, size_t workspace_bytes, double *schur, double *gvec, int32_t *iters,
+                                   double *resnorm_scaled, int32_t *num_singular) {
+  requireReady(false);
+  MHA_REQUIRE(dynamic_cast<shallowwaterHybridized *>(physics_.get()) != nullptr, MHA_ERR_INVALID,
+              "the subgrid driver is built for shallowwaterHybridized blocks");
+  MHA_REQUIRE(u && lambda && workspace && iters && resnorm_scaled && num_singular, MHA_ERR_INVALID, "null argument");
+  MHA_REQUIRE(max_iter >= 1 && tol >= 0.0, MHA_ERR_INVALID, "bad iteration limits");
+  MHA_REQUIRE(workspace_bytes >= subgridWorkspaceBytes(), MHA_ERR_INVALID,
+              "workspace too small: " << workspace_bytes << " < " << subgridWorkspaceBytes());
+  if (!subgrid_checked_) {  // interior unknowns must be element-local (discontinuous): checked once per mesh
+    std::vector<char> seen(nrows_, 0);
+    for (size_t k = 0; k < h_lids_.size(); ++k) {
+      MHA_REQUIRE(!seen[h_lids_[k]], MHA_ERR_INVALID,
+                  "the subgrid driver needs element-local interior unknowns: row " << h_lids_[k] << " belongs to two elements");
+      seen[h_lids_[k]] = 1;
+    }
+    subgrid_checked_ = true;
+  }
+  const size_t E = static_cast<size_t>(nelem_), ni = static_cast<size_t>(n_), n = ni + 24;
+  double *blocks = static_cast<double *>(workspace);
+  double *res = blocks + E * n * n, *lJ = res + E * n, *lr = lJ + E * ni * ni, *du = lr + E * ni, *rn0 = du + E * ni;
+  int32_t *active = reinterpret_cast<int32_t *>(rn0 + E);
+  MHA_HIP(hipMemsetAsync(num_singular, 0, sizeof(int32_t), stream_));
+  auto assemble = [&](int pass) {
+    swhdgElementBlocks(u, u_prev, u_stage, lambda, side_types, farfield, res, blocks);
+    MHA_HIP(hipMemsetAsync(lJ, 0, sizeof(double) * E * (ni * ni + ni), stream_));  // local_J and local_res are contiguous
+    computeLocalJacRes(1, u, u_prev, u_stage, lJ, lr);
+    launch_subgrid_combine(nelem_, n_, static_cast<int>(n), d_offsets_.data(), lJ, lr, blocks, res, pass, tol, rn0,
+                           resnorm_scaled, iters, active, stream_);
+  };
+  for (int pass = 0; pass < max_iter; ++pass) {
+    assemble(pass);
+    launch_condense(n_, 24, nelem_, blocks, res, nullptr, nullptr, du, num_singular, stream_);
+    launch_subgrid_update(nelem_, n_, d_lids_.data(), d_offsets_.data(), du, active, u, stream_);
+  }
+  if (schur || gvec) {
+    assemble(-1);
+    launch_condense(n_, 24, nelem_, blocks, res, schur, gvec, nullptr, num_singular, stream_);
+  }
 }
 
 void AssemblyManager::scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals) {

@@ -50,6 +50,11 @@ class AssemblyManager {
                            const double *values, const int32_t *columns, const double *x, double *y);
   void swhdgElementBlocks(const double *u, const double *u_prev, const double *u_stage, const double *lambda,
                           const uint8_t *side_types, const double *farfield, double *res, double *blocks);
+  // SubGridDtN_Solver::nonlinearSolver for HDG elements with element-local interior unknowns (subgridDtN_solver.cpp:909-1041)
+  size_t subgridWorkspaceBytes() const;
+  void subgridSolve(double *u, const double *u_prev, const double *u_stage, const double *lambda, const uint8_t *side_types,
+                    const double *farfield, int max_iter, double tol, void *workspace, size_t workspace_bytes, double *schur,
+                    double *gvec, int32_t *iters, double *resnorm_scaled, int32_t *num_singular);
   void scatterLocal(const double *local_J, const double *local_res, double *res, double *crs_vals);
   // boundary groups (reference: src/tools/boundaryGroup.hpp, assemblyManager.cpp:2518-2638)
   int addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,
@@ -192,6 +197,7 @@ class AssemblyManager {
   std::vector<int32_t> db_index_, db_first_users_;  // basis database: representative of every element, their element ids
   DeviceBuffer<int32_t> d_db_index_, d_pos_var_;
   std::vector<int8_t> h_orient_;
+  bool subgrid_checked_ = false;
   // per-variable views (multi-variable blocks): reference tables at the volume / side points, physical basis arrays
   struct VarTables { DeviceBuffer<double> val, grad, div; bool ready = false; };
   struct VarViews { DeviceBuffer<double> basis, grad, div; };

@@ -313,6 +313,24 @@ int mha_batched_condense(int n_int, int n_trace, int64_t num_elems, const double
   });
 }
 
+int mha_swhdg_subgrid_workspace_bytes(mha_context *ctx, int64_t *bytes) {
+  return guarded([&] {
+    MHA_REQUIRE(bytes, MHA_ERR_INVALID, "null argument");
+    *bytes = static_cast<int64_t>(mgr(ctx).subgridWorkspaceBytes());
+  });
+}
+
+int mha_swhdg_subgrid_solve(mha_context *ctx, double *u, const double *u_prev, const double *u_stage, const double *lambda,
+                            const uint8_t *side_types, const double *farfield_host, int max_iter, double tol, void *workspace,
+                            int64_t workspace_bytes, double *schur, double *gvec, int32_t *iters, double *resnorm_scaled,
+                            int32_t *num_singular) {
+  return guarded([&] {
+    mgr(ctx).subgridSolve(u, u_prev, u_stage, lambda, side_types, farfield_host, max_iter, tol, workspace,
+                          static_cast<size_t>(std::max<int64_t>(workspace_bytes, 0)), schur, gvec, iters, resnorm_scaled,
+                          num_singular);
+  });
+}
+
 int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat, const double *normals, double *L, double *lam,
                           double *R, void *hip_stream) {
   return guarded([&] {

@@ -122,6 +122,13 @@ void launch_swhdg_element(const BlockDev &b, const SideTablesDev &st, const SwhE
 void launch_condense(int n_int, int n_trace, int64_t nelem, const double *blocks, const double *res, double *schur,
                      double *gvec, double *du, int *singular, hipStream_t stream);
 
+// subgrid.hip: loop state of the subgrid sub-iteration driver (SubGridDtN_Solver::nonlinearSolver)
+void launch_subgrid_combine(int64_t nelem, int ni, int n, const int32_t *offsets, const double *local_J, const double *local_res,
+                            double *blocks, double *res, int pass, double tol, double *rn0, double *scaled, int32_t *iters,
+                            int32_t *active, hipStream_t stream);
+void launch_subgrid_update(int64_t nelem, int ni, const int32_t *lids, const int32_t *offsets, const double *du,
+                           const int32_t *active, double *u, hipStream_t stream);
+
 // export.hip: pack / unpack-add of the shared-row Export(ADD) (export_plan.hpp)
 void launch_export_pack(const double *src, const int32_t *idx, int64_t n, double *dst, hipStream_t stream);
 void launch_export_unpack_add(const double *src, const int32_t *tgt, int64_t n, double *dst, hipStream_t stream);

@@ -760,3 +760,37 @@ def swh_hdg_element(m, qdeg, u, lam, side_types, farfield, g=9.81, roe=True, tra
     rc = lib().orc_swh_hdg_element(C.byref(a), _d(lam), _u(st), _d(ff), _d(blocks), _d(res))
     assert rc == 0, rc
     return res, blocks
+
+
+def subgrid_nonlinear_solver(m, qdeg, u, lam, side_types, farfield, max_iter, tol, g=9.81, roe=True, transient=None):
+    """SubGridDtN_Solver::nonlinearSolver (src/subgrid/subgridDtN_solver.cpp:909-1041) restated for subgrids of one HDG
+    element each (element-local interior unknowns), one independent loop per element:
+        while iter < sub_maxNLiter and resnorm_scaled > sub_NLtol:
+            assembleJacobianResidual (side blocks + volume block); iter 0: resnorm_initial = |res|_inf, scaled = 1 (0 if 0);
+            else scaled = |res|_inf / resnorm_initial; if scaled > tol: solve J du = res, sol += du; iter += 1
+    -> (u, iters[E], scaled[E]).  The element blocks come from the oracle's C restatements; the solve is numpy's."""
+    u = np.array(u, dtype=np.float64)
+    E = m["nelem"]
+    off = m["offsets"]
+    rows = m["lids"][:, off]                              # [E][12] flattened (variable, dof) -> global row
+    iters, scaled, rn0 = np.zeros(E, np.int32), np.full(E, 10.0 * tol), np.zeros(E)
+    inloop = np.ones(E, bool)
+    for it in range(max_iter):
+        if not inloop.any():
+            break
+        res, blk = swh_hdg_element(m, qdeg, u, lam, side_types, farfield, g=g, roe=roe, transient=transient)
+        vol = assemble_block(m, PHYS_SHALLOWWATER_HYBRIDIZED, qdeg, u, params=[g], transient=transient, want_local=True)
+        A = blk[:, :12, :12] + vol["local_J"][:, off][:, :, off]
+        r = res[:, :12] + vol["local_res"][:, off]
+        nrm = np.abs(r).max(axis=1)
+        for e in np.flatnonzero(inloop):
+            if it == 0:
+                rn0[e] = nrm[e]
+                scaled[e] = 1.0 if nrm[e] > 0.0 else 0.0
+            else:
+                scaled[e] = nrm[e] / rn0[e]
+            if scaled[e] > tol:
+                u[rows[e]] += np.linalg.solve(A[e], r[e])
+            iters[e] += 1
+            inloop[e] = scaled[e] > tol
+    return u, iters, scaled

@@ -328,3 +328,99 @@ def test_flux_to_trace_scatter(ncell):
     with pytest.raises(mrhyde_amd.MhaError, match="out of range"):
         mrhyde_amd.ScatterPlan(bad, nrows)
     plan.close()
+
+
+def dg_hdg_case(oracle, ncell, seed):
+    """hdg_case with element-local (discontinuous) interior unknowns: LIDs[e][i] = 12 e + i, as in a subgrid of one HDG
+    element per macro element."""
+    from test_multi_gpu import transient_state
+    from test_oracle_swhdg import hdg_case
+    m, u, lam, st, ff = hdg_case(oracle, ncell=ncell, seed=seed)
+    E = m["nelem"]
+    ue = u[m["lids"]]                                          # [E][12] in LID-position order
+    var_pos = m["dof_var"][m["lids"][0]]                      # variable of every LID position (same for all elements)
+    m["lids"] = np.arange(12 * E, dtype=np.int32).reshape(E, 12)
+    m["ndof"] = 12 * E
+    m["dof_var"] = np.tile(var_pos, E).astype(np.int32)
+    m["side_mask"] = np.zeros(12 * E, np.uint8)
+    u = ue.reshape(-1).copy()
+    rng = np.random.default_rng(seed + 100)
+    tr = transient_state(rng, m["ndof"], u)
+    tr["dt"] = 0.05 / max(ncell)   # a time step ~ h at which Newton on these random states converges (5x larger: most diverge)
+    for k in ("u_prev", "u_stage"):
+        tr[k][m["dof_var"] == 0] = rng.uniform(1.0, 2.0, ((m["dof_var"] == 0).sum(), 2))
+    return m, u, lam, st, ff, tr
+
+
+def run_subgrid(blk, torch, u, lam, st, ff, tr, max_iter, tol):
+    blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+    ud = torch.tensor(u, device="cuda")
+    out = blk.swhdg_subgrid_solve(ud, torch.tensor(lam, device="cuda"), max_iter, tol, side_types=torch.tensor(st, device="cuda"),
+                                  farfield=ff, u_prev=torch.tensor(tr["u_prev"], device="cuda"),
+                                  u_stage=torch.tensor(tr["u_stage"], device="cuda"))
+    torch.cuda.synchronize()
+    return ud.cpu().numpy(), {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def test_subgrid_sub_iteration_matches_oracle(oracle):
+    """SubGridDtN_Solver::nonlinearSolver on the device (side blocks -> volume block -> element-local solve -> update, a
+    fixed schedule of passes without host synchronisation) against the oracle's restatement of the loop: final interior
+    state, the reference's iteration count and scaled residual norm per element, and the condensed blocks at the final
+    state; shared interior unknowns are refused."""
+    torch = _torch()
+    import mrhyde_amd
+    from test_multi_gpu import make_block
+    m, u, lam, st, ff, tr = dg_hdg_case(oracle, (5, 4), 21)
+    max_iter, tol = 8, 1e-9
+    u_ref, it_ref, sc_ref = oracle.subgrid_nonlinear_solver(m, 2, u, lam, st, ff, max_iter, tol, g=7.3, transient=tr)
+    assert it_ref.max() < max_iter and it_ref.min() >= 2 and sc_ref.max() <= tol      # converged inside the budget
+    blk = make_block(m, "shallowwaterHybridized", 2)
+    blk.set_physics_parameter("g", 7.3)
+    u_gpu, out = run_subgrid(blk, torch, u, lam, st, ff, tr, max_iter, tol)
+    assert out["num_singular"][0] == 0
+    assert np.array_equal(out["iters"], it_ref)
+    assert np.abs(u_gpu - u_ref).max() < 1e-10 * np.abs(u_ref).max()
+    assert np.all(out["resnorm"] <= tol) and np.abs(out["resnorm"] - sc_ref).max() < 1e-3 * tol + 1e-6 * sc_ref.max()
+    # closing pass: Schur complement and condensed right-hand side at the final state
+    res, blk36 = oracle.swh_hdg_element(m, 2, u_ref, lam, st, ff, g=7.3, transient=tr)
+    vol = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, u_ref, params=[7.3], transient=tr, want_local=True)
+    off = m["offsets"]
+    blk36[:, :12, :12] += vol["local_J"][:, off][:, :, off]
+    res[:, :12] += vol["local_res"][:, off]
+    X = np.linalg.solve(blk36[:, :12, :12], np.concatenate([blk36[:, :12, 12:], res[:, :12, None]], axis=2))
+    S_ref = blk36[:, 12:, 12:] - blk36[:, 12:, :12] @ X[:, :, :24]
+    g_ref = res[:, 12:] - (blk36[:, 12:, :12] @ X[:, :, 24:])[..., 0]
+    assert np.abs(out["schur"] - S_ref).max() < 1e-9 * np.abs(S_ref).max()
+    assert np.abs(out["gvec"] - g_ref).max() < 1e-8 * max(np.abs(g_ref).max(), np.abs(res).max())
+    # one pass only: every element has done exactly one assembly and one update
+    u1, o1 = run_subgrid(blk, torch, u, lam, st, ff, tr, 1, tol)
+    u1_ref, it1, _ = oracle.subgrid_nonlinear_solver(m, 2, u, lam, st, ff, 1, tol, g=7.3, transient=tr)
+    assert np.all(o1["iters"] == 1) and np.array_equal(it1, o1["iters"]) and np.abs(u1 - u1_ref).max() < 1e-11 * np.abs(u1_ref).max()
+    # continuous (shared) interior unknowns are not a subgrid of independent elements
+    from test_oracle_swhdg import hdg_case
+    mc, uc, lamc, stc, ffc = hdg_case(oracle, ncell=(3, 2), seed=3)
+    blkc = make_block(mc, "shallowwaterHybridized", 2)
+    with pytest.raises(mrhyde_amd.MhaError, match="element-local"):
+        blkc.swhdg_subgrid_solve(torch.tensor(uc, device="cuda"), torch.tensor(lamc, device="cuda"), 2, tol)
+
+
+def test_subgrid_sub_iteration_at_config5_size(oracle):
+    """The driver at BASELINE.json's config-5 size (256^2 HDG elements): every element converges within the budget, and --
+    the elements being independent -- the first 48 of them agree with the oracle's loop run on those 48 alone."""
+    torch = _torch()
+    from test_multi_gpu import make_block
+    m, u, lam, st, ff, tr = dg_hdg_case(oracle, (256, 256), 33)
+    max_iter, tol = 8, 1e-9
+    blk = make_block(m, "shallowwaterHybridized", 2)
+    u_gpu, out = run_subgrid(blk, torch, u, lam, st, ff, tr, max_iter, tol)
+    assert out["num_singular"][0] == 0
+    assert out["iters"].max() < max_iter and out["iters"].min() >= 2 and np.all(out["resnorm"] <= tol)
+    assert np.all(np.isfinite(out["schur"])) and np.all(np.isfinite(out["gvec"]))
+    k = 48
+    sub = dict(m)
+    sub.update(nelem=k, ndof=12 * k, lids=m["lids"][:k].copy(), nodes=m["nodes"][:k].copy(), cell2vert=m["cell2vert"][:k].copy(),
+               orient=m["orient"][:k].copy(), dof_var=m["dof_var"][:12 * k].copy(), side_mask=m["side_mask"][:12 * k].copy())
+    trs = dict(tr, u_prev=tr["u_prev"][:12 * k].copy(), u_stage=tr["u_stage"][:12 * k].copy())
+    u_ref, it_ref, _ = oracle.subgrid_nonlinear_solver(sub, 2, u[:12 * k], lam[:k], st[:k], ff, max_iter, tol, transient=trs)
+    assert np.array_equal(out["iters"][:k], it_ref)
+    assert np.abs(u_gpu[:12 * k] - u_ref).max() < 1e-10 * np.abs(u_ref).max()
