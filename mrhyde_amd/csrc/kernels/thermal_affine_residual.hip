@@ -13,6 +13,10 @@
 // DIM x (order + 1)^DIM.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <mutex>
+#include <vector>
+
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -62,7 +66,11 @@ __device__ __forceinline__ void apply1d(double *v, const double *T) {
 template <int DIM, int P, bool TR, bool EXPR, bool SMALL>
 __global__ __launch_bounds__(kK1tThreads, 2) void thermal_affine_residual_kernel(BlockDev b, ThermalDev ph,
                                                                               const double *__restrict__ geo,
-                                                                              AffineTables1D tab, double *res, int dbg) {
+                                                                              const AffineTables1D *__restrict__ tabp, double *res, int dbg) {
+  // The 60 table entries are scalar operands of several hundred FMAs.  Passed by value they sat in 120 SGPRs for the
+  // whole kernel (with the other arguments: > 1000 SGPR spill instructions); behind a pointer the compiler fetches them
+  // through the scalar cache next to their uses.
+  const AffineTables1D &tab = *tabp;
   constexpr int M = P + 1, N = cpow(M, DIM);
   constexpr int GS = kGeoRec + 1;  // padded record stride (doubles): odd -> one record per lane without bank conflicts
   __shared__ int s_lid[kK1tThreads / 64][64 * N];
@@ -221,19 +229,56 @@ __global__ __launch_bounds__(kK1tThreads, 2) void thermal_affine_residual_kernel
   apply1d<DIM, M, 1, false>(W, tab.phi);
   if constexpr (DIM == 3) apply1d<DIM, M, DIM - 1, false>(W, tab.phi);
   // the global vector receives -res.val(); fixed rows are skipped (assemblyManager.cpp:4075, 4094)
-  if (active && !(dbg & 1)) {
+  // Consecutive lanes are consecutive elements; when those are x-neighbours (element numbering x fastest -- any mesh
+  // where that holds for most of a wavefront) the left face nodes of lane l are the right face nodes of lane l-1: the
+  // two contributions are added in registers (DPP shuffles) and leave as ONE atomic, a third fewer atomics for Q2 hexes.
+  // Decided from the LIDs themselves, so a mesh without that structure simply merges nothing.
+  int rowv[N];
+#pragma unroll
+  for (int ib = 0; ib < N; ++ib) rowv[ib] = active ? L[b.offsets[ib]] : -2 - lane;
+  if (!(dbg & 8)) {
+#pragma unroll
+    for (int il = 0; il < N; il += M) {  // dof index x fastest: il = (0, iy, iz), ir = (M-1, iy, iz)
+      const int ir = il + M - 1;
+      const int prow = __shfl_up(rowv[ir], 1);
+      const double pw = __shfl_up(W[ir], 1);
+      const bool take = lane > 0 && prow == rowv[il];
+      if (take) W[il] += pw;
+      const int given = __shfl_down((int)take, 1);
+      if (lane < 63 && given) rowv[ir] = -1;  // the next lane carries this node
+    }
+  }
+  if (!(dbg & 1)) {
 #pragma unroll
     for (int ib = 0; ib < N; ++ib) {
-      const int row = L[b.offsets[ib]];
-      if (!(b.fixed && b.fixed[row])) atomicAdd(res + row, -W[ib]);
+      const int row = rowv[ib];
+      if (row >= 0 && !(b.fixed && b.fixed[row])) atomicAdd(res + row, -W[ib]);
     }
   }
 }
 
+// device copy of a table, made once per (device, content) and kept for the life of the process
+const AffineTables1D *device_copy(const AffineTables1D &tab) {
+  struct Entry { int device; AffineTables1D host; AffineTables1D *dev; };
+  static std::mutex mu;
+  static std::vector<Entry> cache;
+  int device = 0;
+  MHA_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Entry &e : cache)
+    if (e.device == device && std::memcmp(&e.host, &tab, sizeof(AffineTables1D)) == 0) return e.dev;
+  AffineTables1D *d = nullptr;
+  MHA_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(AffineTables1D)));
+  MHA_HIP(hipMemcpy(d, &tab, sizeof(AffineTables1D), hipMemcpyHostToDevice));
+  cache.push_back({device, tab, d});
+  return d;
+}
+
 template <int DIM, int P>
-void launch_t(const BlockDev &b, const ThermalDev &ph, const double *geo, const AffineTables1D &tab, double *res,
+void launch_t(const BlockDev &b, const ThermalDev &ph, const double *geo, const AffineTables1D &tab_host, double *res,
               bool small_args, hipStream_t stream) {
   if (b.e_count <= 0) return;
+  const AffineTables1D *tab = device_copy(tab_host);
   const int grid = (b.e_count + kK1tThreads - 1) / kK1tThreads;  // a wavefront takes 64 consecutive elements
   const bool tr = ph.time.transient != 0;
   static const int dbg = [] { const char *m = std::getenv("MHA_K1_DBG"); return m ? std::atoi(m) : 0; }();  // profiling aid: 1 no atomics, 2 general source evaluation, 4 no gather
