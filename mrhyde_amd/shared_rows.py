@@ -204,15 +204,20 @@ class SharedRowExport:
                 sv, sr, _, _ = self._t[k]
                 self._send[k][:len(sv)] = vals[sv] if vals is not None else 0.0
                 self._send[k][len(sv):] = res[sr]
-        staged = self._on_gpu and dist.get_backend() == "gloo"  # rehearsal of N>1 on one GPU: gloo moves host buffers
+        # The plan's buffers are the library's (seen by torch through __cuda_array_interface__).  gloo (rehearsal of N > 1
+        # on one GPU) moves host copies; RCCL moves torch-owned device copies of the few MB involved -- collectives on
+        # memory the caching allocator does not own are legal but have never run on hardware here, and a device copy costs
+        # microseconds (MHA_EXPORT_ZERO_COPY=1 hands the library's buffers to RCCL directly).
+        gloo = self._on_gpu and dist.get_backend() == "gloo"
+        staged = self._on_gpu and (gloo or os.environ.get("MHA_EXPORT_ZERO_COPY", "0") != "1")
         ops, keep = [], []
         for k in self.neighbors:
             if len(self._send[k]):
-                b = self._send[k].cpu() if staged else self._send[k]
+                b = (self._send[k].cpu() if gloo else self._send[k].clone()) if staged else self._send[k]
                 keep.append(b)
                 ops.append(dist.P2POp(dist.isend, b, k))
             if len(self._recv[k]):
-                b = self._recv[k].cpu() if staged else self._recv[k]
+                b = (self._recv[k].cpu() if gloo else torch.empty_like(self._recv[k])) if staged else self._recv[k]
                 keep.append((k, b))
                 ops.append(dist.P2POp(dist.irecv, b, k))
         for w in dist.batch_isend_irecv(ops):
