@@ -395,8 +395,8 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
               if (tile % NWV != wv) continue;
               const bool cb = c0 + l15 < cardj;
               v4d d = {0.0, 0.0, 0.0, 0.0};
-              if (dbg_stop == 7) {  // profiling: no products, the stores only
-              } else if (nsj == 4 && NQ % 9 == 0) {
+              if (!EXPR && dbg_stop == 7) {  // profiling (plain-coefficient instantiations only: the deck-string ones are at their scratch limit): no products, the stores only
+              } else if (!EXPR && nsj == 4 && NQ % 9 == 0) {  // (the deck-string instantiations keep the plain loop: they are at their scratch limit)
                 // one point per MFMA (k = slot).  Operands of nine points are requested before the first product and the
                 // products alternate between two accumulators: the loop used to be a chain of 27 dependent MFMAs, each
                 // waiting for its own two LDS reads (a wave has one tile per panel: nothing else hides that latency) --
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
                   d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, d, 0, 0, 0);
                 }
               }
-              if (dbg_stop == 6) {  // profiling: products only (kept alive), no stores
+              if (!EXPR && dbg_stop == 6) {  // profiling: products only (kept alive), no stores
                 if (d[0] + d[1] + d[2] + d[3] == 1.2345e300 && lj_e) lj_e[0] = 1.0;
               } else if (cb) {
                 const int j = vl.varptr[vj] + c0 + l15, pos_j = s_pos[j];
