@@ -1472,6 +1472,16 @@ void AssemblyManager::prepareBlockPattern() {
   if (std::getenv("MHA_VERBOSE"))
     fprintf(stderr, "[mrhyde_amd] block patterns: usable %d (%s), %d patterns, %d roles, %d parts, %d workgroups, %lld MFMAs per assembly\n",
             int(h.usable), h.why.c_str(), h.num_patterns, h.num_roles, h.num_parts, h.num_wgs, (long long)h.mfma_per_assembly);
+  if (std::getenv("MHA_VERBOSE") && h.usable) {  // shapes of the units: (k-steps, tiles, tail, trim class) -> count
+    std::map<std::vector<int>, int> shapes;
+    for (int p = 0; p < h.num_parts; ++p) {
+      const int32_t *hd = h.part_hdr.data() + static_cast<size_t>(p) * kBpHdrInts;
+      shapes[{hd[1], hd[5], (hd[6] >> 1) & 1, (hd[6] >> 2) & 7, hd[6] & 1}]++;
+    }
+    for (const auto &kv : shapes)
+      fprintf(stderr, "[mrhyde_amd]   units ks %d tiles %d tail %d trim %d fixed %d: %d\n", kv.first[0], kv.first[1], kv.first[2],
+              kv.first[3], kv.first[4], kv.second);
+  }
   if (!h.usable) return;
   bp.num_patterns = h.num_patterns;
   bp.num_roles = h.num_roles;

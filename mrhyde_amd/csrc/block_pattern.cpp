@@ -1,6 +1,9 @@
 // block_pattern.cpp -- see block_pattern.hpp.
 #include "block_pattern.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -18,7 +21,7 @@ namespace {
 enum { R_EREC_LO = 0, R_EREC_HI, R_ESTRIDE, R_ROWB_LO, R_ROWB_HI, R_NRUNS, R_NBLOCKS, R_COST, R_WOFF_LO, R_WOFF_HI,
        R_WDOUBLES, R_PATTERN, R_NELEMS };
 // part header (kBpHdrInts ints)
-enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_CT0, H_NTILE, H_FLAGS, H_CLASS, H_MASK0, H_MASK1, H_MASK2 };  // flags: 1 rows of fixed dofs, 2 a plain tail tile follows the group
+enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_CT0, H_NTILE, H_FLAGS, H_CLASS, H_MASK0, H_MASK1, H_MASK2 };  // flags: 1 rows of fixed dofs, 2 a plain tail tile follows the group, 4 / 8 trim class (see the mask loop)
 
 uint64_t fnv1a(const std::vector<uint8_t> &b) {
   uint64_t h = 1469598103934665603ull;
@@ -306,6 +309,37 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
               const int bit = sidx * 5 + q;
               if (any) hdr[H_MASK0 + bit / 32] |= static_cast<int32_t>(1u << (bit % 32));
             }
+          // trim class of the unit (flags bits 2..4, read by the kernel's specialised forms): all column tiles but the
+          // last (classes 1, 3) or but the first (2, 4) have only zero blocks in the second (1, 4) or first (2, 3) half
+          // of the k-steps
+          const int nq = pb.ntile + pb.tail;
+          if (nq >= 2 && rc.ks >= 2) {
+            bool t[5] = {false, true, true, true, true};
+            for (int sidx = 0; sidx < rc.ks; ++sidx)
+              for (int q = 0; q < nq; ++q) {
+                const int bit = sidx * 5 + q;
+                const bool nz = (static_cast<uint32_t>(hdr[H_MASK0 + bit / 32]) >> (bit % 32)) & 1u;
+                if (!nz) continue;
+                const bool second = sidx >= rc.ks / 2;
+                if (q < nq - 1 && second) t[1] = false;
+                if (q >= 1 && !second) t[2] = false;
+                if (q < nq - 1 && !second) t[3] = false;
+                if (q >= 1 && second) t[4] = false;
+              }
+            for (int k = 1; k <= 4; ++k)
+              if (t[k]) { hdr[H_FLAGS] |= k << 2; break; }
+            if (std::getenv("MHA_BP_PRINT")) {  // debugging aid: the zero-block mask of every unit
+              fprintf(stderr, "unit ks %d ct0 %d nq %d:", rc.ks, pb.ct0, nq);
+              for (int sidx = 0; sidx < rc.ks; ++sidx) {
+                fprintf(stderr, " ");
+                for (int q = 0; q < nq; ++q) {
+                  const int bit = sidx * 5 + q;
+                  fprintf(stderr, "%d", (static_cast<uint32_t>(hdr[H_MASK0 + bit / 32]) >> (bit % 32)) & 1u);
+                }
+              }
+              fprintf(stderr, "\n");
+            }
+          }
         }
         pl.part_hdr.insert(pl.part_hdr.end(), hdr, hdr + kBpHdrInts);
         const size_t base = pl.part_lane.size();

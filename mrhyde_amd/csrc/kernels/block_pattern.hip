@@ -103,6 +103,7 @@ struct UnitCtx {
   int ct0;                 // first column tile of the unit
   const double *Wl;        // this lane's corner of the class's W image in LDS
   unsigned mask[3];        // bit s * 5 + q: the W block of k-step s, tile q of the unit is not zero
+  int trim;                // trim class of the unit (host: flags 4 / 8), wave-uniform
   double *recbuf;          // LDS: two images of a block's element records, recstride doubles apart
   int recstride;
   long long *tlog;         // profiling (DBG & 8): 8 wall-clock stamps of this wavefront
@@ -135,7 +136,13 @@ constexpr int kRecLoads = 8;  // 64-lane loads of 8 bytes per block: (T + 1) * 8
 // barrier once per block: the rows of a block reach the memory together.  The loader's record fetches are inline asm
 // (hipcc does not track them; gfx950 counts loads and stores in one in-order vmcnt) retired with a counted s_waitcnt
 // that leaves the current block's stores in flight.
-template <int KS, int NT, bool TAIL, int DBG>
+// TRIM = 3: k-steps whose W block is zero for a whole group of column tiles are not multiplied.  The columns of a row are
+// sorted by global id and so are a block's elements: around a vertex dof of a hex mesh one half of the k-steps (four of
+// the eight elements) reaches only the first ~5 column tiles and the other half only the last ~5, so in a unit of four
+// tiles three tiles see zero blocks during one half of the k-steps (56 -> 35 products for the 14 x 4 units).  The host
+// classifies the unit (c.trim: 1..4 = which tiles, which half; block_pattern.cpp), wave-uniform; the conditions below
+// fold to one scalar test per product after unrolling.
+template <int KS, int NT, bool TAIL, int DBG, int TRIM = 0>
 __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__restrict__ L, int lane, bool loader) {
   constexpr int NPK = (KS + 1) / 2;
   constexpr int NQ = NT + (TAIL ? 1 : 0);                 // accumulation chains
@@ -224,8 +231,16 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
       const double a = rec[aoff(s)];
       if constexpr (!(DBG & 4)) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)  // (skipping the zero 4 x 16 blocks of W -- c.mask, a quarter of them -- costs a branch per
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c.Wl[(4 * s) * stride + 16 * q], acc[q], 0, 0, 0);  // product and spills)
+        for (int q = 0; q < NQ; ++q) {
+          // TRIM 3: the class is a run-time (wave-uniform) value: one instantiation serves the trimmed and the full units
+          const bool second = s >= KS / 2;
+          const int mbit = s * 5 + q;  // a constant after unrolling: the mask word stays in a scalar register
+          const unsigned mw = mbit < 32 ? c.mask[0] : (mbit < 64 ? c.mask[1] : c.mask[2]);
+          const bool zero_block = (TRIM == 3 && ((c.trim == 1 && q < NQ - 1 && second) || (c.trim == 2 && q >= 1 && !second) ||
+                                                 (c.trim == 3 && q < NQ - 1 && !second) || (c.trim == 4 && q >= 1 && second))) ||
+                                  (TRIM == 4 && !((mw >> (mbit & 31)) & 1u));  // TRIM 4: any pattern, one scalar bit test per product
+          if (!zero_block) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c.Wl[(4 * s) * stride + 16 * q], acc[q], 0, 0, 0);
+        }
       } else {
         acc[0][0] += a;
       }
@@ -284,7 +299,7 @@ __device__ __forceinline__ void run_fixed_units(UnitCtx &c, const BlockPatternDe
 
 // One block of one unit, any depth / width, store or accumulate, plain (compiler-counted) loads: units the specialised
 // form does not cover, rows of fixed dofs (zeros when storing), and the accumulate mode.
-__device__ void unit_generic(const UnitCtx &c, const int32_t *__restrict__ L, int lane, int i, int ks, int ntile,
+__device__ __forceinline__ void unit_generic(const UnitCtx &c, const int32_t *__restrict__ L, int lane, int i, int ks, int ntile,
                              bool fixed_class, bool overwrite) {
   const int nct_all = (c.len + 15) / 16;
   const int stride = (nct_all % 2 == 1) ? 16 * nct_all : 16 * nct_all + 16;
@@ -401,11 +416,15 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
       bool fixed_class, tail;
       const int32_t *L = setup(p_begin, ks, ntile, fixed_class, tail);
       const int key = fixed_class ? -1 : (ks * 8 + ntile) * 2 + (tail ? 1 : 0);
+      // zero-block pattern of the unit (bit s * 5 + q of c.mask set = the W block of k-step s, chain q is not zero)
       done = true;
       switch (key) {
         // Q2 hexes: 8 / 4 / 2 / 1 elements around a vertex / edge / face / cell dof
-        case (14 * 8 + 4) * 2: run_unit<14, 4, false, DBG>(c, L, lane, loader); break;
-        case (7 * 8 + 4) * 2 + 1: run_unit<7, 4, true, DBG>(c, L, lane, loader); break;
+        case (14 * 8 + 4) * 2:
+          c.trim = __builtin_amdgcn_readfirstlane((d.dbg & 16) ? 0 : ((d.part_hdr[(size_t)p_begin * kBpHdrInts + H_FLAGS] >> 2) & 7));  // host-computed trim class of the unit
+          run_unit<14, 4, false, DBG, 3>(c, L, lane, loader);
+          break;
+        case (7 * 8 + 4) * 2 + 1: run_unit<7, 4, true, DBG>(c, L, lane, loader); break;  // (its 29 % of zero blocks stay: the mask-bit form, TRIM 4, needs two registers more than the kernel has)
         case (7 * 8 + 4) * 2: run_unit<7, 4, false, DBG>(c, L, lane, loader); break;
         case (4 * 8 + 3) * 2: run_unit<4, 3, false, DBG>(c, L, lane, loader); break;
         case (2 * 8 + 2) * 2: run_unit<2, 2, false, DBG>(c, L, lane, loader); break;
@@ -473,7 +492,7 @@ void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, 
     MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(kern, dim3(d.num_wgs), dim3(kBpWaves * 64), lds, stream, d, out, su, st);
   };
-  switch (d.dbg | (d.timing ? 8 : 0)) {
+  switch ((d.dbg & 15) | (d.timing ? 8 : 0)) {  // (bit 16 is a run-time switch: no k-step trim)
     case 0: go(block_pattern_jacobian_kernel<0>); break;
     case 1: go(block_pattern_jacobian_kernel<1>); break;
     case 2: go(block_pattern_jacobian_kernel<2>); break;
