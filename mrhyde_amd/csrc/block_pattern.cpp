@@ -271,11 +271,27 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
         if (ng == 0 && rem == 1) parts.push_back({t.cls, t.tile, 0, 0, 1, static_cast<double>(rc.ks + 1)});
         if (rem >= 2) parts.push_back({t.cls, t.tile, 4 * ng, rem, 0, static_cast<double>(rem * (rc.ks + 1) + 2)});
       }
+      // cost of a product unit = its non-zero 4 x 16 blocks of W (the products the kernel's trimmed forms issue)
+      for (PartBuild &pb : parts) {
+        const RowClass &rc = classes[pb.cls];
+        if (rc.fixed) continue;
+        const double *Wk = pl.w.data() + role_woff[rc.bin] + rc.w_off, *Wm = Wk + bin_fill[rc.bin];
+        int nzb = 0;
+        for (int sidx = 0; sidx < rc.ks; ++sidx)
+          for (int q = 0; q < pb.ntile + pb.tail; ++q) {
+            bool any = false;
+            for (int r = 4 * sidx; r < 4 * sidx + 4 && !any; ++r)
+              for (int cc = 16 * (pb.ct0 + q); cc < 16 * (pb.ct0 + q) + 16 && !any; ++cc)
+                any = Wk[static_cast<size_t>(r) * rc.stride + cc] != 0.0 || Wm[static_cast<size_t>(r) * rc.stride + cc] != 0.0;
+            nzb += any ? 1 : 0;
+          }
+        pb.cost = nzb + 1;
+      }
       std::stable_sort(parts.begin(), parts.end(), [](const PartBuild &a, const PartBuild &c) { return a.cost > c.cost; });
       // units of fixed rows (zeros, no products) go to wavefronts that carry no products when there are any: the
       // kernel's fast forms take wavefronts whose units are all of one kind
       std::stable_partition(parts.begin(), parts.end(), [&](const PartBuild &a) { return !classes[a.cls].fixed; });
-      std::vector<double> load(kBpWaves, 0.0);
+      std::vector<double> load(kBpWaves, 0.0), simd_load(4, 0.0);
       std::vector<char> has_products(kBpWaves, 0);
       for (const PartBuild &pb : parts) {
         int wv = -1;
@@ -283,7 +299,14 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
           for (int w = 0; w < kBpWaves; ++w)
             if (!has_products[w] && (wv < 0 || load[w] < load[wv])) wv = w;
         }
-        if (wv < 0) wv = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+        if (wv < 0) {
+          // a product unit: a wavefront of its own while there are free ones, on the SIMD (wavefront id mod 4: the four
+          // SIMDs of a CU take a workgroup's wavefronts round robin) whose matrix pipe has the least work so far
+          for (int w = 0; w < kBpWaves; ++w)
+            if (load[w] == 0.0 && (wv < 0 || simd_load[w % 4] < simd_load[wv % 4])) wv = w;
+          if (wv < 0) wv = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+          simd_load[wv % 4] += pb.cost;
+        }
         load[wv] += pb.cost;
         if (!classes[pb.cls].fixed) has_products[wv] = 1;
         const RowClass &rc = classes[pb.cls];

@@ -125,7 +125,7 @@ __device__ __forceinline__ void transpose_quarters(unsigned (&x)[4]) {
 // them with a handful of coalesced loads two blocks ahead and puts them into a double-buffered LDS image; every unit
 // reads its A operands from there.  (Gathered straight from memory by every unit they were ~100 scattered load
 // instructions per block in front of the CU's one address pipeline, which the stores already saturate.)
-constexpr int kRecLoads = 8;  // 64-lane loads of 8 bytes per block: (T + 1) * 8 doubles <= 512 (the host checks)
+constexpr int kRecLoads = 8;  // 64-lane loads of 8 bytes per block: (T + 1) * 8 doubles <= 512 (the host checks); DBG bit 32: <= 384, 6 loads
 
 // One unit over all blocks of the segment: depth KS, NT column tiles stored row-contiguous (0: none) and, with TAIL, one
 // more tile stored as it stands; overwrite mode.
@@ -165,15 +165,18 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
 
   // ---- loader state: records of block i + 1 in registers, block i + 2 in flight ----
   const int rec_doubles = c.estride * kBpRecDoubles;
-  double Rc[kRecLoads];
-  auto fetch = [&](int i, double (&dst)[kRecLoads]) {  // past the end: the last block again (in bounds, counted)
+  // (the build with DBG bit 32 -- blocks of at most 47 touched elements, e.g. the 4 x 2 x 2 chunks of a hex mesh -- carries
+  // six record registers instead of eight: the four VGPRs are what the mask-bit trim of the 7 x 4 + tail units needs)
+  constexpr int RL = (DBG & 32) ? 6 : kRecLoads;
+  double Rc[RL];
+  auto fetch = [&](int i, double (&dst)[RL]) {  // past the end: the last block again (in bounds, counted)
     const int boff = __builtin_amdgcn_readfirstlane((c.first + min(i, c.nblocks - 1)) * rec_doubles * 8);
 #pragma unroll
-    for (int k = 0; k < kRecLoads; ++k) dst[k] = asm_load_f64(c.erec, (unsigned)min(k * 64 + lane, rec_doubles - 1) * 8u, boff);
+    for (int k = 0; k < RL; ++k) dst[k] = asm_load_f64(c.erec, (unsigned)min(k * 64 + lane, rec_doubles - 1) * 8u, boff);
   };
-  auto deposit = [&](double (&src)[kRecLoads], double *buf) {
+  auto deposit = [&](double (&src)[RL], double *buf) {
 #pragma unroll
-    for (int k = 0; k < kRecLoads; ++k) {
+    for (int k = 0; k < RL; ++k) {
       asm volatile("" : "+v"(src[k]));
       if (k * 64 + lane < rec_doubles) buf[k * 64 + lane] = src[k];
     }
@@ -424,7 +427,10 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
           c.trim = __builtin_amdgcn_readfirstlane((d.dbg & 16) ? 0 : ((d.part_hdr[(size_t)p_begin * kBpHdrInts + H_FLAGS] >> 2) & 7));  // host-computed trim class of the unit
           run_unit<14, 4, false, DBG, 3>(c, L, lane, loader);
           break;
-        case (7 * 8 + 4) * 2 + 1: run_unit<7, 4, true, DBG>(c, L, lane, loader); break;  // (its 29 % of zero blocks stay: the mask-bit form, TRIM 4, needs two registers more than the kernel has)
+        case (7 * 8 + 4) * 2 + 1:  // zero blocks (29 % on a hex mesh) skipped by mask bit where the register budget allows
+          if constexpr ((DBG & 32) != 0) run_unit<7, 4, true, DBG, 4>(c, L, lane, loader);
+          else run_unit<7, 4, true, DBG>(c, L, lane, loader);
+          break;
         case (7 * 8 + 4) * 2: run_unit<7, 4, false, DBG>(c, L, lane, loader); break;
         case (4 * 8 + 3) * 2: run_unit<4, 3, false, DBG>(c, L, lane, loader); break;
         case (2 * 8 + 2) * 2: run_unit<2, 2, false, DBG>(c, L, lane, loader); break;
@@ -492,7 +498,10 @@ void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, 
     MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(kern, dim3(d.num_wgs), dim3(kBpWaves * 64), lds, stream, d, out, su, st);
   };
-  switch ((d.dbg & 15) | (d.timing ? 8 : 0)) {  // (bit 16 is a run-time switch: no k-step trim)
+  // (bit 16 is a run-time switch: no k-step trim of the 14 x 4 units; 32 selects the small-record build)
+  const int small_rec = (d.max_rec_doubles <= 384 && (d.dbg & 15) == 0 && !d.timing && !(d.dbg & 32)) ? 32 : 0;
+  switch ((d.dbg & 15) | (d.timing ? 8 : 0) | small_rec) {
+    case 32: go(block_pattern_jacobian_kernel<32>); break;
     case 0: go(block_pattern_jacobian_kernel<0>); break;
     case 1: go(block_pattern_jacobian_kernel<1>); break;
     case 2: go(block_pattern_jacobian_kernel<2>); break;
