@@ -29,7 +29,7 @@
 //      (thermal.cpp:125-163 restricted to the owned rows), reduced over the four lane groups and added to the row's sum.
 //      The 16 x n results go into the block's CRS image in LDS with ds_add_f64 through the block-major one-byte slot
 //      table (a row's elements overlap in most of its columns).
-//      Meanwhile waves 0-3 start the phase by fetching the NEXT block's tables, vertices and seeded solution values
+//      Meanwhile the fetching waves (0-1) start the phase by fetching the NEXT block's tables, vertices and seeded solution values
 //      (global -> LDS, two dependent loads deep); the other wave of each SIMD runs its tiles under that latency
 //   S  the finished rows stream out in contiguous runs (and are zeroed), the residual rows are written: every CRS
 //      entry and every residual entry is stored exactly once, by its owner -- no atomics on global memory.
@@ -115,6 +115,9 @@ __host__ __device__ inline RgLds rg_layout(int T, int rows, int acc, int pairs, 
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+#ifndef MHA_RG_FETCH_WAVES
+#define MHA_RG_FETCH_WAVES 2
+#endif
 constexpr int kRgSlotRegs = 2;  // uint4 per fetching thread: pairs * n <= 2 * 256 * 16 bytes
 
 template <int DIM, int P, int NQ1, bool TR, bool EXPR, bool TIMING>
@@ -170,25 +173,32 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
   };
   const bool jac = out.compute_jacobian != 0;
 
-  // Fetch of a block's inputs by the 256 threads of waves 0-3, in two stages so that nothing waits on a chain of
+  // Fetch of a block's inputs by the threads of the fetching waves (waves 0..NF-1, NF = 2), in two stages so that nothing waits on a chain of
   // dependent loads.  Stage A (while the current block's fields are formed): the small tables and the slot table into
   // the other table buffer, the row ids of the touched elements' dofs into s_ids.  Stage B (once the scratch is free,
   // after G2, while the other waves start on the tiles): vertices and seeded solution values through those ids.
   // Every load of a stage is issued before its first store.
-  constexpr int PT = NT / 2;
+  constexpr int NF = MHA_RG_FETCH_WAVES;  // waves that load from global memory; the other NW - NF store to it
+  constexpr int PT = NF * 64;
+  constexpr int KA = (256 + PT - 1) / PT;                         // table entries per fetching thread (every table holds <= 256)
   constexpr int MAXT = (DIM == 3) ? 27 : 25;            // touched elements of a block (host caps)
   constexpr int UI = (MAXT * N + PT - 1) / PT;         // solution values per fetching thread
   constexpr int XI = (MAXT * NN * DIM + PT - 1) / PT;  // vertex coordinates per fetching thread
-  int a_ur[UI], a_po = 0, a_sg0 = 0, a_sg1 = 0, a_sg2 = 0, a_rw = 0, a_el = 0;  // stage A values in flight
-  uint32_t a_pr = 0u;
+  int a_ur[UI], a_po[KA], a_sg0[KA], a_sg1[KA], a_sg2[KA], a_rw[KA], a_el = 0;  // stage A values in flight
+  uint32_t a_pr[KA];
+#pragma unroll
+  for (int k = 0; k < KA; ++k) { a_po[k] = 0; a_sg0[k] = 0; a_sg1[k] = 0; a_sg2[k] = 0; a_rw[k] = 0; a_pr[k] = 0u; }
 #define MHA_RG_STAGE_A_LOAD(h_)                                                                                     \
   {                                                                                                                 \
     const int t0 = (h_)[0], T_ = (h_)[1], p0 = (h_)[2], NP_ = (h_)[3], r0 = (h_)[4], NR_ = (h_)[5];                 \
     const int g0 = (h_)[6], NS_ = (h_)[7];                                                                          \
     _Pragma("unroll") for (int k = 0; k < UI; ++k) a_ur[k] = blk_rows[(size_t)t0 * N + min(tid + k * PT, T_ * N - 1)]; \
-    if (tid < NP_) { a_pr = rb.pairs[p0 + tid]; a_po = rb.pair_off[p0 + tid]; }                                     \
-    if (tid < NS_) { a_sg0 = rb.seg_acc[g0 + tid]; a_sg1 = rb.seg_base[g0 + tid]; a_sg2 = rb.seg_len[g0 + tid]; }   \
-    if (tid < NR_) a_rw = rb.row_len[r0 + tid] < 0 ? ~rb.rows[r0 + tid] : rb.rows[r0 + tid];                        \
+    _Pragma("unroll") for (int k = 0; k < KA; ++k) {                                                                \
+      const int i = tid + k * PT;                                                                                   \
+      if (i < NP_) { a_pr[k] = rb.pairs[p0 + i]; a_po[k] = rb.pair_off[p0 + i]; }                                   \
+      if (i < NS_) { a_sg0[k] = rb.seg_acc[g0 + i]; a_sg1[k] = rb.seg_base[g0 + i]; a_sg2[k] = rb.seg_len[g0 + i]; } \
+      if (i < NR_) a_rw[k] = rb.row_len[r0 + i] < 0 ? ~rb.rows[r0 + i] : rb.rows[r0 + i];                           \
+    }                                                                                                               \
     if (tid < T_) a_el = rb.elems[t0 + tid];                                                                        \
   }
 #define MHA_RG_STAGE_A_STORE(h_, tb_)                                                                               \
@@ -196,17 +206,20 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
     const int T_ = (h_)[1], NP_ = (h_)[3], NR_ = (h_)[5], NS_ = (h_)[7];                                            \
     char *tbn = (tb_);                                                                                              \
     _Pragma("unroll") for (int k = 0; k < UI; ++k) if (tid + k * PT < T_ * N) s_ids[tid + k * PT] = a_ur[k];        \
-    if (tid < NP_) {                                                                                                \
-      reinterpret_cast<uint32_t *>(tbn + L.t_pairs)[tid] = a_pr;                                                    \
-      reinterpret_cast<uint16_t *>(tbn + L.t_pairoff)[tid] = (uint16_t)a_po;                                        \
+    _Pragma("unroll") for (int k = 0; k < KA; ++k) {                                                                \
+      const int i = tid + k * PT;                                                                                   \
+      if (i < NP_) {                                                                                                \
+        reinterpret_cast<uint32_t *>(tbn + L.t_pairs)[i] = a_pr[k];                                                 \
+        reinterpret_cast<uint16_t *>(tbn + L.t_pairoff)[i] = (uint16_t)a_po[k];                                     \
+      }                                                                                                             \
+      if (i < NS_) {                                                                                                \
+        int *t_segs = reinterpret_cast<int *>(tbn + L.t_segs);                                                      \
+        t_segs[i] = a_sg0[k];                                                                                       \
+        t_segs[rb.lds_segs + i] = a_sg1[k];                                                                         \
+        t_segs[2 * rb.lds_segs + i] = a_sg2[k];                                                                     \
+      }                                                                                                             \
+      if (i < NR_) reinterpret_cast<int *>(tbn + L.t_rows)[i] = a_rw[k];                                            \
     }                                                                                                               \
-    if (tid < NS_) {                                                                                                \
-      int *t_segs = reinterpret_cast<int *>(tbn + L.t_segs);                                                        \
-      t_segs[tid] = a_sg0;                                                                                          \
-      t_segs[rb.lds_segs + tid] = a_sg1;                                                                            \
-      t_segs[2 * rb.lds_segs + tid] = a_sg2;                                                                        \
-    }                                                                                                               \
-    if (tid < NR_) reinterpret_cast<int *>(tbn + L.t_rows)[tid] = a_rw;                                             \
     if (tid < T_) reinterpret_cast<int *>(tbn + L.t_elems)[tid] = a_el;                                             \
   }
 #define MHA_RG_STAGE_B(h_, tb_)                                                                                     \
@@ -248,23 +261,24 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
   __shared__ int s_hdr[2][HW];
   // the slot table of the next block: requested by the fetching waves when their stage B is issued, held in registers
   // under their tiles, stored once the current block's accumulation is over (after the barrier that ends T)
-  uint4 sl0 = {0u, 0u, 0u, 0u}, sl1 = {0u, 0u, 0u, 0u};
-#define MHA_RG_SLOT_LOAD(h_)                                                       \
-  {                                                                                \
-    const uint4 *ssrc = reinterpret_cast<const uint4 *>(slot8) + (h_)[8];          \
-    const int n16 = (h_)[9];                                                       \
-    if (tid < n16) sl0 = ssrc[tid];                                                \
-    if (tid + PT < n16) sl1 = ssrc[tid + PT];                                      \
+  constexpr int KS4 = (kRgSlotRegs * 256 + PT - 1) / PT;
+  uint4 slr[KS4];
+#pragma unroll
+  for (int k = 0; k < KS4; ++k) slr[k] = uint4{0u, 0u, 0u, 0u};
+#define MHA_RG_SLOT_LOAD(h_)                                                                   \
+  {                                                                                            \
+    const uint4 *ssrc = reinterpret_cast<const uint4 *>(slot8) + (h_)[8];                      \
+    const int n16 = (h_)[9];                                                                   \
+    _Pragma("unroll") for (int k = 0; k < KS4; ++k) if (tid + k * PT < n16) slr[k] = ssrc[tid + k * PT]; \
   }
-#define MHA_RG_SLOT_STORE(h_)                                                      \
-  {                                                                                \
-    uint4 *dsl = reinterpret_cast<uint4 *>(s_slot);                                \
-    const int n16 = (h_)[9];                                                       \
-    if (tid < n16) dsl[tid] = sl0;                                                 \
-    if (tid + PT < n16) dsl[tid + PT] = sl1;                                       \
+#define MHA_RG_SLOT_STORE(h_)                                                                  \
+  {                                                                                            \
+    uint4 *dsl = reinterpret_cast<uint4 *>(s_slot);                                            \
+    const int n16 = (h_)[9];                                                                   \
+    _Pragma("unroll") for (int k = 0; k < KS4; ++k) if (tid + k * PT < n16) dsl[tid + k * PT] = slr[k]; \
   }
   int cur = 0;  // table buffer / header slot of the current block
-  const bool fetcher = wave < NW / 2;
+  const bool fetcher = wave < NF;
   if (tid == 0) { s_job = 0; s_tile = 0; }
   if ((int)blockIdx.x < rb.num_blocks) {
     if (tid < HW) {
@@ -305,8 +319,8 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
     int hdr2 = 0;  // header of the block after the next one (lanes 0..HW-1 of wave 0), stored after the first barrier
     if (tid < HW && next + (int)gridDim.x < rb.num_blocks) hdr2 = blk_hdr[(size_t)(next + gridDim.x) * HW + tid];
 
-    // ---- G1 (waves 4-7). fields on the matrix cores: gu[t][(a,q)] = sum_j ue[t][j] dhat_a N_j(q) -> s_F,
-    //      tt[t][q] = sum_j ud[t][j] N_j(q) -> s_S; waves 0-3 run stage A of the next block meanwhile
+    // ---- G1 (all waves, the fetching ones join late). fields on the matrix cores: gu[t][(a,q)] = sum_j ue[t][j] dhat_a N_j(q) -> s_F,
+    //      tt[t][q] = sum_j ud[t][j] N_j(q) -> s_S; the fetching waves issue stage A of the next block first
     if (prefetch) MHA_RG_STAGE_A_LOAD(hn)
     if (!(dbg & 1)) {
       constexpr int KJ = (N + 3) / 4, CG = (DIM * NQ4 + 15) / 16, CS = TR ? (NQ4 + 15) / 16 : 0;
@@ -418,7 +432,7 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
     lds_barrier();  // point data complete; the scratch (vertices, seeded values) is dead
     MHA_RG_STAMP(1)
 
-    // ---- T. stage B of the next block (waves 0-3), Jacobian rows + residual entries of the pairs ----
+    // ---- T. stage B of the next block (fetching waves), Jacobian rows + residual entries of the pairs ----
     if (prefetch) {
       MHA_RG_SLOT_LOAD(hn)
       MHA_RG_STAGE_B(hn, tbnext)
@@ -536,11 +550,12 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
     if (prefetch) MHA_RG_SLOT_STORE(hn)  // nobody reads the slot table again before the next block's T
 
     // ---- S. stream the finished rows in contiguous runs; what has been read is zeroed for the next block ----
-    // Only waves 4-7 store to global memory, only waves 0-3 load from it: on gfx950 a wave's loads and stores retire
+    // Only waves NF..7 store to global memory, only waves 0..NF-1 load from it (measured: 2 fetching waves 2.12 ms,
+    // 3: 2.13 ms, 4: 2.17 ms on perturbed config 2, profiles/r2_fetch_waves.log): on gfx950 a wave's loads and stores retire
     // through one in-order counter (vmcnt), so a wave that has just streamed out CRS rows would wait for the last of
     // those writes to be acknowledged before it could use the first value it loads for the next block.
     if (jac && !fetcher) {
-      for (int sg = wave - NW / 2; sg < ((dbg & 16) ? 0 : NS); sg += NW / 2) {
+      for (int sg = wave - NF; sg < ((dbg & 16) ? 0 : NS); sg += NW - NF) {
         int len = s_segs[2 * rb.lds_segs + sg];
         const bool fixed_run = len < 0;  // run of fixed rows: zeros when storing, untouched when accumulating
         if (fixed_run) len = -len;
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
         }
       }
     }
-    for (int i = tid - NT / 2; i >= 0 && i < NR; i += NT / 2) {
+    for (int i = tid - PT; i >= 0 && i < NR; i += NT - PT) {
       const int rr = s_rows[i];
       double v = racc[i];
       racc[i] = 0.0;
@@ -600,7 +615,8 @@ void launch_rg(const BlockDev &b, const ThermalDev &ph, RowBlocksDev rb, const u
   const bool tr = ph.time.transient != 0, expr = has_expression(ph);
   rb.lds_acc = (rb.lds_acc + 1) / 2 * 2;
   constexpr size_t n_dofs = RG<DIM, P, NQ1, true>::N;
-  MHA_REQUIRE(rb.lds_pairs * n_dofs <= size_t(kRgSlotRegs) * 256 * 16 && rb.lds_elems <= 32, MHA_ERR_INVALID,
+  MHA_REQUIRE(rb.lds_pairs * n_dofs <= size_t(kRgSlotRegs) * 256 * 16 && rb.lds_elems <= 32 && rb.lds_pairs <= 256 &&
+                  rb.lds_rows <= 256 && rb.lds_segs <= 256, MHA_ERR_INVALID,
               "general row-owner kernel: row block exceeds the kernel's caps");
   auto go = [&](auto kern, size_t lds) {
     MHA_REQUIRE(lds <= 160 * 1024, MHA_ERR_INVALID, "general row-owner kernel needs " << lds << " B of LDS (> 160 KiB)");
