@@ -299,6 +299,7 @@ int mha_workset_compute_residual(mha_context *ctx, int compute_jacobian, const d
 #define MHA_BC_NEUMANN 1
 #define MHA_BC_WEAK_DIRICHLET 2
 #define MHA_BC_FLUX 3
+#define MHA_BC_DIRICHLET 4 /* strong condition (mha_add_dirichlet_group): nothing in mha_assemble_boundary, see mha_set_dirichlet */
 /* shallowwaterHybridized side types (bcs(H_num, side): "interface", "Far-field", "Slip",
  * shallowwaterHybridized.cpp:286-300, 612-620): the group's entries are element sides (all four sides of every
  * element for the HDG interior problem); the trace state comes from the functions "aux H <sidename>",
@@ -313,6 +314,40 @@ int mha_add_boundary_group(mha_context *ctx, const char *sidename, int bc_type, 
 int mha_add_flux_group(mha_context *ctx, const char *sidename, const char *varname, int num_sides,
                        const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id);
 int mha_clear_boundary_groups(mha_context *ctx);
+
+/* ---- L2-projection systems of initial and strong-Dirichlet data -------------------------------------------------
+ * The caller solves mass * x = rhs (the reference hands both to its linear solver, solverManager.cpp:1876-1957);
+ * building them is the assembly manager's part.  mass_vals_dev / rhs_dev are ACCUMULATED into (zero them first).
+ *
+ * mha_set_initial replaces AssemblyManager::setInitial(set, rhs, mass, useadjoint, lumpmass, scale)
+ *   (src/managers/assemblyManager.cpp:1185-1305) with getInitial(project = true) (:7632-7682), getMass (:7776-7840) and
+ *   PhysicsInterface::getInitial (src/interfaces/physicsInterface.cpp:898-958):
+ *     rhs[LIDs(e, off_v(i))] += sum_q init_v(e,q) . basis_v(e,i,q) wts(e,q)            (no sign change, fixed rows too)
+ *     mass(LIDs(e, off_v(i)), LIDs(e, off_v(j))) += sum_q basis_v(e,i,q) . basis_v(e,j,q) wts(e,q); with lump_mass
+ *     every entry goes to the diagonal; afterwards rows with sum |a| < 1e-14 get a one on the diagonal (:1284-1302).
+ *   Data = the functions "initial <var>" (HGRAD / HVOL) or "initial <var>[x]", "[y]", "[z]" (HDIV) registered with
+ *   mha_set_function / mha_set_function_expression (MHA_FUNC_IP_ARRAY: [E][numip]).
+ * mha_set_initial_nodal replaces AssemblyManager::setInitial(set, initial, useadjoint) (:1830-1850) with
+ *   getInitial(project = false) (:7683-7727): initial[LIDs(e, off_v(k))] = "initial <var>" at vertex k of element e
+ *   (replaceLocalValue).  As in the reference this is for HGRAD variables of order 1 only: MHA_ERR_INVALID otherwise.
+ *   (MHA_FUNC_IP_ARRAY here: [E][vertices per element].)
+ * mha_add_dirichlet_group + mha_set_dirichlet replace AssemblyManager::setDirichlet (:1855-1943) with
+ *   getDirichletBoundary (:6288-6350), getMassBoundary (:6360-6425) and PhysicsInterface::getDirichlet
+ *   (physicsInterface.cpp:1065-1083): for every entry of the groups whose variable carries "Dirichlet" on the side set,
+ *   and only in rows with is_fixed,
+ *     rhs[row] += sum_pt D(k,pt) basis side(k,i,pt,0) wts side(k,pt)        HGRAD / HVOL
+ *              += sum_pt D(k,pt) sum_c basis side(k,i,pt,c) n_c(k,pt) wts   HDIV
+ *     mass(row, LIDs(e, off_v(j))) += sum_pt basis side_i basis side_j wts  (HDIV: sum_c b_i,c n_c b_j,c n_c wts, :6400-6408)
+ *   with D = the function "Dirichlet <var> <sidename>" at the side points; every row that is NOT fixed and is touched
+ *   by an element gets a one on its diagonal (replaceValues, :1920-1938).  With lump_mass the reference adds the row total
+ *   to the column of the LAST entry of the element's LID list, not to the diagonal (the `cols[0]` its summing loop leaves
+ *   behind, :1888-1897); reproduced as it is.                                                                        */
+int mha_add_dirichlet_group(mha_context *ctx, const char *sidename, const char *varname, int num_sides,
+                            const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id);
+int mha_set_initial(mha_context *ctx, int lump_mass, double *rhs_dev, double *mass_vals_dev);
+int mha_set_initial_nodal(mha_context *ctx, double *initial_dev);
+int mha_set_dirichlet(mha_context *ctx, int lump_mass, double *rhs_dev, double *mass_vals_dev);
+
 int mha_num_boundary_groups(mha_context *ctx);
 int mha_assemble_boundary(mha_context *ctx, int flags, const double *u_dev, const double *u_prev_dev,
                           const double *u_stage_dev, double *res_dev, double *crs_vals_dev);

@@ -25,7 +25,8 @@ EXPORTS = [
     "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
     "mha_assemble_boundary", "mha_boundary_update", "mha_boundary_view", "mha_set_physics_parameter",
     "mha_set_orientation", "mha_swhdg_side_terms", "mha_swhdg_eigendecomp", "mha_get_mass", "mha_swhdg_element_blocks", "mha_batched_condense", "mha_set_function_expression", "mha_set_time", "mha_check_expression",
-    "mha_add_flux_group", "mha_workset_compute_solution", "mha_workset_compute_residual",
+    "mha_add_flux_group", "mha_add_dirichlet_group", "mha_set_initial", "mha_set_initial_nodal", "mha_set_dirichlet",
+    "mha_workset_compute_solution", "mha_workset_compute_residual",
     "mha_sparse3d_create", "mha_sparse3d_views", "mha_sparse3d_size", "mha_sparse3d_destroy", "mha_database_build",
     "mha_database_get", "mha_apply_mass_matrix_free", "mha_swhdg_subgrid_workspace_bytes", "mha_swhdg_subgrid_solve",
 ]
@@ -96,6 +97,10 @@ def load_library():
         _lib.mha_add_boundary_group.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_void_p]
         _lib.mha_add_flux_group.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.mha_add_dirichlet_group.argtypes = _lib.mha_add_flux_group.argtypes
+        _lib.mha_set_initial.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.mha_set_initial_nodal.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.mha_set_dirichlet.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.mha_workset_compute_solution.argtypes = [C.c_void_p] * 4
         _lib.mha_workset_compute_residual.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         _lib.mha_clear_boundary_groups.argtypes = [C.c_void_p]
@@ -550,6 +555,27 @@ class Block:
                                                  e.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p),
                                                  C.byref(gid)))
         return gid.value
+
+    def add_dirichlet_group(self, sidename, varname, elem_ids, side_ids):
+        """Strong Dirichlet entries of one variable (setDirichlet); data = function "Dirichlet <var> <side>"."""
+        e, s_ = _np(elem_ids, np.int32), _np(side_ids, np.int32)
+        gid = C.c_int()
+        _check(load_library().mha_add_dirichlet_group(self._h, sidename.encode(), varname.encode(), len(e),
+                                                      e.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p),
+                                                      C.byref(gid)))
+        return gid.value
+
+    def set_initial(self, rhs, mass_vals, lump_mass=False):
+        """AssemblyManager::setInitial: rhs += (initial, basis), mass_vals += mass matrix (CRS), zero rows -> identity."""
+        _check(load_library().mha_set_initial(self._h, int(lump_mass), _ptr(rhs), _ptr(mass_vals)))
+
+    def set_initial_nodal(self, initial):
+        """AssemblyManager::setInitial(initial): values of "initial <var>" at the vertices (HGRAD order 1)."""
+        _check(load_library().mha_set_initial_nodal(self._h, _ptr(initial)))
+
+    def set_dirichlet(self, rhs, mass_vals, lump_mass=False):
+        """AssemblyManager::setDirichlet: boundary mass + data on the fixed rows, identity on the others."""
+        _check(load_library().mha_set_dirichlet(self._h, int(lump_mass), _ptr(rhs), _ptr(mass_vals)))
 
     def clear_boundary_groups(self):
         _check(load_library().mha_clear_boundary_groups(self._h))

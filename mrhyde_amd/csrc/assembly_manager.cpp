@@ -1078,10 +1078,10 @@ int AssemblyManager::addBoundaryGroup(const std::string &sidename, int bc_type, 
   return static_cast<int>(boundary_groups_.size()) - 1;
 }
 
-// reference: wkset->var_bcs(var, side) == "Flux" for `varname` on this side set (physicsInterface.cpp:1705-1712); the data
-// is the function "Flux <var> <sidename>"
-int AssemblyManager::addFluxGroup(const std::string &sidename, const std::string &varname, int num, const int32_t *elem_ids,
-                                  const int32_t *side_ids) {
+// reference: wkset->var_bcs(var, side) == "Flux" / "Dirichlet" for `varname` on this side set (physicsInterface.cpp:1705-1712,
+// assemblyManager.cpp:6300): the data is the function "Flux <var> <sidename>" / "Dirichlet <var> <sidename>"
+int AssemblyManager::addVarGroup(int bc_type, const std::string &sidename, const std::string &varname, int num,
+                                 const int32_t *elem_ids, const int32_t *side_ids) {
   MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
   const int var = varIndex(varname);
   MHA_REQUIRE(var >= 0, MHA_ERR_INVALID, "the block has no variable named '" << varname << "'");
@@ -1096,13 +1096,129 @@ int AssemblyManager::addFluxGroup(const std::string &sidename, const std::string
   }
   std::unique_ptr<BoundaryGroupData> g(new BoundaryGroupData());
   g->sidename = sidename;
-  g->bc_type = MHA_BC_FLUX;
+  g->bc_type = bc_type;
   g->var = var;
   g->num = num;
   g->elem.upload(elem_ids, num);
   g->side.upload(side_ids, num);
   boundary_groups_.push_back(std::move(g));
   return static_cast<int>(boundary_groups_.size()) - 1;
+}
+
+int AssemblyManager::addFluxGroup(const std::string &sidename, const std::string &varname, int num, const int32_t *elem_ids,
+                                  const int32_t *side_ids) {
+  return addVarGroup(MHA_BC_FLUX, sidename, varname, num, elem_ids, side_ids);
+}
+
+int AssemblyManager::addDirichletGroup(const std::string &sidename, const std::string &varname, int num,
+                                       const int32_t *elem_ids, const int32_t *side_ids) {
+  return addVarGroup(MHA_BC_DIRICHLET, sidename, varname, num, elem_ids, side_ids);
+}
+
+// PhysicsInterface::getInitial (physicsInterface.cpp:911-958): "initial <var>" for HGRAD / HVOL, "initial <var>[x]", "[y]",
+// "[z]" for HDIV
+void AssemblyManager::initialFunctions(int v, FuncDesc f[3]) const {
+  const std::string base = "initial " + varName(v);
+  if (vars_[v].type == MHA_BASIS_HDIV) {
+    static const char *comp[3] = {"[x]", "[y]", "[z]"};
+    for (int d = 0; d < dim_; ++d) f[d] = functions_.evaluate(base + comp[d]);
+  } else {
+    f[0] = functions_.evaluate(base);
+  }
+}
+
+// reference: AssemblyManager::setInitial(set, rhs, mass, useadjoint, lumpmass, scale) (assemblyManager.cpp:1185-1305): per
+// group getInitial(project = true) and getMass, summed into the vector and the matrix (no sign change, fixed rows
+// included), then rows without entries get a one on the diagonal.  `scale` is not used by the reference either.
+void AssemblyManager::setInitial(int lump_mass, double *rhs, double *mass_vals) {
+  requireReady(false);
+  MHA_REQUIRE(rhs && mass_vals, MHA_ERR_INVALID, "null pointer");
+  MHA_REQUIRE(has_graph_, MHA_ERR_STATE, "no CRS graph: call mha_set_graph first");
+  for (int w = 0; w < numWorksets(); ++w) {
+    worksetUpdate(w);
+    for (int v = 0; v < static_cast<int>(vars_.size()); ++v) {
+      const double *basis, *grad, *div;
+      worksetVarArrays(v, &basis, &grad, &div);
+      ProjectDev p;
+      p.num = wkset_.numElem;
+      p.card = vars_[v].card;
+      p.var_off = layout_.varptr[v];
+      p.np = nq_;
+      p.ncomp = varComps(v);
+      p.e0 = wkset_.first_elem;
+      p.wts = static_cast<const double *>(wkset_.get("wts").ptr);
+      static const char *xyz[3] = {"x", "y", "z"};
+      for (int d = 0; d < dim_; ++d) p.xyz[d] = static_cast<const double *>(wkset_.get(xyz[d]).ptr);
+      p.basis = basis;
+      FuncDesc f[3];
+      initialFunctions(v, f);
+      launch_project_rhs(blockDev(), p, f, rhs, stream_);
+      launch_project_mass(blockDev(), p, lump_mass ? 1 : 0, mass_vals, stream_);
+    }
+  }
+  launch_fix_zero_rows(blockDev(), mass_vals, stream_);
+}
+
+// reference: AssemblyManager::setInitial(set, initial, useadjoint) (assemblyManager.cpp:1830-1850) with getInitial(project =
+// false) (:7683-7727) -- "only works if using HGRAD linear basis": the function's value at the element's vertices replaces
+// the vector entries of the vertex dofs
+void AssemblyManager::setInitialNodal(double *initial) {
+  requireReady(false);
+  MHA_REQUIRE(initial, MHA_ERR_INVALID, "null pointer");
+  for (size_t v = 0; v < vars_.size(); ++v)
+    MHA_REQUIRE(vars_[v].type == MHA_BASIS_HGRAD && vars_[v].order == 1, MHA_ERR_INVALID,
+                "nodal initial values need HGRAD variables of order 1 (variable '" << varName(static_cast<int>(v)) << "')");
+  // the vertex each order-1 basis function sits on, from the reference values at the reference vertices (shards order)
+  static const double quad[8] = {-1, -1, 1, -1, 1, 1, -1, 1};
+  static const double hex[24] = {-1, -1, -1, 1, -1, -1, 1, 1, -1, -1, 1, -1, -1, -1, 1, 1, -1, 1, 1, 1, 1, -1, 1, 1};
+  const int nn = 1 << dim_;
+  std::vector<double> val, g, dv;
+  const int card = ref_basis_var(dim_, MHA_BASIS_HGRAD, 1, nn, dim_ == 2 ? quad : hex, val, g, dv);
+  MHA_REQUIRE(card == nn, MHA_ERR_INVALID, "order-1 HGRAD basis has " << card << " functions on " << nn << " vertices");
+  int vert_of_dof[8] = {0};
+  for (int k = 0; k < nn; ++k) {
+    int at = -1;
+    for (int v = 0; v < nn; ++v)
+      if (std::fabs(val[static_cast<size_t>(k) * nn + v] - 1.0) < 1e-12) at = v;
+    MHA_REQUIRE(at >= 0, MHA_ERR_INVALID, "order-1 HGRAD basis function " << k << " is not nodal");
+    vert_of_dof[k] = at;
+  }
+  for (int v = 0; v < static_cast<int>(vars_.size()); ++v) {
+    const FuncDesc f = functions_.evaluate("initial " + varName(v));
+    launch_interpolate_nodes(blockDev(), f, layout_.varptr[v], vert_of_dof, initial, stream_);
+  }
+}
+
+// reference: AssemblyManager::setDirichlet (assemblyManager.cpp:1855-1943): on the Dirichlet groups, the fixed rows get
+// getDirichletBoundary (:6288-6350) in the vector and getMassBoundary (:6360-6425) in the matrix; every other row
+// touched by an element gets a one on its diagonal
+void AssemblyManager::setDirichlet(int lump_mass, double *rhs, double *mass_vals) {
+  requireReady(false);
+  MHA_REQUIRE(rhs && mass_vals, MHA_ERR_INVALID, "null pointer");
+  MHA_REQUIRE(has_graph_, MHA_ERR_STATE, "no CRS graph: call mha_set_graph first");
+  for (size_t gi = 0; gi < boundary_groups_.size(); ++gi) {
+    BoundaryGroupData &g = *boundary_groups_[gi];
+    if (g.bc_type != MHA_BC_DIRICHLET) continue;
+    if (!g.has_views) boundaryUpdate(static_cast<int>(gi));
+    const VarInfo &vi = vars_[g.var];
+    ProjectDev p;
+    p.num = g.num;
+    p.card = vi.card;
+    p.var_off = layout_.varptr[g.var];
+    p.np = side_ref_.nqs;
+    p.ncomp = varComps(g.var);
+    p.elem = g.elem.data();
+    p.fixed_only = 1;
+    p.normal_trace = vi.type == MHA_BASIS_HDIV ? 1 : 0;
+    p.wts = g.wts.data();
+    for (int d = 0; d < dim_; ++d) { p.xyz[d] = g.xyz[d].data(); p.nrm[d] = g.nrm[d].data(); }
+    p.basis = single_hgrad_ ? g.basis.data() : g.var_views[g.var].basis.data();
+    FuncDesc f[3];
+    f[0] = functions_.evaluate("Dirichlet " + varName(g.var) + " " + g.sidename);
+    launch_project_rhs(blockDev(), p, f, rhs, stream_);
+    launch_project_mass(blockDev(), p, lump_mass ? 1 : 0, mass_vals, stream_);
+  }
+  launch_free_row_identity(blockDev(), mass_vals, stream_);
 }
 
 // reference: the boundary-group loop of assembleJacRes (assemblyManager.cpp:2518-2638): per group
@@ -1119,6 +1235,7 @@ void AssemblyManager::assembleBoundary(int flags, const double *u, const double 
   timedBegin();
   for (size_t gi = 0; gi < boundary_groups_.size(); ++gi) {
     const auto &g = boundary_groups_[gi];
+    if (g->bc_type == MHA_BC_DIRICHLET) continue;  // strong condition: its rows are fixed (setDirichlet builds their system)
     if (g->bc_type == MHA_BC_FLUX) {
       // PhysicsInterface::fluxConditions (physicsInterface.cpp:1702-1762): reads the group's stored side views
       if (!g->has_views) boundaryUpdate(static_cast<int>(gi));

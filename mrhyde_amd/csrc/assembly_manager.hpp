@@ -62,6 +62,11 @@ class AssemblyManager {
   // "Flux" condition of one variable on a side set (PhysicsInterface::fluxConditions, physicsInterface.cpp:1702-1762)
   int addFluxGroup(const std::string &sidename, const std::string &varname, int num, const int32_t *elem_ids,
                    const int32_t *side_ids);
+  int addDirichletGroup(const std::string &sidename, const std::string &varname, int num, const int32_t *elem_ids,
+                        const int32_t *side_ids);
+  void setInitial(int lump_mass, double *rhs, double *mass_vals);
+  void setInitialNodal(double *initial);
+  void setDirichlet(int lump_mass, double *rhs, double *mass_vals);
   void clearBoundaryGroups() { boundary_groups_.clear(); }
   int numBoundaryGroups() const { return static_cast<int>(boundary_groups_.size()); }
   void assembleBoundary(int flags, const double *u, const double *u_prev, const double *u_stage, double *res,
@@ -212,6 +217,9 @@ class AssemblyManager {
   std::string varName(int v) const;
   int varComps(int v) const { return vars_[v].type == MHA_BASIS_HDIV ? dim_ : 1; }
   VarPointsDev varPoints(int v, bool side);
+  int addVarGroup(int bc_type, const std::string &sidename, const std::string &varname, int num, const int32_t *elem_ids,
+                  const int32_t *side_ids);
+  void initialFunctions(int v, FuncDesc f[3]) const;
   // basis arrays of variable v on the current workset (aliases the single-variable views of the workset)
   void worksetVarArrays(int v, const double **basis, const double **grad, const double **div) const;
 
@@ -219,7 +227,7 @@ class AssemblyManager {
   struct BoundaryGroupData {
     std::string sidename;
     int bc_type = 0, num = 0;
-    int var = -1;  // MHA_BC_FLUX: the variable the condition is for
+    int var = -1;  // MHA_BC_FLUX / MHA_BC_DIRICHLET: the variable the condition is for
     DeviceBuffer<int32_t> elem, side;
     DeviceBuffer<double> wts, xyz[3], nrm[3], basis, basis_grad;
     std::vector<VarViews> var_views;  // multi-variable blocks: "basis side <var>", "basis_grad side <var>"

@@ -233,6 +233,26 @@ int mha_add_flux_group(mha_context *ctx, const char *sidename, const char *varna
   });
 }
 
+int mha_add_dirichlet_group(mha_context *ctx, const char *sidename, const char *varname, int num_sides,
+                            const int32_t *elem_ids_host, const int32_t *local_side_ids_host, int *group_id) {
+  return guarded([&] {
+    MHA_REQUIRE(sidename && varname && group_id, MHA_ERR_INVALID, "null argument");
+    *group_id = mgr(ctx).addDirichletGroup(sidename, varname, num_sides, elem_ids_host, local_side_ids_host);
+  });
+}
+
+int mha_set_initial(mha_context *ctx, int lump_mass, double *rhs, double *mass_vals) {
+  return guarded([&] { mgr(ctx).setInitial(lump_mass, rhs, mass_vals); });
+}
+
+int mha_set_initial_nodal(mha_context *ctx, double *initial) {
+  return guarded([&] { mgr(ctx).setInitialNodal(initial); });
+}
+
+int mha_set_dirichlet(mha_context *ctx, int lump_mass, double *rhs, double *mass_vals) {
+  return guarded([&] { mgr(ctx).setDirichlet(lump_mass, rhs, mass_vals); });
+}
+
 int mha_workset_compute_solution(mha_context *ctx, const double *u, const double *u_prev, const double *u_stage) {
   return guarded([&] { mgr(ctx).worksetComputeSolution(u, u_prev, u_stage); });
 }

@@ -180,6 +180,20 @@ struct VarFieldsDev {
   double *grad[3] = {nullptr, nullptr, nullptr}, *div = nullptr;
 };
 
+// One variable's stored views on a list of elements or (element, side) entries, for the L2-projection systems of
+// initial and Dirichlet data (kernels/projection.hip)
+struct ProjectDev {
+  int num = 0, card = 0, var_off = 0, np = 0, ncomp = 1;
+  int e0 = 0;                       // first element of a contiguous range (elem == null)
+  const int32_t *elem = nullptr;    // [num] element of each boundary entry
+  int fixed_only = 0;               // setDirichlet: only rows with isFixedDOF
+  int normal_trace = 0;             // HDIV on a side: data * (basis . n), mass of the normal components
+  const double *wts = nullptr;      // [num][np]
+  const double *xyz[3] = {nullptr, nullptr, nullptr};  // [num][np]
+  const double *nrm[3] = {nullptr, nullptr, nullptr};  // [num][np] (sides)
+  const double *basis = nullptr;    // [num][card][np][ncomp]
+};
+
 // What a physics module's point function reads besides the fields: its named functions and scalar settings.
 struct PhysParamsDev {
   int physics = 0;

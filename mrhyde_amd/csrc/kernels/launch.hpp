@@ -59,6 +59,14 @@ void launch_flux_condition(const BlockDev &b, const FuncDesc &flux, const int32_
                            const double *basis, double *res, hipStream_t stream);
 void launch_negate(double *a, size_t n, hipStream_t stream);
 
+// projection.hip
+void launch_project_rhs(const BlockDev &b, const ProjectDev &p, const FuncDesc f[3], double *rhs, hipStream_t stream);
+void launch_project_mass(const BlockDev &b, const ProjectDev &p, int lump, double *vals, hipStream_t stream);
+void launch_fix_zero_rows(const BlockDev &b, double *vals, hipStream_t stream);
+void launch_free_row_identity(const BlockDev &b, double *vals, hipStream_t stream);
+void launch_interpolate_nodes(const BlockDev &b, const FuncDesc &f, int var_off, const int *vert_of_dof, double *initial,
+                              hipStream_t stream);
+
 // thermal_row_owner.hip
 void launch_classify_affine(const BlockDev &b, uint8_t *flags, double tol, hipStream_t stream);
 void launch_build_block_slots(const BlockDev &b, const RowBlocksDev &rb, void *bslot, int slot_bytes,

@@ -321,6 +321,23 @@ int orc_apply_mass_sparse(int nelem, int n_tot, int nvars, const int *varptr, co
  * checks at tolerance tol; returns the number of representatives                                                    */
 int orc_identify_database(const orc_block_args *a, double tol, int *index, int *first_users);
 
+/* L2-projection systems of initial and Dirichlet data (AssemblyManager::setInitial assemblyManager.cpp:1185-1305,
+ * :1830-1850, getInitial :7632-7728; setDirichlet :1855-1943, getDirichletBoundary :6288-6350, getMassBoundary
+ * :6360-6425), one variable / one boundary group at a time; see the definitions for the array shapes               */
+int orc_project_rhs(int nelem, int card, int nq, int ncomp, const int *lids, int n_tot, const int *off, const double *data,
+                    const double *basis, const double *wts, double *rhs);
+int orc_set_initial_mass(int nelem, int n_tot, const int *lids, const double *mass, int lump, int nrows, const int *rowptr,
+                         const int *colind, double *vals);
+int orc_set_initial_nodal(int nelem, int nnodes, const int *lids, int n_tot, const int *off, const int *vert_of_dof,
+                          const double *vals, double *initial);
+int orc_dirichlet_boundary(int nb, int card, int nqs, int ncomp, int n_tot, const int *off, int hdiv, const double *dip,
+                           const double *basis, const double *wts, const double *normals, double *dvals, double *mass);
+int orc_set_dirichlet_group(int nb, int n_tot, const int *belem, const int *lids, const unsigned char *fixed,
+                            const double *dvals, const double *mass, int lump, const int *rowptr, const int *colind,
+                            double *vals, double *rhs);
+int orc_set_dirichlet_identity(int nelem, int n_tot, const int *lids, const unsigned char *fixed, const int *rowptr,
+                               const int *colind, double *vals);
+
 /* PhysicsInterface::fluxConditions (physicsInterface.cpp:1702-1762) + scatterRes for one variable of a boundary group:
  * res[LIDs(elem, off(dof))] -= sum_pt -flux(k,pt) wts(k,pt) basis(k,dof,pt,0); flux[nb][nqs], wts[nb][nqs],
  * basis[nb][card][nqs][ncomp], off[card], fixed rows skipped                                                  */

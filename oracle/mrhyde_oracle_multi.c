@@ -1075,6 +1075,145 @@ int orc_flux_condition(int nb, int card, int nqs, int ncomp, const int *belem, c
 }
 
 /* ------------------------------------------------------------------------ */
+/* L2-projection systems: setInitial, setDirichlet                           */
+/* ------------------------------------------------------------------------ */
+
+/* KokkosSparse sumIntoValues / replaceValues on a sorted CRS row: columns the row does not hold are ignored */
+static int prj_find(const int *rowptr, const int *colind, int row, int col) {
+  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+    if (colind[k] == col) return k;
+  return -1;
+}
+
+/* getInitial(project = true) for one variable (assemblyManager.cpp:7643-7682) followed by the vector loop of setInitial
+ * (:1243-1254): initialvals(e, off(dof)) += data(e,pt,c) basis(e,dof,pt,c) wts(e,pt); rhs[LIDs(e,row)] += initialvals.
+ * data[E][nq][ncomp], basis[E][card][nq][ncomp], wts[E][nq]                                                       */
+int orc_project_rhs(int nelem, int card, int nq, int ncomp, const int *lids, int n_tot, const int *off, const double *data,
+                    const double *basis, const double *wts, double *rhs) {
+  if (nelem < 0 || card <= 0 || nq <= 0 || ncomp <= 0) return -1;
+  for (size_t e = 0; e < (size_t)nelem; ++e)
+    for (int dof = 0; dof < card; ++dof) {
+      double v = 0.0;
+      for (int pt = 0; pt < nq; ++pt)
+        for (int c = 0; c < ncomp; ++c)
+          v += data[(e * nq + pt) * ncomp + c] * basis[((e * card + dof) * nq + pt) * ncomp + c] * wts[e * nq + pt];
+      rhs[lids[e * n_tot + off[dof]]] += v;
+    }
+  return 0;
+}
+
+/* matrix loop of setInitial (:1256-1280) over dense element mass matrices mass[E][n][n] (getMass), then fix_zero_rows
+ * (:1284-1302)                                                                                                   */
+int orc_set_initial_mass(int nelem, int n_tot, const int *lids, const double *mass, int lump, int nrows, const int *rowptr,
+                         const int *colind, double *vals) {
+  for (size_t e = 0; e < (size_t)nelem; ++e) {
+    const int *L = lids + e * n_tot;
+    for (int row = 0; row < n_tot; ++row) {
+      const int rowIndex = L[row];
+      for (int col = 0; col < n_tot; ++col) {
+        const int c = lump ? rowIndex : L[col];
+        const int k = prj_find(rowptr, colind, rowIndex, c);
+        if (k >= 0) vals[k] += mass[(e * n_tot + row) * n_tot + col];
+      }
+    }
+  }
+  for (int row = 0; row < nrows; ++row) {
+    double abssum = 0.0;
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) abssum += fabs(vals[k]);
+    if (abssum < 1.0e-14) {
+      const int k = prj_find(rowptr, colind, row, row);
+      if (k >= 0) vals[k] = 1.0;
+    }
+  }
+  return 0;
+}
+
+/* setInitial(set, initial, useadjoint) (:1830-1850) with getInitial(project = false) (:7683-7727): nodal values of one
+ * variable; vals[E][nnodes] = "initial <var>" at the element's vertices.  The reference's order-1 HGRAD dof k sits on
+ * vertex k (Intrepid2); this oracle's tables are in tensor order, so the vertex of dof k is vert_of_dof[k] (NULL = k).  */
+int orc_set_initial_nodal(int nelem, int nnodes, const int *lids, int n_tot, const int *off, const int *vert_of_dof,
+                          const double *vals, double *initial) {
+  for (size_t e = 0; e < (size_t)nelem; ++e)
+    for (int dof = 0; dof < nnodes; ++dof)
+      initial[lids[e * n_tot + off[dof]]] = vals[e * nnodes + (vert_of_dof ? vert_of_dof[dof] : dof)];
+  return 0;
+}
+
+/* getDirichletBoundary (:6288-6350) and getMassBoundary (:6360-6425) for one variable of a boundary group:
+ * dvals[nb][n_tot], mass[nb][n_tot][n_tot] accumulated; dip[nb][nqs], basis[nb][card][nqs][ncomp], wts[nb][nqs],
+ * normals[nb][nqs][ncomp] (HDIV only)                                                                             */
+int orc_dirichlet_boundary(int nb, int card, int nqs, int ncomp, int n_tot, const int *off, int hdiv, const double *dip,
+                           const double *basis, const double *wts, const double *normals, double *dvals, double *mass) {
+  if (nb < 0 || card <= 0 || nqs <= 0 || ncomp <= 0) return -1;
+  for (size_t e = 0; e < (size_t)nb; ++e)
+    for (int i = 0; i < card; ++i) {
+      for (int j = 0; j < nqs; ++j) {
+        const double *bi = basis + ((e * card + i) * nqs + j) * ncomp;
+        if (!hdiv) dvals[e * n_tot + off[i]] += dip[e * nqs + j] * bi[0] * wts[e * nqs + j];
+        else
+          for (int c = 0; c < ncomp; ++c)
+            dvals[e * n_tot + off[i]] += dip[e * nqs + j] * bi[c] * normals[(e * nqs + j) * ncomp + c] * wts[e * nqs + j];
+      }
+      for (int j = 0; j < card; ++j)
+        for (int k = 0; k < nqs; ++k) {
+          const double *bi = basis + ((e * card + i) * nqs + k) * ncomp, *bj = basis + ((e * card + j) * nqs + k) * ncomp;
+          double *m = mass + (e * n_tot + off[i]) * n_tot + off[j];
+          if (!hdiv) *m += bi[0] * bj[0] * wts[e * nqs + k];
+          else
+            for (int c = 0; c < ncomp; ++c) {
+              const double nc = normals[(e * nqs + k) * ncomp + c];
+              *m += bi[c] * nc * bj[c] * nc * wts[e * nqs + k];
+            }
+        }
+    }
+  return 0;
+}
+
+/* setDirichlet, the boundary-group loop (:1870-1917) for one group: fixed rows only; lumped: the row total goes to the
+ * column left in cols[0] by the summing loop = LIDs(c, n_tot - 1)                                                    */
+int orc_set_dirichlet_group(int nb, int n_tot, const int *belem, const int *lids, const unsigned char *fixed,
+                            const double *dvals, const double *mass, int lump, const int *rowptr, const int *colind,
+                            double *vals, double *rhs) {
+  for (size_t c = 0; c < (size_t)nb; ++c) {
+    const int *L = lids + (size_t)belem[c] * n_tot;
+    for (int row = 0; row < n_tot; ++row) {
+      const int rowIndex = L[row];
+      if (!(fixed && fixed[rowIndex])) continue;
+      rhs[rowIndex] += dvals[c * n_tot + row];
+      if (lump) {
+        int col0 = 0;
+        double totalval = 0.0;
+        for (int col = 0; col < n_tot; ++col) {
+          col0 = L[col];
+          totalval += mass[(c * n_tot + row) * n_tot + col];
+        }
+        const int k = prj_find(rowptr, colind, rowIndex, col0);
+        if (k >= 0) vals[k] += totalval;
+      } else {
+        for (int col = 0; col < n_tot; ++col) {
+          const int k = prj_find(rowptr, colind, rowIndex, L[col]);
+          if (k >= 0) vals[k] += mass[(c * n_tot + row) * n_tot + col];
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* setDirichlet, the closing loop (:1920-1938): ones on the diagonal of the rows that are not fixed */
+int orc_set_dirichlet_identity(int nelem, int n_tot, const int *lids, const unsigned char *fixed, const int *rowptr,
+                               const int *colind, double *vals) {
+  for (size_t c = 0; c < (size_t)nelem; ++c)
+    for (int row = 0; row < n_tot; ++row) {
+      const int rowIndex = lids[c * n_tot + row];
+      if (fixed && fixed[rowIndex]) continue;
+      const int k = prj_find(rowptr, colind, rowIndex, rowIndex);
+      if (k >= 0) vals[k] = 1.0;
+    }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* applyMassMatrixFree, Sparse3DView, the basis database                     */
 /* ------------------------------------------------------------------------ */
 

@@ -681,6 +681,69 @@ def flux_condition(belem, lids, off, flux, wts, basis, res, fixed=None):
     assert rc == 0, rc
 
 
+# ---- L2-projection systems (setInitial / setDirichlet) ----------------------------------------------------------------
+def _ci(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _cd(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def project_rhs(lids, off, data, basis, wts, rhs):
+    """getInitial(project) + setInitial's vector loop, one variable; data[E][nq][ncomp], basis[E][card][nq][ncomp]."""
+    lids, off, data, basis, wts = _ci(lids), _ci(off), _cd(data), _cd(basis), _cd(wts)
+    ne, card, nq, ncomp = basis.shape
+    rc = lib().orc_project_rhs(ne, card, nq, ncomp, _i(lids), lids.shape[1], _i(off), _d(data), _d(basis), _d(wts), _d(rhs))
+    assert rc == 0, rc
+
+
+def set_initial_mass(lids, mass, lump, rowptr, colind, vals):
+    """setInitial's matrix loop over dense element mass matrices + fix_zero_rows."""
+    lids, mass, rowptr, colind = _ci(lids), _cd(mass), _ci(rowptr), _ci(colind)
+    rc = lib().orc_set_initial_mass(lids.shape[0], lids.shape[1], _i(lids), _d(mass), int(lump), len(rowptr) - 1, _i(rowptr),
+                                    _i(colind), _d(vals))
+    assert rc == 0, rc
+
+
+def set_initial_nodal(lids, off, nodal, initial, vert_of_dof=None):
+    """vert_of_dof[k] = vertex of order-1 dof k; default: the single-variable mesh of this oracle, whose LID list starts
+    with the vertex sites in vertex order, so that dof k (LID position off[k]) sits on vertex off[k]."""
+    lids, off, nodal = _ci(lids), _ci(off), _cd(nodal)
+    vod = _ci(off[:nodal.shape[1]] if vert_of_dof is None else vert_of_dof)
+    rc = lib().orc_set_initial_nodal(lids.shape[0], nodal.shape[1], _i(lids), lids.shape[1], _i(off), _i(vod), _d(nodal),
+                                     _d(initial))
+    assert rc == 0, rc
+
+
+def dirichlet_boundary(n_tot, off, dip, basis, wts, normals=None):
+    """getDirichletBoundary + getMassBoundary of one variable: (dvals[nb][n_tot], mass[nb][n_tot][n_tot])."""
+    off, dip, basis, wts = _ci(off), _cd(dip), _cd(basis), _cd(wts)
+    nb, card, nqs, ncomp = basis.shape
+    dvals, mass = np.zeros((nb, n_tot)), np.zeros((nb, n_tot, n_tot))
+    nr = None if normals is None else _cd(normals)
+    rc = lib().orc_dirichlet_boundary(nb, card, nqs, ncomp, n_tot, _i(off), 0 if nr is None else 1, _d(dip), _d(basis),
+                                      _d(wts), None if nr is None else _d(nr), _d(dvals), _d(mass))
+    assert rc == 0, rc
+    return dvals, mass
+
+
+def set_dirichlet_group(belem, lids, fixed, dvals, mass, lump, rowptr, colind, vals, rhs):
+    belem, lids, rowptr, colind = _ci(belem), _ci(lids), _ci(rowptr), _ci(colind)
+    fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8)
+    rc = lib().orc_set_dirichlet_group(len(belem), lids.shape[1], _i(belem), _i(lids), None if fx is None else _u(fx),
+                                       _d(_cd(dvals)), _d(_cd(mass)), int(lump), _i(rowptr), _i(colind), _d(vals), _d(rhs))
+    assert rc == 0, rc
+
+
+def set_dirichlet_identity(lids, fixed, rowptr, colind, vals):
+    lids, rowptr, colind = _ci(lids), _ci(rowptr), _ci(colind)
+    fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8)
+    rc = lib().orc_set_dirichlet_identity(lids.shape[0], lids.shape[1], _i(lids), None if fx is None else _u(fx), _i(rowptr),
+                                          _i(colind), _d(vals))
+    assert rc == 0, rc
+
+
 # ---- shallowwaterHybridized, point level ---------------------------------------------------------------------------
 PHYS_SHALLOWWATER_HYBRIDIZED = 4
 PHYS_FUNCS[PHYS_SHALLOWWATER_HYBRIDIZED] = ["source H", "source Hux", "source Huy"]

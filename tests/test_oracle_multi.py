@@ -278,3 +278,50 @@ def test_mass_storage_and_database_restatements(oracle):
         y3 = np.zeros(m["ndof"])
         oracle.apply_mass_sparse(m, vals, cls, nnz, x, y3, index=idx)
         assert np.abs(y3 - y0).max() < 1e-12 * np.abs(y0).max()
+
+
+def test_projection_restatements_partition_of_unity(oracle):
+    """setInitial / setDirichlet restatements (oracle/mrhyde_oracle_multi.c) against closed forms: with data == 1 the
+    projected right-hand side of an HGRAD variable is the row sum of its mass matrix (partition of unity), the lumped
+    matrix carries exactly that on the diagonal, the mass of the whole block integrates 1 to the domain's measure, and the
+    Dirichlet system has the boundary row sums on fixed rows and the identity elsewhere."""
+    dim, ncell, qdeg = 2, (4, 3), 4
+    m = oracle.mesh_multi(dim, ncell, [oracle.HGRAD, oracle.HGRAD], [2, 1], hi=[2.0, 1.5, 1.0])
+    nd, n_tot = m["ndof"], m["lids"].shape[1]
+    rowptr, colind = oracle.build_graph(nd, m["lids"])
+    rhs = np.zeros(nd)
+    for v, order in enumerate((2, 1)):
+        pb = oracle.physical_basis_var(dim, oracle.HGRAD, order, qdeg, m["nodes"])
+        off = m["offsets"][m["varptr"][v]:m["varptr"][v + 1]]
+        oracle.project_rhs(m["lids"], off, np.ones(pb["wts"].shape + (1,)), pb["basis"], pb["wts"], rhs)
+    mass = oracle.get_mass(m, qdeg)
+    vals, lumped = np.zeros(len(colind)), np.zeros(len(colind))
+    oracle.set_initial_mass(m["lids"], mass, False, rowptr, colind, vals)
+    oracle.set_initial_mass(m["lids"], mass, True, rowptr, colind, lumped)
+    rowsum = np.add.reduceat(vals, rowptr[:-1])
+    assert np.allclose(rowsum, rhs, rtol=1e-13, atol=1e-15)
+    diag = np.array([lumped[rowptr[r]:rowptr[r + 1]][colind[rowptr[r]:rowptr[r + 1]] == r][0] for r in range(nd)])
+    assert np.allclose(diag, rhs, rtol=1e-13) and np.isclose(lumped.sum(), diag.sum())
+    assert np.isclose(rhs[m["dof_var"] == 0].sum(), 3.0) and np.isclose(rhs[m["dof_var"] == 1].sum(), 3.0)   # |domain| = 2 * 1.5
+
+    # Dirichlet data 1 for variable 0 on the right side (x = 2): length 1.5
+    belem, bside = oracle.boundary_sides(dim, ncell, "right")
+    sb = oracle.physical_side_basis(dim, 2, qdeg, m["nodes"], belem, bside)
+    fixed = ((m["dof_var"] == 0) & ((m["side_mask"] >> 1) & 1 == 1)).astype(np.uint8)
+    off = m["offsets"][m["varptr"][0]:m["varptr"][1]]
+    dvals, bmass = oracle.dirichlet_boundary(n_tot, off, np.ones(sb["wts"].shape), sb["basis"][..., None], sb["wts"])
+    for lump in (False, True):
+        dv, dr = np.zeros(len(colind)), np.zeros(nd)
+        oracle.set_dirichlet_group(belem, m["lids"], fixed, dvals, bmass, lump, rowptr, colind, dv, dr)
+        oracle.set_dirichlet_identity(m["lids"], fixed, rowptr, colind, dv)
+        assert np.isclose(dr.sum(), 1.5) and np.all(dr[fixed == 0] == 0.0)
+        rs = np.add.reduceat(dv, rowptr[:-1])
+        assert np.allclose(rs[fixed == 1], dr[fixed == 1], rtol=1e-13)       # row sums of the boundary mass = (1, basis)
+        free = np.flatnonzero(fixed == 0)
+        assert np.all(rs[free] == 1.0) and all(dv[rowptr[r]:rowptr[r + 1]][colind[rowptr[r]:rowptr[r + 1]] == r][0] == 1.0 for r in free)
+    # nodal values replace entries
+    init = np.full(nd, -1.0)
+    m1 = oracle.mesh_multi(dim, ncell, [oracle.HGRAD], [1])
+    init = np.full(m1["ndof"], -1.0)
+    oracle.set_initial_nodal(m1["lids"], m1["offsets"], m1["nodes"][..., 0] + 2 * m1["nodes"][..., 1], init)
+    assert np.allclose(init, m1["verts"][:, 0] + 2 * m1["verts"][:, 1])
