@@ -364,6 +364,38 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       double *lj_e = out.local_J ? out.local_J + (size_t)(e - out.local_base) * n * n : nullptr;
       constexpr int NWV = TPE / 64;             // waves working on this element
       const int wv = gt >> 6, lane = gt & 63, l15 = lane & 15, l4 = lane >> 4;
+      // When every wave has at most one column tile (the 89-dof navierstokes element: seven tiles on eight waves), the
+      // tile's B operand -- table values, the same for all row panels -- is read once per element and kept in registers:
+      // the products of a panel then read only P from the LDS, half the traffic of the 2 x 512 B per product that kept
+      // the LDS pipe as busy as the matrix pipe (profiles/r2_ns_regb.log)
+      // (only in the instantiation that has that shape; the offset passes through an empty asm so that the reads stay
+      // inside the element loop -- hoisted, they would be live across the point functions: +56 registers, spills)
+      constexpr int QB = 27;
+      constexpr bool REGB = !EXPR && PHYS == MHA_PHYSICS_NAVIERSTOKES && DIM == 3 && TPE == 512;
+      bool reg_b = REGB && NQ == QB && !(dbg_stop & 8);
+      double breg[REGB ? QB : 1];
+      if constexpr (REGB) {
+        int tile = 0, my_vj = -1, my_c0 = 0;
+        for (int vj = 0; vj < vl.nvars; ++vj) {
+          if (vl.nslot[vj] != 4) reg_b = false;
+          for (int c0 = 0; c0 < vl.card[vj]; c0 += 16, ++tile)
+            if (tile == wv) { my_vj = vj; my_c0 = c0; }
+        }
+        if (tile > NWV) reg_b = false;
+        if (reg_b) {
+          const int vj = max(my_vj, 0);
+          const double *Tj = tab + vl.table_off[vj];
+          const int cpj = vl.cardpad[vj];
+          const bool cb = my_vj >= 0 && my_c0 + l15 < vl.card[vj];
+          int col = cb ? my_c0 + l15 : 0;
+          asm volatile("" : "+v"(col));
+#pragma unroll
+          for (int q = 0; q < QB; ++q) {
+            const double t = Tj[(q * 4 + l4) * cpj + col];
+            breg[q] = cb ? t : 0.0;
+          }
+        }
+      }
       for (int vi = 0; vi < vl.nvars; ++vi) {
         const int nsi = vl.nslot[vi], spi = vl.slotptr[vi], cpi = vl.cardpad[vi], cardi = vl.card[vi];
         const double *Ti = tab + vl.table_off[vi];
@@ -395,7 +427,22 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
               if (tile % NWV != wv) continue;
               const bool cb = c0 + l15 < cardj;
               v4d d = {0.0, 0.0, 0.0, 0.0};
-              if (!EXPR && dbg_stop == 7) {  // profiling (plain-coefficient instantiations only: the deck-string ones are at their scratch limit): no products, the stores only
+              if (!EXPR && (dbg_stop & 7) == 7) {  // profiling (plain-coefficient instantiations only: the deck-string ones are at their scratch limit): no products, the stores only
+              } else if (REGB && reg_b) {
+                v4d d1 = {0.0, 0.0, 0.0, 0.0};
+                const double *pa = s_P + (spj + l4) * kPanelRows + l15;
+#pragma unroll
+                for (int q0 = 0; q0 < QB; q0 += 9) {
+                  double av[9];
+#pragma unroll
+                  for (int u = 0; u < 9; ++u) av[u] = pa[(q0 + u) * NS * kPanelRows];
+#pragma unroll
+                  for (int u = 0; u < 9; ++u) {
+                    if (u & 1) d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], breg[REGB ? q0 + u : 0], d1, 0, 0, 0);
+                    else d = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], breg[REGB ? q0 + u : 0], d, 0, 0, 0);
+                  }
+                }
+                d += d1;
               } else if (!EXPR && nsj == 4 && NQ % 9 == 0) {  // (the deck-string instantiations keep the plain loop: they are at their scratch limit)
                 // one point per MFMA (k = slot).  Operands of nine points are requested before the first product and the
                 // products alternate between two accumulators: the loop used to be a chain of 27 dependent MFMAs, each
@@ -433,7 +480,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
                   d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, d, 0, 0, 0);
                 }
               }
-              if (!EXPR && dbg_stop == 6) {  // profiling: products only (kept alive), no stores
+              if (!EXPR && (dbg_stop & 7) == 6) {  // profiling: products only (kept alive), no stores
                 if (d[0] + d[1] + d[2] + d[3] == 1.2345e300 && lj_e) lj_e[0] = 1.0;
               } else if (cb) {
                 const int j = vl.varptr[vj] + c0 + l15, pos_j = s_pos[j];

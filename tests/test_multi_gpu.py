@@ -347,7 +347,48 @@ def test_launch_that_needs_too_much_scratch_is_refused(oracle, monkeypatch):
     monkeypatch.delenv("MHA_MAX_SCRATCH_BYTES")
     blk.assemble_jacres(ud, res, None, compute_jacobian=False, path=mrhyde_amd.PATH_POINT_ENGINE)
     torch.cuda.synchronize()
-    assert np.all(np.isfinite(res.cpu().numpy()))
+    ref = oracle.assemble_block(m, oracle.PHYS_POROUS_MIXED, 2, np.zeros(m["ndof"]), funcs={"source": ("expr", "sin(x)*y + 0.5", 0.0)})
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+
+
+@pytest.mark.parametrize("physics", ["thermal", "porousMixed", "navierstokes", "shallowwaterHybridized"])
+def test_deck_string_source_on_every_module(oracle, physics):
+    """The deck-string (MHA_FUNC_EXPRESSION) instantiations of the point engine are separate kernels that carry the
+    interpreter's stack and spill heavily: each module's, in 2-D and 3-D, on one-wave and whole-workgroup element sizes,
+    against the oracle's independent evaluator -- residual and Jacobian, on the engine itself and on the module's default
+    path.  (A finite result is not a check: a broken build of the 3-D porousMixed instantiation once produced finite
+    garbage here.)"""
+    torch = _torch()
+    import mrhyde_amd
+    H, V, D = oracle.HGRAD, oracle.HVOL, oracle.HDIV
+    spec = {"thermal": (oracle.PHYS_THERMAL, [H], [2], "thermal source", []),
+            "porousMixed": (oracle.PHYS_POROUS_MIXED, [V, D], [0, 1], "source", []),
+            "navierstokes": (oracle.PHYS_NAVIERSTOKES, [H] * 4, [2, 1, 2, 2], "source ux", [1, 1, 0]),
+            "shallowwaterHybridized": (oracle.PHYS_SHALLOWWATER_HYBRIDIZED, [H] * 3, [1, 1, 1], "source H", [9.81])}
+    pid, types, orders, fname, params = spec[physics]
+    expr = "sin(x)*y + 0.5"
+    for dim in (2, 3):
+        if physics == "shallowwaterHybridized" and dim == 3:
+            continue
+        ty, od = (types[:3], orders[:3]) if physics == "navierstokes" and dim == 2 else (types, orders)
+        for ncell in ([2] * dim, [5, 3, 2][:dim]):
+            m = warp(oracle.mesh_multi(dim, ncell, ty, od))
+            u = np.random.default_rng(5).uniform(0.5, 1.5, m["ndof"])
+            qdeg = 2 * max(max(od), 1)
+            ref = oracle.assemble_block(m, pid, qdeg, u, funcs={fname: ("expr", expr, 0.0)}, params=params)
+            blk = make_block(m, physics, qdeg, graph=(ref["rowptr"], ref["colind"]))
+            blk.set_function(fname, expr)
+            for name, val in zip({"navierstokes": ("useSUPG", "usePSPG", "fix_uz_offsets"),
+                                  "shallowwaterHybridized": ("g",)}.get(physics, ()), params):
+                blk.set_physics_parameter(name, val)
+            ud = torch.tensor(u, device="cuda")
+            for path in (mrhyde_amd.PATH_POINT_ENGINE, mrhyde_amd.PATH_AUTO):
+                res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+                vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+                blk.assemble_jacres(ud, res, vals, overwrite=(path == mrhyde_amd.PATH_AUTO), path=path)
+                torch.cuda.synchronize()
+                assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL, (physics, dim, ncell, path)
+                assert rel_err(vals.cpu().numpy(), ref["crs_vals"]) < RTOL, (physics, dim, ncell, path)
 
 
 def test_workset_views_of_multi_variable_blocks(oracle):
