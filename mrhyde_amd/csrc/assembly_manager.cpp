@@ -203,6 +203,10 @@ void AssemblyManager::prepareRowGather(bool need_jacobian) {
     d_inc_ptr_.upload(ptr);
     d_inc_elem_.upload(elem);
     d_inc_pos_.upload(lpos);
+    std::vector<int32_t> offs(n_), p2d(n_, 0);
+    d_offsets_.download(offs.data());
+    for (int f = 0; f < n_; ++f) p2d[offs[f]] = f;
+    d_pos2dof_.upload(p2d);
     max_row_ = 0;
     for (int r = 0; r < nrows_; ++r) max_row_ = std::max(max_row_, h_rowptr_[r + 1] - h_rowptr_[r]);
     has_incidence_ = true;
@@ -498,6 +502,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
     case MHA_PATH_ROW_GATHER: {
       // dense element matrices from the element kernel (stored, not accumulated), then one wavefront per CRS row
       ElemOut o;
+      bool dof_order = false;
       o.compute_jacobian = compute_jacobian ? 1 : 0;
       o.local_store = 1;
       o.local_J = compute_jacobian ? d_gather_J_.data() : nullptr;
@@ -518,9 +523,18 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         }
         physics_->volumeResidual();
       } else {
+        // porousMixed: its thread-per-element kernel writes the element arrays in dof order, straight from registers
+        // (kernels/porous_element.hip); MHA_GATHER_ORDER=pos keeps the LID-position order and the LDS staging
+        static const bool by_pos = [] {
+          const char *m = std::getenv("MHA_GATHER_ORDER"), *k = std::getenv("MHA_POROUS_KERNEL");
+          return (m && m[0] == 'p') || (k && k[0] == 'e');  // the point engine writes LID-position order only
+        }();
+        dof_order = !by_pos && !adjoint && !lump_mass && physics_->label == "porousMixed";
+        o.local_dof_order = dof_order ? 1 : 0;
         launchPointEngine(compute_jacobian, o, 0, nelem_);
       }
       RowGatherDev g;
+      g.pos2dof = dof_order ? d_pos2dof_.data() : nullptr;
       g.inc_ptr = d_inc_ptr_.data();
       g.inc_elem = d_inc_elem_.data();
       g.inc_pos = d_inc_pos_.data();

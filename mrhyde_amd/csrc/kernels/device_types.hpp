@@ -70,6 +70,8 @@ struct ElemOut {
   int compute_jacobian = 1;
   int local_store = 0;          // 1: local_J / local_res are stored (scratch of the row-gather path), 0: accumulated
   int local_base = 0;           // element id stored at local_J[0] / local_res[0]
+  int local_dof_order = 0;      // row-gather scratch only (porousMixed element kernel): rows and columns of local_J and the
+                                // entries of local_res in (variable, dof) order instead of LID-position order
   double *local_J = nullptr;    // [E][n][n]   (updateJac convention, +=)
   double *local_res = nullptr;  // [E][n]      (updateRes convention, -=)
   double *res = nullptr;        // [nrows]     atomic scatter of -res.val()
@@ -209,6 +211,8 @@ struct RowGatherDev {
   // scatter options of the reference (assemblyManager.cpp:4124-4133): isAdjoint_ takes res(row).dx(row) for every column
   // of the row; lump_mass_ sends every column's value to the diagonal entry (cols[col] = rowIndex)
   int adjoint = 0, lump_mass = 0;
+  const int32_t *pos2dof = nullptr;  // non-null: the element arrays are in (variable, dof) order (ElemOut::local_dof_order);
+                                     // pos2dof[LID position] = flattened dof index, BlockDev::offsets the other way
 };
 
 // shallowwaterHybridized side terms at npts side integration points (kernels/swhdg_side.hip); state order H, Hux, Huy

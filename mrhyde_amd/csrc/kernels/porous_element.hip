@@ -11,11 +11,15 @@
 // Output: dense local_J / local_res in LID-position order (updateJac / updateRes convention), from which
 // kernels/row_gather.hip builds the CRS rows.  Same gather / seeding conventions as the point engine.
 // A thread's 24 vertex coordinates and 56 results are contiguous per ELEMENT, i.e. 192 / 392 bytes apart between
-// lanes: read and written directly, every memory instruction touched 64 cache lines.  The workgroup's 128 elements are
-// therefore staged through LDS and move to and from memory as flat, fully coalesced arrays.
+// lanes.  Two forms: (DOF = false, the public updateJac / updateRes arrays) the workgroup's 128 elements are staged through
+// LDS and move to and from memory as flat, fully coalesced arrays in LID-position order -- 448 B of LDS per thread, i.e.
+// four wavefronts per CU; (DOF = true, the private scratch of the row-gather path) no staging and no barrier: every thread parks
+// its vertices in its own 192 B of LDS (48 registers less) and writes its results from registers at compile-time offsets,
+// rows and columns in dof order (the row gather maps positions to dofs); two wavefronts per SIMD instead of one.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -25,18 +29,18 @@ namespace {
 
 constexpr int kPorousThreads = 128;
 
-template <int DIM, bool EXPR>
-__global__ __launch_bounds__(kPorousThreads) void porous_element_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm,
-                                                             ElemOut out) {
+template <int DIM, bool EXPR, bool DOF>
+__device__ __forceinline__ void porous_element_body(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp,
+                                                    const TimeDev &tm, const ElemOut &out) {
   constexpr int NN = 1 << DIM, NU = 2 * DIM, N = 1 + NU;
   extern __shared__ double sm[];  // in: [128][NN*DIM] vertices; out: [128][N*N] element matrices + [128][N] residuals
   const int tid = threadIdx.x, e0 = blockIdx.x * kPorousThreads;
   const int cnt = min(kPorousThreads, b.e_count - e0);
-  {
+  if constexpr (!DOF) {
     const double *src = b.nodes + (size_t)(b.e_begin + e0) * NN * DIM;
     for (int i = tid; i < cnt * NN * DIM; i += kPorousThreads) sm[i] = src[i];
+    __syncthreads();
   }
-  __syncthreads();
   const bool active = tid < cnt;
   const int e = b.e_begin + e0 + (active ? tid : 0), NQ = vl.nq;
   const int32_t *L = b.lids + (size_t)e * N;
@@ -58,12 +62,19 @@ __global__ __launch_bounds__(kPorousThreads) void porous_element_kernel(BlockDev
     }
     u[f] = ue;
   }
-  double xn[NN][DIM];
+  double xn[DOF ? 1 : NN][DIM];
+  double *sx = sm + (size_t)tid * NN * DIM;  // DOF: the thread's own vertices (read back by the same thread: no barrier)
+  if constexpr (DOF) {
+    const double *src = b.nodes + (size_t)e * NN * DIM;  // 16-byte aligned: NN * DIM is even
 #pragma unroll
-  for (int k = 0; k < NN; ++k)
+    for (int k = 0; k < NN * DIM; k += 2) *reinterpret_cast<double2 *>(sx + k) = *reinterpret_cast<const double2 *>(src + k);
+  } else {
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) xn[k][d] = sm[((active ? tid : 0) * NN + k) * DIM + d];
-  __syncthreads();  // vertices are in registers: the buffer is reused for the results
+    for (int k = 0; k < NN; ++k)
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) xn[k][d] = sm[((active ? tid : 0) * NN + k) * DIM + d];
+    __syncthreads();  // vertices are in registers: the buffer is reused for the results
+  }
   double A[NU][NU], Bv[NU], rp = 0.0, ru[NU];
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
@@ -80,12 +91,12 @@ __global__ __launch_bounds__(kPorousThreads) void porous_element_kernel(BlockDev
       for (int c = 0; c < DIM; ++c) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < NN; ++k) s += xn[k][r] * b.nodegrad[(k * NQ + q) * DIM + c];
+        for (int k = 0; k < NN; ++k) s += (DOF ? sx[k * DIM + r] : xn[k][r]) * b.nodegrad[(k * NQ + q) * DIM + c];
         J[r * DIM + c] = s;
       }
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < NN; ++k) s += xn[k][r] * b.nodeval[k * NQ + q];
+      for (int k = 0; k < NN; ++k) s += (DOF ? sx[k * DIM + r] : xn[k][r]) * b.nodeval[k * NQ + q];
       x[r] = s;
     }
     invert<DIM>(J, Ji, det);
@@ -134,11 +145,37 @@ __global__ __launch_bounds__(kPorousThreads) void porous_element_kernel(BlockDev
       ru[i] += (kuv * ph[i] * rmob - u[0] * dv[i]) * w;
       Bv[i] -= dv[i] * w;
 #pragma unroll
-      for (int j = 0; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1] * w;
+      for (int j = i; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1] * w;  // symmetric: upper triangle only
     }
   }
-  // dense output, LID-position order: into LDS per thread, then flat and coalesced to memory
   const double au = tm.alpha_u;
+  if constexpr (DOF) {
+    // dof order, stored (the row-gather scratch is never accumulated into): residual [p, u_0..], matrix rows [p | u_i]
+    if (active) {
+      if (out.local_res) {
+        double *lr = out.local_res + (size_t)(e - out.local_base) * N;
+        lr[0] = -rp;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) lr[1 + i] = -ru[i];
+      }
+      if (out.local_J && out.compute_jacobian) {
+        double *lj = out.local_J + (size_t)(e - out.local_base) * N * N;
+        double row[N * N];
+        row[0] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          row[1 + i] = au * Bv[i];
+          row[(1 + i) * N] = au * Bv[i];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) row[(1 + i) * N + 1 + j] = au * (j >= i ? A[i][j] : A[j][i]);
+        }
+#pragma unroll
+        for (int k = 0; k < N * N; ++k) lj[k] = row[k];
+      }
+    }
+    return;
+  }
+  // dense output, LID-position order: into LDS per thread, then flat and coalesced to memory
   double *sJ = sm + (size_t)tid * N * N, *sR = sm + (size_t)kPorousThreads * N * N + (size_t)tid * N;
   if (active) {
     sR[pos[0]] = -rp;
@@ -150,7 +187,7 @@ __global__ __launch_bounds__(kPorousThreads) void porous_element_kernel(BlockDev
       sJ[pos[0] * N + pos[1 + i]] = au * Bv[i];
       sJ[pos[1 + i] * N + pos[0]] = au * Bv[i];
 #pragma unroll
-      for (int j = 0; j < NU; ++j) sJ[pos[1 + i] * N + pos[1 + j]] = au * A[i][j];
+      for (int j = 0; j < NU; ++j) sJ[pos[1 + i] * N + pos[1 + j]] = au * (j >= i ? A[i][j] : A[j][i]);
     }
   }
   __syncthreads();
@@ -165,6 +202,19 @@ __global__ __launch_bounds__(kPorousThreads) void porous_element_kernel(BlockDev
   }
 }
 
+// The plain-coefficient instantiations are held to 256 registers (two wavefronts per SIMD; left alone the compiler takes
+// ~310 and runs one); the deck-string ones call the interpreter and keep the default budget.
+template <int DIM, bool DOF>
+__global__ __launch_bounds__(kPorousThreads) __attribute__((amdgpu_waves_per_eu(2))) void porous_element_kernel(
+    BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm, ElemOut out) {
+  porous_element_body<DIM, false, DOF>(b, vl, pp, tm, out);
+}
+template <int DIM, bool DOF>
+__global__ __launch_bounds__(kPorousThreads) void porous_element_expr_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
+                                                                            TimeDev tm, ElemOut out) {
+  porous_element_body<DIM, true, DOF>(b, vl, pp, tm, out);
+}
+
 }  // namespace
 
 void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
@@ -174,10 +224,18 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
               "porous element kernel writes dense element arrays only");
   const int grid = (b.e_count + kPorousThreads - 1) / kPorousThreads;
   const int n = 1 + 2 * b.dim;
-  const size_t lds = sizeof(double) * kPorousThreads * std::max<size_t>((size_t)(1 << b.dim) * b.dim, (size_t)n * n + n);
+  const bool dof = out.local_dof_order != 0;
+  MHA_REQUIRE(!dof || out.local_store, MHA_ERR_INVALID, "dof-ordered element arrays are stored, never accumulated into");
+  const size_t lds = dof ? sizeof(double) * kPorousThreads * (size_t)(1 << b.dim) * b.dim : sizeof(double) * kPorousThreads * std::max<size_t>((size_t)(1 << b.dim) * b.dim, (size_t)n * n + n);
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kPorousThreads), lds, stream, b, vl, pp, tm, out); };
-  if (has_expression(pp)) { if (b.dim == 2) go(porous_element_kernel<2, true>); else go(porous_element_kernel<3, true>); }
-  else { if (b.dim == 2) go(porous_element_kernel<2, false>); else go(porous_element_kernel<3, false>); }
+  const bool expr = has_expression(pp);
+  auto pick = [&](auto dim_c, auto dof_c) {
+    constexpr int D = decltype(dim_c)::value;
+    constexpr bool F = decltype(dof_c)::value;
+    if (expr) go(porous_element_expr_kernel<D, F>); else go(porous_element_kernel<D, F>);
+  };
+  if (b.dim == 2) { if (dof) pick(std::integral_constant<int, 2>(), std::true_type()); else pick(std::integral_constant<int, 2>(), std::false_type()); }
+  else { if (dof) pick(std::integral_constant<int, 3>(), std::true_type()); else pick(std::integral_constant<int, 3>(), std::false_type()); }
   MHA_HIP(hipGetLastError());
 }
 

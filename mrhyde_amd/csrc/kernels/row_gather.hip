@@ -81,7 +81,12 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
             if (k >= LPR) { e = g.inc_elem[i0 + k]; pos = g.inc_pos[i0 + k]; }
             const size_t off = ((size_t)e * n + pos) * n + sj, offd = ((size_t)e * n + pos) * n + pos;
             // isAdjoint_: vals[col] = res(elem,row).fastAccessDx(row) for every col; lump_mass_: cols[col] = rowIndex
-            unsafeAtomicAdd(acc + slot[g.lump_mass ? offd : off], local_J[g.adjoint ? offd : off]);
+            if (g.pos2dof) {  // element arrays in dof order (never with those two options): column sj = dof sj at position offsets[sj]
+              const size_t so = ((size_t)e * n + pos) * n + b.offsets[sj];
+              unsafeAtomicAdd(acc + slot[so], local_J[((size_t)e * n + g.pos2dof[pos]) * n + sj]);
+            } else {
+              unsafeAtomicAdd(acc + slot[g.lump_mass ? offd : off], local_J[g.adjoint ? offd : off]);
+            }
           }
         }
         wave_lds_sync();
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
         double r = 0.0;
         for (int k = lane; k < ni; k += LPR) {
           const int e = k < LPR ? e_cur : g.inc_elem[i0 + k], pos = k < LPR ? p_cur : g.inc_pos[i0 + k];
-          r += local_res[(size_t)e * n + pos];
+          r += local_res[(size_t)e * n + (g.pos2dof ? g.pos2dof[pos] : pos)];
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) r += __shfl_xor(r, o, LPR);
