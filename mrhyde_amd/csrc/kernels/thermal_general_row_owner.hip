@@ -346,15 +346,9 @@ __global__ __launch_bounds__(512) void thermal_general_row_owner_kernel(BlockDev
           av[ks] = (j < N && t < T) ? ar : 0.0;
           bv[ks] = (j < N && cok) ? br : 0.0;
         }
-        // two accumulators: the job is a wave's whole work here, a single chain of KJ dependent products would leave the
-        // matrix pipe idle half of the time
-        v4d d = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
+        v4d d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < KJ; ++ks) {
-          if (ks & 1) d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], d1, 0, 0, 0);
-          else d = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], d, 0, 0, 0);
-        }
-        d += d1;
+        for (int ks = 0; ks < KJ; ++ks) d = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], d, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int te = rt * 16 + g4 + 4 * u;
