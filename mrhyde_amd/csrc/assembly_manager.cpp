@@ -206,7 +206,9 @@ void AssemblyManager::prepareRowGather(bool need_jacobian) {
     std::vector<int32_t> offs(n_), p2d(n_, 0);
     d_offsets_.download(offs.data());
     for (int f = 0; f < n_; ++f) p2d[offs[f]] = f;
-    d_pos2dof_.upload(p2d);
+    std::vector<int32_t> ldof(lpos.size());
+    for (size_t k = 0; k < lpos.size(); ++k) ldof[k] = p2d[lpos[k]];
+    d_inc_dof_.upload(ldof);
     max_row_ = 0;
     for (int r = 0; r < nrows_; ++r) max_row_ = std::max(max_row_, h_rowptr_[r + 1] - h_rowptr_[r]);
     has_incidence_ = true;
@@ -534,7 +536,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         launchPointEngine(compute_jacobian, o, 0, nelem_);
       }
       RowGatherDev g;
-      g.pos2dof = dof_order ? d_pos2dof_.data() : nullptr;
+      g.inc_dof = dof_order ? d_inc_dof_.data() : nullptr;
       g.inc_ptr = d_inc_ptr_.data();
       g.inc_elem = d_inc_elem_.data();
       g.inc_pos = d_inc_pos_.data();

@@ -117,7 +117,7 @@ class AssemblyManager {
   bool has_orient_ = false;
   void buildVarLayout();
   // row-gather path: row -> (element, position) incidences on the device, full-block dense scratch
-  DeviceBuffer<int32_t> d_inc_ptr_, d_inc_elem_, d_inc_pos_, d_pos2dof_;
+  DeviceBuffer<int32_t> d_inc_ptr_, d_inc_elem_, d_inc_pos_, d_inc_dof_;
   DeviceBuffer<double> d_gather_J_, d_gather_res_;
   bool has_incidence_ = false;
   int max_row_ = 0;

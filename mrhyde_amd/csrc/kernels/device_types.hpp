@@ -211,8 +211,9 @@ struct RowGatherDev {
   // scatter options of the reference (assemblyManager.cpp:4124-4133): isAdjoint_ takes res(row).dx(row) for every column
   // of the row; lump_mass_ sends every column's value to the diagonal entry (cols[col] = rowIndex)
   int adjoint = 0, lump_mass = 0;
-  const int32_t *pos2dof = nullptr;  // non-null: the element arrays are in (variable, dof) order (ElemOut::local_dof_order);
-                                     // pos2dof[LID position] = flattened dof index, BlockDev::offsets the other way
+  const int32_t *inc_dof = nullptr;  // non-null: the element arrays are in (variable, dof) order (ElemOut::local_dof_order);
+                                     // inc_dof[k] = flattened dof index of incidence k (inc_pos[k] is its LID position),
+                                     // BlockDev::offsets maps a column's dof index to its position
 };
 
 // shallowwaterHybridized side terms at npts side integration points (kernels/swhdg_side.hip); state order H, Hux, Huy

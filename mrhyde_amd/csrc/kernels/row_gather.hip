@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -25,7 +26,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// LPR lanes per row: 64 (one row per wavefront) or 16 (four short rows per wavefront: mixed lowest-order elements have
+// LPR lanes per row: 64 (one row per wavefront), 16 or 8 (four / eight short rows per wavefront: mixed lowest-order elements have
 // CRS rows of ~10 entries)
 template <typename SlotT, int LPR>
 __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDev g, const double *__restrict__ local_J,
@@ -57,10 +58,12 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
   const int row0 = (blockIdx.x * 4 + wave) * RPW + sub;
   Meta m_cur = load_meta(row0), m_nxt = load_meta(row0 + nwaves);
   int e_cur = (lane < m_cur.ni) ? g.inc_elem[m_cur.i0 + lane] : 0, p_cur = (lane < m_cur.ni) ? g.inc_pos[m_cur.i0 + lane] : 0;
+  int d_cur = (g.inc_dof && lane < m_cur.ni) ? g.inc_dof[m_cur.i0 + lane] : 0;  // dof-ordered element arrays only
   for (int row = row0; row < b.nrows; row += nwaves) {
     // prefetch: incidences of the next row (its pointers were requested one iteration ago), pointers of the one after
     const int e_nxt = (lane < m_nxt.ni) ? g.inc_elem[m_nxt.i0 + lane] : 0;
     const int p_nxt = (lane < m_nxt.ni) ? g.inc_pos[m_nxt.i0 + lane] : 0;
+    const int d_nxt = (g.inc_dof && lane < m_nxt.ni) ? g.inc_dof[m_nxt.i0 + lane] : 0;
     const Meta m_nn = load_meta(row + 2 * nwaves);
     const int lo = m_cur.lo, len = m_cur.len, i0 = m_cur.i0, ni = m_cur.ni;
     if (m_cur.fixed) {  // isFixedDOF rows are skipped by the scatter (assemblyManager.cpp:4075,4120)
@@ -77,13 +80,14 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
           const int k = valid ? t / n : 0, sj = t - k * n;
           // incidences 0..LPR-1 sit in the row group's registers; longer rows (never for quads / hexes) re-read them
           int e = __shfl(e_cur, k & (LPR - 1), LPR), pos = __shfl(p_cur, k & (LPR - 1), LPR);
+          int dof = __shfl(d_cur, k & (LPR - 1), LPR);
           if (valid) {
-            if (k >= LPR) { e = g.inc_elem[i0 + k]; pos = g.inc_pos[i0 + k]; }
+            if (k >= LPR) { e = g.inc_elem[i0 + k]; pos = g.inc_pos[i0 + k]; dof = g.inc_dof ? g.inc_dof[i0 + k] : 0; }
             const size_t off = ((size_t)e * n + pos) * n + sj, offd = ((size_t)e * n + pos) * n + pos;
             // isAdjoint_: vals[col] = res(elem,row).fastAccessDx(row) for every col; lump_mass_: cols[col] = rowIndex
-            if (g.pos2dof) {  // element arrays in dof order (never with those two options): column sj = dof sj at position offsets[sj]
+            if (g.inc_dof) {  // element arrays in dof order (never with those two options): column sj = dof sj at position offsets[sj]
               const size_t so = ((size_t)e * n + pos) * n + b.offsets[sj];
-              unsafeAtomicAdd(acc + slot[so], local_J[((size_t)e * n + g.pos2dof[pos]) * n + sj]);
+              unsafeAtomicAdd(acc + slot[so], local_J[((size_t)e * n + dof) * n + sj]);
             } else {
               unsafeAtomicAdd(acc + slot[g.lump_mass ? offd : off], local_J[g.adjoint ? offd : off]);
             }
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
         double r = 0.0;
         for (int k = lane; k < ni; k += LPR) {
           const int e = k < LPR ? e_cur : g.inc_elem[i0 + k], pos = k < LPR ? p_cur : g.inc_pos[i0 + k];
-          r += local_res[(size_t)e * n + (g.pos2dof ? g.pos2dof[pos] : pos)];
+          const int dof = k < LPR ? d_cur : (g.inc_dof ? g.inc_dof[i0 + k] : 0);
+          r += local_res[(size_t)e * n + (g.inc_dof ? dof : pos)];
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) r += __shfl_xor(r, o, LPR);
@@ -112,6 +117,7 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
     m_nxt = m_nn;
     e_cur = e_nxt;
     p_cur = p_nxt;
+    d_cur = d_nxt;
   }
 }
 
@@ -121,14 +127,20 @@ void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *l
                        double *res, double *vals, int overwrite, hipStream_t stream) {
   if (b.nrows <= 0) return;
   const bool small_rows = g.max_row <= 32 && b.n <= 16;
-  const int rpw = small_rows ? 4 : 1;
+  // eight rows per wavefront for the lowest-order mixed element (CRS rows of <= 13 entries from <= 2 elements): twice the
+  // rows in flight per wavefront; MHA_GATHER_LPR=16 keeps four
+  static const int lpr_env = [] { const char *m = std::getenv("MHA_GATHER_LPR"); return m ? std::atoi(m) : 0; }();
+  const bool tiny_ok = small_rows && g.max_row <= 16 && b.n <= 8 && g.slot_bytes == 1;
+  const int lpr = !small_rows ? 64 : (tiny_ok && lpr_env != 16) ? 8 : 16;  // (4 lanes per row: 1.65 against 1.53 ms at config 3)
+  const int rpw = 64 / lpr;
   const size_t lds = sizeof(double) * 4 * rpw * (size_t)g.max_row;
   MHA_REQUIRE(lds <= 64 * 1024, MHA_ERR_INVALID, "CRS rows of " << g.max_row << " entries do not fit the row-gather kernel");
   const int grid = std::min((b.nrows + 4 * rpw - 1) / (4 * rpw), 256 * 8);
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, b, g, local_J, local_res, res, vals, overwrite);
   };
-  if (g.slot_bytes == 1) { if (small_rows) go(row_gather_kernel<uint8_t, 16>); else go(row_gather_kernel<uint8_t, 64>); }
+  if (lpr == 8) go(row_gather_kernel<uint8_t, 8>);
+  else if (g.slot_bytes == 1) { if (small_rows) go(row_gather_kernel<uint8_t, 16>); else go(row_gather_kernel<uint8_t, 64>); }
   else { if (small_rows) go(row_gather_kernel<uint16_t, 16>); else go(row_gather_kernel<uint16_t, 64>); }
   MHA_HIP(hipGetLastError());
 }
