@@ -116,8 +116,9 @@ inline int current_device_num_cus() {
 // bytes out of device memory at launch; when that fails the HSA runtime abort()s the process -- nothing the C ABI can
 // catch (the round-1 `MHA_ENGINE_MINW` build variants of the point engine spilled up to 359 registers = 1.4 KB per lane,
 // 0.75 GB for the chip, and their porousMixed run died with SIGABRT).  Launchers of kernels that CAN spill ask here
-// first: more than the limit (default 1.25 KB per lane -- the deck-string instantiations of the point engine carry the
-// interpreter's 1.0-1.06 KB of stack by design --, env MHA_MAX_SCRATCH_BYTES) is refused with MHA_ERR_DEVICE.
+// first: more than the limit (default 1.25 KB per lane; the deck-string instantiations, which carry the interpreter's
+// stack and spill around it, need 0.15-0.55 KB since the interpreter is inlined -- 1.0-1.3 KB when it was a call --, env
+// MHA_MAX_SCRATCH_BYTES) is refused with MHA_ERR_DEVICE.
 template <class Kernel>
 inline void require_modest_scratch(Kernel kern, const char *what) {
   hipFuncAttributes attr;

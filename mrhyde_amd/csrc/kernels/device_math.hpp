@@ -60,8 +60,10 @@ __device__ __forceinline__ double sin_reduced(double x) {
 
 // MHA_FUNC_EXPRESSION: postfix program over x y z t nx ny nz h pi (expression.hpp); normals / h are 0 when the caller
 // has none.  The reference evaluates one kernel per node of the expression DAG (functionManager.cpp:543-860).
+// Inlined: as a call it made every deck-string kernel save its live registers around each evaluation (1.0-1.3 KB of
+// scratch per lane, 200+ spilled registers in the row-owner and engine kernels; inlined 0.15-0.55 KB).
 template <int DIM>
-__device__ __noinline__ double eval_expression(const FuncDesc &f, const double *x, const double *nrm, double h) {
+__device__ __forceinline__ double eval_expression(const FuncDesc &f, const double *x, const double *nrm, double h) {
   double st[kExprStack];
   int sp = 0;
   for (const int32_t *pc = f.code;; ++pc) {

@@ -331,7 +331,7 @@ def test_launch_that_needs_too_much_scratch_is_refused(oracle, monkeypatch):
     """A kernel whose spills need a large scratch arena can take the process down inside the runtime (the round-1
     MHA_ENGINE_MINW variants of the engine did, on porousMixed 128^3).  The launchers check the kernel's private segment
     first: over the limit -> MHA_ERR_DEVICE and a message, not SIGABRT.  The deck-string instantiation of the engine
-    carries the interpreter's 640-byte stack: with the limit lowered below that it must be refused, and run with the
+    carries the interpreter's stack and the spills around it (about 150 B per lane): with the limit lowered below that it must be refused, and run with the
     default limit."""
     torch = _torch()
     import mrhyde_amd
