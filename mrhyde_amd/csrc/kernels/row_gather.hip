@@ -28,7 +28,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // LPR lanes per row: 64 (one row per wavefront), 16 or 8 (four / eight short rows per wavefront: mixed lowest-order elements have
 // CRS rows of ~10 entries)
-template <typename SlotT, int LPR>
+// DOF: the element arrays are in (variable, dof) order (RowGatherDev::inc_dof); a template flag so that the position-order
+// instantiations carry none of it (as a run-time branch it cost the 89-dof gather 0.94 -> 1.5 ms at 32^3)
+template <typename SlotT, int LPR, bool DOF>
 __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDev g, const double *__restrict__ local_J,
                                                          const double *__restrict__ local_res, double *res, double *vals,
                                                          int overwrite) {
@@ -58,12 +60,12 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
   const int row0 = (blockIdx.x * 4 + wave) * RPW + sub;
   Meta m_cur = load_meta(row0), m_nxt = load_meta(row0 + nwaves);
   int e_cur = (lane < m_cur.ni) ? g.inc_elem[m_cur.i0 + lane] : 0, p_cur = (lane < m_cur.ni) ? g.inc_pos[m_cur.i0 + lane] : 0;
-  int d_cur = (g.inc_dof && lane < m_cur.ni) ? g.inc_dof[m_cur.i0 + lane] : 0;  // dof-ordered element arrays only
+  int d_cur = (DOF && lane < m_cur.ni) ? g.inc_dof[m_cur.i0 + lane] : 0;  // dof-ordered element arrays only
   for (int row = row0; row < b.nrows; row += nwaves) {
     // prefetch: incidences of the next row (its pointers were requested one iteration ago), pointers of the one after
     const int e_nxt = (lane < m_nxt.ni) ? g.inc_elem[m_nxt.i0 + lane] : 0;
     const int p_nxt = (lane < m_nxt.ni) ? g.inc_pos[m_nxt.i0 + lane] : 0;
-    const int d_nxt = (g.inc_dof && lane < m_nxt.ni) ? g.inc_dof[m_nxt.i0 + lane] : 0;
+    const int d_nxt = (DOF && lane < m_nxt.ni) ? g.inc_dof[m_nxt.i0 + lane] : 0;
     const Meta m_nn = load_meta(row + 2 * nwaves);
     const int lo = m_cur.lo, len = m_cur.len, i0 = m_cur.i0, ni = m_cur.ni;
     if (m_cur.fixed) {  // isFixedDOF rows are skipped by the scatter (assemblyManager.cpp:4075,4120)
@@ -80,12 +82,12 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
           const int k = valid ? t / n : 0, sj = t - k * n;
           // incidences 0..LPR-1 sit in the row group's registers; longer rows (never for quads / hexes) re-read them
           int e = __shfl(e_cur, k & (LPR - 1), LPR), pos = __shfl(p_cur, k & (LPR - 1), LPR);
-          int dof = __shfl(d_cur, k & (LPR - 1), LPR);
+          int dof = DOF ? __shfl(d_cur, k & (LPR - 1), LPR) : 0;
           if (valid) {
-            if (k >= LPR) { e = g.inc_elem[i0 + k]; pos = g.inc_pos[i0 + k]; dof = g.inc_dof ? g.inc_dof[i0 + k] : 0; }
+            if (k >= LPR) { e = g.inc_elem[i0 + k]; pos = g.inc_pos[i0 + k]; if constexpr (DOF) dof = g.inc_dof[i0 + k]; }
             const size_t off = ((size_t)e * n + pos) * n + sj, offd = ((size_t)e * n + pos) * n + pos;
             // isAdjoint_: vals[col] = res(elem,row).fastAccessDx(row) for every col; lump_mass_: cols[col] = rowIndex
-            if (g.inc_dof) {  // element arrays in dof order (never with those two options): column sj = dof sj at position offsets[sj]
+            if constexpr (DOF) {  // element arrays in dof order (never with those two options): column sj = dof sj at position offsets[sj]
               const size_t so = ((size_t)e * n + pos) * n + b.offsets[sj];
               unsafeAtomicAdd(acc + slot[so], local_J[((size_t)e * n + dof) * n + sj]);
             } else {
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void row_gather_kernel(BlockDev b, RowGatherDe
         double r = 0.0;
         for (int k = lane; k < ni; k += LPR) {
           const int e = k < LPR ? e_cur : g.inc_elem[i0 + k], pos = k < LPR ? p_cur : g.inc_pos[i0 + k];
-          const int dof = k < LPR ? d_cur : (g.inc_dof ? g.inc_dof[i0 + k] : 0);
-          r += local_res[(size_t)e * n + (g.inc_dof ? dof : pos)];
+          const int dof = !DOF ? 0 : k < LPR ? d_cur : g.inc_dof[i0 + k];
+          r += local_res[(size_t)e * n + (DOF ? dof : pos)];
         }
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) r += __shfl_xor(r, o, LPR);
@@ -139,9 +141,15 @@ void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *l
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, b, g, local_J, local_res, res, vals, overwrite);
   };
-  if (lpr == 8) go(row_gather_kernel<uint8_t, 8>);
-  else if (g.slot_bytes == 1) { if (small_rows) go(row_gather_kernel<uint8_t, 16>); else go(row_gather_kernel<uint8_t, 64>); }
-  else { if (small_rows) go(row_gather_kernel<uint16_t, 16>); else go(row_gather_kernel<uint16_t, 64>); }
+  const bool dof = g.inc_dof != nullptr;
+  MHA_REQUIRE(!dof || (small_rows && g.slot_bytes == 1 && !g.adjoint && !g.lump_mass), MHA_ERR_INVALID,
+              "dof-ordered element arrays are gathered by the short-row kernels only");
+  if (lpr == 8) { if (dof) go(row_gather_kernel<uint8_t, 8, true>); else go(row_gather_kernel<uint8_t, 8, false>); }
+  else if (g.slot_bytes == 1) {
+    if (!small_rows) go(row_gather_kernel<uint8_t, 64, false>);
+    else if (dof) go(row_gather_kernel<uint8_t, 16, true>);
+    else go(row_gather_kernel<uint8_t, 16, false>);
+  } else { if (small_rows) go(row_gather_kernel<uint16_t, 16, false>); else go(row_gather_kernel<uint16_t, 64, false>); }
   MHA_HIP(hipGetLastError());
 }
 
