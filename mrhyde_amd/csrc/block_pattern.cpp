@@ -281,8 +281,10 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
           for (int q = 0; q < pb.ntile + pb.tail; ++q) {
             bool any = false;
             for (int r = 4 * sidx; r < 4 * sidx + 4 && !any; ++r)
-              for (int cc = 16 * (pb.ct0 + q); cc < 16 * (pb.ct0 + q) + 16 && !any; ++cc)
+              for (int lc = 0; lc < 16 && !any; ++lc) {
+                const int cc = bp_unit_col(pb.ct0, pb.ntile, q, lc);
                 any = Wk[static_cast<size_t>(r) * rc.stride + cc] != 0.0 || Wm[static_cast<size_t>(r) * rc.stride + cc] != 0.0;
+              }
             nzb += any ? 1 : 0;
           }
         pb.cost = nzb + 1;
@@ -327,27 +329,29 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
             for (int q = 0; q < pb.ntile + pb.tail; ++q) {
               bool any = false;
               for (int r = 4 * sidx; r < 4 * sidx + 4 && !any; ++r)
-                for (int cc = 16 * (pb.ct0 + q); cc < 16 * (pb.ct0 + q) + 16 && !any; ++cc)
+                for (int lc = 0; lc < 16 && !any; ++lc) {
+                  const int cc = bp_unit_col(pb.ct0, pb.ntile, q, lc);
                   any = Wk[static_cast<size_t>(r) * rc.stride + cc] != 0.0 || Wm[static_cast<size_t>(r) * rc.stride + cc] != 0.0;
+                }
               const int bit = sidx * 5 + q;
               if (any) hdr[H_MASK0 + bit / 32] |= static_cast<int32_t>(1u << (bit % 32));
             }
-          // trim class of the unit (flags bits 2..4, read by the kernel's specialised forms): all column tiles but the
-          // last (classes 1, 3) or but the first (2, 4) have only zero blocks in the second (1, 4) or first (2, 3) half
-          // of the k-steps
+          // trim class of a unit of two tile pairs (flags bits 2..4, read by the kernel's specialised form): the first pair
+          // (classes 1, 3) or the second (2, 4) has only zero blocks in the second (1, 4) or first (2, 3) half of the k-steps
           const int nq = pb.ntile + pb.tail;
           if (nq >= 2 && rc.ks >= 2) {
             bool t[5] = {false, true, true, true, true};
+            if (pb.ntile != 4 || pb.tail) t[1] = t[2] = t[3] = t[4] = false;
             for (int sidx = 0; sidx < rc.ks; ++sidx)
               for (int q = 0; q < nq; ++q) {
                 const int bit = sidx * 5 + q;
                 const bool nz = (static_cast<uint32_t>(hdr[H_MASK0 + bit / 32]) >> (bit % 32)) & 1u;
                 if (!nz) continue;
                 const bool second = sidx >= rc.ks / 2;
-                if (q < nq - 1 && second) t[1] = false;
-                if (q >= 1 && !second) t[2] = false;
-                if (q < nq - 1 && !second) t[3] = false;
-                if (q >= 1 && second) t[4] = false;
+                if (q < 2 && second) t[1] = false;
+                if (q >= 2 && !second) t[2] = false;
+                if (q < 2 && !second) t[3] = false;
+                if (q >= 2 && second) t[4] = false;
               }
             for (int k = 1; k <= 4; ++k)
               if (t[k]) { hdr[H_FLAGS] |= k << 2; break; }
@@ -406,6 +410,24 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
         }
       }
     }
+    // wave 0 also fetches the element records, which the kernel builds only into its shapes of at most three chains:
+    // give it such a unit (from the same SIMD if there is one: wavefront id mod 4)
+    for (size_t k = 0; k < bin_fill.size(); ++k) {
+      RoleBuild &role = roles[first_role + k];
+      auto chains = [&](int wv) {  // of a wavefront that owns exactly one product unit, else 0
+        if (role.wave_parts[wv].size() != 1) return 0;
+        const int32_t *h = &pl.part_hdr[static_cast<size_t>(role.wave_parts[wv][0]) * kBpHdrInts];
+        return (h[H_FLAGS] & 1) ? 0 : h[H_NTILE] + ((h[H_FLAGS] & 2) ? 1 : 0);
+      };
+      if (chains(0) <= 3) continue;
+      int best = -1;
+      for (int wv = 1; wv < kBpWaves; ++wv) {
+        const int nc = chains(wv);
+        if (nc < 1 || nc > 3) continue;
+        if (best < 0 || (wv % 4 == 0 && best % 4 != 0)) best = wv;
+      }
+      if (best > 0) std::swap(role.wave_parts[0], role.wave_parts[best]);
+    }
     pl.num_classes += static_cast<int>(classes.size());
   }
 
@@ -435,41 +457,6 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
       }
     pl.part_hdr.swap(new_hdr);
     pl.part_lane.swap(new_lane);
-  }
-  for (int k = 0; k < pl.num_roles; ++k) {
-    const RoleBuild &r = roles[k];
-    const std::vector<int32_t> &blocks = members[r.pattern];
-    int32_t *ro = &pl.role[static_cast<size_t>(k) * kBpRoleInts];
-    const int64_t erec_base = static_cast<int64_t>(pl.erec_elem.size());
-    const int64_t row_base = static_cast<int64_t>(pl.rowbase.size());
-    ro[R_EREC_LO] = static_cast<int32_t>(erec_base & 0xffffffffll);
-    ro[R_EREC_HI] = static_cast<int32_t>(erec_base >> 32);
-    ro[R_ESTRIDE] = r.T + 1;
-    ro[R_ROWB_LO] = static_cast<int32_t>(row_base & 0xffffffffll);
-    ro[R_ROWB_HI] = static_cast<int32_t>(row_base >> 32);
-    ro[R_NRUNS] = r.nruns;
-    ro[R_NBLOCKS] = static_cast<int32_t>(blocks.size());
-    ro[R_COST] = static_cast<int32_t>(std::min<int64_t>(r.cost, 0x7fffffff));
-    ro[R_WOFF_LO] = static_cast<int32_t>(r.w_off & 0xffffffffll);
-    ro[R_WOFF_HI] = static_cast<int32_t>(r.w_off >> 32);
-    ro[R_WDOUBLES] = r.w_doubles;
-    ro[R_PATTERN] = r.pattern;
-    ro[R_NELEMS] = r.T;
-    for (int32_t b : blocks) {
-      for (int t = rb.elem_ptr[b]; t < rb.elem_ptr[b + 1]; ++t) pl.erec_elem.push_back(rb.elems[t]);
-      pl.erec_elem.push_back(-1);
-      for (int o = rb.row_ptr[b]; o < rb.row_ptr[b + 1]; ++o)  // CRS offset of the first row of every run
-        if (o == rb.row_ptr[b] || rb.rows[o - 1] + 1 != rb.rows[o]) pl.rowbase.push_back(rb.row_base[o]);
-    }
-    int64_t mf = 0;
-    for (int wv = 0; wv < kBpWaves; ++wv)
-      for (int p = pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv]; p < pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv + 1]; ++p) {
-        const int32_t *h = &pl.part_hdr[static_cast<size_t>(p) * kBpHdrInts];
-        int bits = 0;
-        for (int wd = 0; wd < 3; ++wd) bits += __builtin_popcount(static_cast<uint32_t>(h[H_MASK0 + wd]));
-        mf += static_cast<int64_t>(bits) * static_cast<int64_t>(blocks.size());
-      }
-    pl.mfma_per_assembly += mf;
   }
   // ---- 5. persistent workgroups, exactly one per CU: the role-major block sequence is cut into num_cus contiguous
   //         pieces of equal cost; a piece that crosses a role boundary becomes several SEGMENTS (the workgroup reloads
@@ -522,6 +509,70 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
     }
     pl.num_wgs = nwg;
   }
+  // ---- 5b. order of a role's blocks inside its block-major tables.  A workgroup walks a contiguous range of them
+  //          (its segment), one block at a time, and all workgroups run at about the same pace: the t-th blocks of all
+  //          segments are written at about the same time.  They are made NEIGHBOURS IN THE CRS VALUE ARRAY (blocks sorted
+  //          by the offset of their first row, dealt round robin over the role's segments): the ~256 x 64 KB in flight
+  //          then cover a few contiguous megabytes instead of 4096 scattered row runs, which is what the memory's
+  //          row buffers need (measured: the stores alone took 336 us for 1.08 GB with every workgroup in a region of
+  //          its own).  MHA_BP_ORDER=morton keeps the blocks in partition order. ----
+  std::vector<std::vector<int32_t>> role_blocks(pl.num_roles);
+  {
+    const char *env = std::getenv("MHA_BP_ORDER");
+    const bool interleave = !(env && std::string(env) == "morton");
+    std::vector<std::vector<std::pair<int, int>>> segs(pl.num_roles);  // per role: (first, blocks) of its segments
+    for (size_t sg = 0; sg < pl.seg.size() / 4; ++sg) segs[pl.seg[4 * sg]].push_back({pl.seg[4 * sg + 1], pl.seg[4 * sg + 2]});
+    for (int k = 0; k < pl.num_roles; ++k) {
+      std::vector<int32_t> sorted = members[roles[k].pattern];
+      if (interleave)
+        std::stable_sort(sorted.begin(), sorted.end(), [&](int32_t x, int32_t y) { return rb.row_base[rb.row_ptr[x]] < rb.row_base[rb.row_ptr[y]]; });
+      std::vector<int32_t> &out = role_blocks[k];
+      out.assign(sorted.size(), -1);
+      if (!interleave) { out = sorted; continue; }
+      size_t next = 0;
+      int longest = 0;
+      for (const auto &sg : segs[k]) longest = std::max(longest, sg.second);
+      for (int t = 0; t < longest; ++t)
+        for (const auto &sg : segs[k])
+          if (t < sg.second) out[static_cast<size_t>(sg.first) + t] = sorted[next++];
+      if (next != sorted.size()) return fail("the segments of a role do not cover its blocks");
+    }
+  }
+  for (int k = 0; k < pl.num_roles; ++k) {
+    const RoleBuild &r = roles[k];
+    const std::vector<int32_t> &blocks = role_blocks[k];
+    int32_t *ro = &pl.role[static_cast<size_t>(k) * kBpRoleInts];
+    const int64_t erec_base = static_cast<int64_t>(pl.erec_elem.size());
+    const int64_t row_base = static_cast<int64_t>(pl.rowbase.size());
+    ro[R_EREC_LO] = static_cast<int32_t>(erec_base & 0xffffffffll);
+    ro[R_EREC_HI] = static_cast<int32_t>(erec_base >> 32);
+    ro[R_ESTRIDE] = r.T + 1;
+    ro[R_ROWB_LO] = static_cast<int32_t>(row_base & 0xffffffffll);
+    ro[R_ROWB_HI] = static_cast<int32_t>(row_base >> 32);
+    ro[R_NRUNS] = r.nruns;
+    ro[R_NBLOCKS] = static_cast<int32_t>(blocks.size());
+    ro[R_COST] = static_cast<int32_t>(std::min<int64_t>(r.cost, 0x7fffffff));
+    ro[R_WOFF_LO] = static_cast<int32_t>(r.w_off & 0xffffffffll);
+    ro[R_WOFF_HI] = static_cast<int32_t>(r.w_off >> 32);
+    ro[R_WDOUBLES] = r.w_doubles;
+    ro[R_PATTERN] = r.pattern;
+    ro[R_NELEMS] = r.T;
+    for (int32_t b : blocks) {
+      for (int t = rb.elem_ptr[b]; t < rb.elem_ptr[b + 1]; ++t) pl.erec_elem.push_back(rb.elems[t]);
+      pl.erec_elem.push_back(-1);
+      for (int o = rb.row_ptr[b]; o < rb.row_ptr[b + 1]; ++o)  // CRS offset of the first row of every run
+        if (o == rb.row_ptr[b] || rb.rows[o - 1] + 1 != rb.rows[o]) pl.rowbase.push_back(rb.row_base[o]);
+    }
+    int64_t mf = 0;
+    for (int wv = 0; wv < kBpWaves; ++wv)
+      for (int p = pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv]; p < pl.part_ptr[static_cast<size_t>(k) * (kBpWaves + 1) + wv + 1]; ++p) {
+        const int32_t *h = &pl.part_hdr[static_cast<size_t>(p) * kBpHdrInts];
+        int bits = 0;
+        for (int wd = 0; wd < 3; ++wd) bits += __builtin_popcount(static_cast<uint32_t>(h[H_MASK0 + wd]));
+        mf += static_cast<int64_t>(bits) * static_cast<int64_t>(blocks.size());
+      }
+    pl.mfma_per_assembly += mf;
+  }
   pl.usable = true;
   return pl;
 }
@@ -566,12 +617,26 @@ void block_patterns_host_apply(const BlockPatternPlan &pl, const double *factors
             const int base = pl.rowbase[static_cast<size_t>(row_base + j * nruns + (packed >> 20))] + (packed & 0xfffff);
             for (int c = c_begin; c < c_end; ++c) {
               double v = 0.0;
-              for (int s = 0; s < ks; ++s)
+              // chain of the unit that holds column c (bp_unit_col), then the products the kernel skips for it
+              int qc = -1;
+              for (int q = 0; q < h[H_NTILE] + ((h[H_FLAGS] & 2) ? 1 : 0) && qc < 0; ++q)
+                for (int lc = 0; lc < 16; ++lc)
+                  if (bp_unit_col(h[H_CT0], h[H_NTILE], q, lc) == c) { qc = q; break; }
+              MHA_REQUIRE(qc >= 0, MHA_ERR_STATE, "a column of a unit belongs to none of its chains");
+              const int trim = (h[H_NTILE] == 4 && !(h[H_FLAGS] & 2)) ? (h[H_FLAGS] >> 2) & 7 : 0;
+              for (int s = 0; s < ks; ++s) {
+                const bool second = s >= ks / 2;
+                if ((trim == 1 && qc < 2 && second) || (trim == 2 && qc >= 2 && !second) || (trim == 3 && qc < 2 && !second) ||
+                    (trim == 4 && qc >= 2 && second))
+                  continue;
+                const int bit = s * 5 + qc;
+                if (!((static_cast<uint32_t>(h[H_MASK0 + bit / 32]) >> (bit % 32)) & 1u)) continue;  // a zero block of W
                 for (int kk = 0; kk < 4; ++kk) {
                   const int lane = kk * 16 + row;  // A operand: row = lane & 15, k = 4 s + (lane >> 4)
                   const size_t wi = static_cast<size_t>(4 * s + kk) * stride + c;
                   v += rec[L[s * 64 + lane]] * (su * W[wi] + st * Wm[wi]);
                 }
+              }
               if (overwrite) vals[base + c] = fixed_class ? 0.0 : v;
               else vals[base + c] += v;
             }

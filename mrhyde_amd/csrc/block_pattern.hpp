@@ -41,6 +41,18 @@ constexpr int kBpRoleInts = 16;    // see block_pattern.cpp
 constexpr int kBpSegInts = 2048;    // (blocks of one segment) x (runs of consecutive rows per block): their CRS offsets sit in LDS
 constexpr int kBpRecDoubles = 8;   // element record: g_0..g_{nsym-1}, detJ, zero padding
 
+// Columns of a UNIT (up to four 16-column tiles of a 16-row class tile + an optional tail tile) as the kernel's
+// accumulation chains see them: the tiles come in PAIRS whose columns interleave -- lane c of chain 2p holds column
+// 32p + 2c, of chain 2p + 1 column 32p + 2c + 1 -- so that a lane owns two neighbouring entries of a row and stores
+// them with one 16-byte instruction (the store path of a CU takes one instruction per ~40 cycles whatever its width);
+// an odd last tile and the tail tile keep the plain order.  Offsets are relative to the row, in entries.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int bp_unit_col(int ct0, int ntile, int q, int c) {
+  return q < 2 * (ntile / 2) ? 16 * ct0 + 32 * (q >> 1) + 2 * c + (q & 1) : 16 * (ct0 + q) + c;
+}
+
 struct BlockPatternPlan {
   bool usable = false;
   std::string why;

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_math.hpp"
 #include "launch.hpp"
@@ -74,6 +75,7 @@ __device__ __forceinline__ v4i make_rsrc(const void *p, unsigned bytes) {
 constexpr unsigned kOutOfRange = 0x80000000u;  // offset of a lane that must not store
 // the raw buffer store intrinsic with the descriptor as four ints (a store hipcc tracks like any other: it never waits for it)
 __device__ void raw_buffer_store_b64(v2i data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
+__device__ void raw_buffer_store_b128(v4i data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4i32");
 
 // loads hipcc does not count (see the header): destination "=v", descriptor and block offset in scalar registers
 __device__ __forceinline__ double asm_load_f64(const v4i &rsrc, unsigned lane_off, int block_off) {
@@ -103,23 +105,11 @@ struct UnitCtx {
   int ct0;                 // first column tile of the unit
   const double *Wl;        // this lane's corner of the class's W image in LDS
   unsigned mask[3];        // bit s * 5 + q: the W block of k-step s, tile q of the unit is not zero
-  int trim;                // trim class of the unit (host: flags 4 / 8), wave-uniform
+  int trim;                // trim class of the unit (host: flags 4 / 8 / 16), wave-uniform
   double *recbuf;          // LDS: two images of a block's element records, recstride doubles apart
   int recstride;
   long long *tlog;         // profiling (DBG & 8): 8 wall-clock stamps of this wavefront
 };
-
-// 4 x 4 transpose of quarter waves across four registers: x[c] holds M[g][c] in quarter wave g, afterwards M[c][g]
-// (gfx950's lane-swap instructions: v_permlane32_swap exchanges the upper half of its first operand with the lower half
-// of its second, v_permlane16_swap the odd quarter waves of the first with the even ones of the second).
-__device__ __forceinline__ void transpose_quarters(unsigned (&x)[4]) {
-  auto swap32 = [](unsigned &a, unsigned &b) { const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; };
-  auto swap16 = [](unsigned &a, unsigned &b) { const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1]; };
-  swap32(x[0], x[2]);
-  swap32(x[1], x[3]);
-  swap16(x[0], x[1]);
-  swap16(x[2], x[3]);
-}
 
 // Element records of a block: (T + 1) x 8 doubles, contiguous in memory.  One wavefront (the loader: wave 0) fetches
 // them with a handful of coalesced loads two blocks ahead and puts them into a double-buffered LDS image; every unit
@@ -127,27 +117,34 @@ __device__ __forceinline__ void transpose_quarters(unsigned (&x)[4]) {
 // instructions per block in front of the CU's one address pipeline, which the stores already saturate.)
 constexpr int kRecLoads = 8;  // 64-lane loads of 8 bytes per block: (T + 1) * 8 doubles <= 512 (the host checks); DBG bit 32: <= 384, 6 loads
 
-// One unit over all blocks of the segment: depth KS, NT column tiles stored row-contiguous (0: none) and, with TAIL, one
-// more tile stored as it stands; overwrite mode.
+// One unit over all blocks of the segment: depth KS, NT column tiles and, with TAIL, one more tile; overwrite mode.
 //
-// Software pipeline, one block deep: while the products of block i accumulate, the results of block i - 1 are
-// transposed and stored, a few store instructions after every k-step (a CU's store path takes one 512-byte instruction
-// per ~40 cycles -- 156 per block: 2.7 us -- and the matrix cores need ~2 us per block).  All wavefronts meet at a
-// barrier once per block: the rows of a block reach the memory together.  The loader's record fetches are inline asm
-// (hipcc does not track them; gfx950 counts loads and stores in one in-order vmcnt) retired with a counted s_waitcnt
-// that leaves the current block's stores in flight.
-// TRIM = 3: k-steps whose W block is zero for a whole group of column tiles are not multiplied.  The columns of a row are
-// sorted by global id and so are a block's elements: around a vertex dof of a hex mesh one half of the k-steps (four of
-// the eight elements) reaches only the first ~5 column tiles and the other half only the last ~5, so in a unit of four
-// tiles three tiles see zero blocks during one half of the k-steps (56 -> 35 products for the 14 x 4 units).  The host
-// classifies the unit (c.trim: 1..4 = which tiles, which half; block_pattern.cpp), wave-uniform; the conditions below
-// fold to one scalar test per product after unrolling.
-template <int KS, int NT, bool TAIL, int DBG, int TRIM = 0>
-__device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__restrict__ L, int lane, bool loader) {
+// Columns (bp_unit_col, block_pattern.hpp): the NT tiles come in pairs with interleaved columns -- lane (g, c) of chains
+// 2p and 2p + 1 holds entries 32p + 2c and 32p + 2c + 1 of tile row g + 4t in result register t -- so the lane stores
+// both with ONE 16-byte instruction, four 256-byte row pieces per instruction and no transposition; an odd last tile
+// and the tail tile keep the MFMA layout (16 entries x 4 rows per register, 8-byte stores).  A CU's store path takes
+// one instruction per ~40 cycles whatever its width: 16 x (8-byte, one row of 64 entries) stores per unit of four
+// tiles became 8.  Where the row ends inside a pair (odd row length: every row of a hex mesh) the lane holding the
+// last entry stores it with an 8-byte instruction of its own (STRADDLE, 4 more instructions; wave-uniform).
+//
+// Software pipeline, one block deep: while the products of block i accumulate, the results of block i - 1 are stored,
+// a few store instructions after every k-step.  All wavefronts meet at a barrier once per block: the rows of a block
+// reach the memory together.  The loader's record fetches are inline asm (hipcc does not track them; gfx950 counts
+// loads and stores in one in-order vmcnt) retired with a counted s_waitcnt that leaves the current block's stores in
+// flight (with STRADDLE stores it waits for the four oldest of them as well).
+// TRIM = 4: products whose 4 x 16 block of W is zero are skipped by a scalar mask-bit test (host: H_MASK*).
+// LOADER: this wavefront also fetches the element records (wave 0; only the shapes of at most three chains are built
+// with it -- the record registers are what the widest shapes have no room for -- and the planner gives wave 0 such a
+// unit; a wave 0 that holds a wider one runs the plain form).
+template <int KS, int NT, bool TAIL, int DBG, int TRIM = 0, bool LOADER = false>
+__device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__restrict__ L, int lane) {
+  constexpr bool loader = LOADER;
   constexpr int NPK = (KS + 1) / 2;
   constexpr int NQ = NT + (TAIL ? 1 : 0);                 // accumulation chains
-  constexpr int NGS = NT > 0 ? 16 : 0, STORES = NGS + (TAIL ? 4 : 0);
-  static_assert(STORES < 64, "the counted wait must fit vmcnt");
+  constexpr int NP = NT / 2;                              // pairs of interleaved tiles
+  constexpr int NL = NQ - 2 * NP;                         // tiles in MFMA layout: chains 2 NP .. NQ - 1
+  constexpr int SPT = NP + NL, STORES = 4 * SPT;          // store instructions per result register / per block
+  static_assert(STORES < 60, "the counted wait must fit vmcnt");
   unsigned apk[NPK];  // offsets (doubles) of the A operands inside a block's records, two per register
 #pragma unroll
   for (int q = 0; q < NPK; ++q) {
@@ -159,15 +156,18 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
   const int nct_all = (c.len + 15) / 16;
   const int stride = (nct_all % 2 == 1) ? 16 * nct_all : 16 * nct_all + 16;
   auto aoff = [&](int s) { return (s & 1) ? (apk[s >> 1] >> 16) : (apk[s >> 1] & 0xffffu); };
-  // lane l <- column 16 ct0 + l of the group's rows; the tail tile keeps the MFMA layout (16 columns x 4 rows per register)
-  const int gcol = 16 * c.ct0 + lane, tcol = 16 * (c.ct0 + NT) + (lane & 15);
-  const unsigned gvoff = (lane < 16 * NT && gcol < c.len) ? (unsigned)gcol * 8u : kOutOfRange;
-
+  const int l15 = lane & 15;
+  const double *Wp = c.Wl + l15;  // pairs: lane c reads column 2c (+ 1) of the pair's 32
+  // entries of this lane inside a row: pair p -> 16 ct0 + 32 p + 2 l15 (+ 1), plain tile u -> 16 (ct0 + 2 NP + u) + l15; the
+  // limits below (wave-uniform) say which lanes have something to store
+  const int cbase = __builtin_amdgcn_readfirstlane(16 * c.ct0), rlen = __builtin_amdgcn_readfirstlane(c.len - 16 * c.ct0);
+  // the row ends inside the last pair on an odd entry: that lane's first value goes out alone
+  const bool straddle = NP > 0 && NL == 0 && (rlen & 1) && rlen > 32 * (NP - 1) && rlen < 32 * NP;
   // ---- loader state: records of block i + 1 in registers, block i + 2 in flight ----
   const int rec_doubles = c.estride * kBpRecDoubles;
   // (the build with DBG bit 32 -- blocks of at most 47 touched elements, e.g. the 4 x 2 x 2 chunks of a hex mesh -- carries
-  // six record registers instead of eight: the four VGPRs are what the mask-bit trim of the 7 x 4 + tail units needs)
-  constexpr int RL = (DBG & 32) ? 6 : kRecLoads;
+  // six record registers instead of eight)
+  constexpr int RL = !LOADER ? 1 : ((DBG & 32) ? 6 : kRecLoads);
   double Rc[RL];
   auto fetch = [&](int i, double (&dst)[RL]) {  // past the end: the last block again (in bounds, counted)
     const int boff = __builtin_amdgcn_readfirstlane((c.first + min(i, c.nblocks - 1)) * rec_doubles * 8);
@@ -181,7 +181,7 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
       if (k * 64 + lane < rec_doubles) buf[k * 64 + lane] = src[k];
     }
   };
-  if (loader) {
+  if constexpr (loader) {
     fetch(0, Rc);
     asm_wait_vmcnt<0>();
     deposit(Rc, c.recbuf);  // block 0: visible after the first barrier
@@ -189,72 +189,103 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
   }
 
   v4d accP[NQ];       // results of the previous block, stored during this one
-  int vrowP = -1;     // lane r < 16: CRS offset of its tile row r of the previous block, -1 = no store
+  int rowP[4];        // byte offset of tile row (lane >> 4) + 4 t of the previous block in the CRS values, < 0 = no store
 #pragma unroll
   for (int q = 0; q < NQ; ++q) accP[q] = v4d{0.0, 0.0, 0.0, 0.0};
-  // store j (0 .. STORES - 1) of the previous block: group stores first (register t = j / 4, row q = j % 4 + 4 t), then the tail's
-  unsigned tlo[4], thi[4];
-  auto store_prev = [&](int j) {
-    if (j < NGS) {
-      const int t = j >> 2, q = j & 3;
-      if (q == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          tlo[k] = k < NT ? (unsigned)__double2loint(accP[k < NT ? k : 0][t]) : 0u;
-          thi[k] = k < NT ? (unsigned)__double2hiint(accP[k < NT ? k : 0][t]) : 0u;
-        }
-        transpose_quarters(tlo);
-        transpose_quarters(thi);
-      }
-      const int rowoff = __builtin_amdgcn_readlane(vrowP, q + 4 * t);  // wave-uniform: the row this instruction writes
-      v2i bits;
-      bits[0] = (int)tlo[q];
-      bits[1] = (int)thi[q];
-      raw_buffer_store_b64(bits, c.out, (int)(rowoff >= 0 ? gvoff : kOutOfRange), rowoff * 8, 0);
+  for (int t = 0; t < 4; ++t) rowP[t] = -1;
+  // store j (0 .. STORES - 1) of the previous block: result register t = j / SPT, then the pairs, then the plain tiles
+  auto store_prev = [&](int j) {
+    const int t = j / SPT, u = j % SPT;
+    if (u < NP) {
+      v4i bits;
+      bits[0] = __double2loint(accP[2 * u][t]);
+      bits[1] = __double2hiint(accP[2 * u][t]);
+      bits[2] = __double2loint(accP[2 * u + 1][t]);
+      bits[3] = __double2hiint(accP[2 * u + 1][t]);
+      const bool on = rowP[t] >= 0 && 32 * u + 2 * l15 + 1 < rlen;
+      // soffset stays the CONSTANT 0: with a scalar register there hipcc's hazard recognizer assumes that a 16-byte store
+      // needs no wait state before a VALU write of its data registers (GCNHazardRecognizer::createsVALUHazard) and reuses
+      // the first data register for the next address at once -- on gfx950 lanes 12..15 of every row then stored that
+      // address in place of the low half of their first value (found as a 4e-7 relative error in 48 entries, first launch only)
+      raw_buffer_store_b128(bits, c.out, (int)(on ? (unsigned)rowP[t] + (unsigned)(l15 * 16) + (unsigned)((cbase + 32 * u) * 8) : kOutOfRange), 0, 0);
     } else {
-      const int t = j - NGS;  // result register t of this lane belongs to tile row (lane >> 4) + 4 t
-      const int rowoff = __builtin_amdgcn_ds_bpermute(((lane >> 4) + 4 * t) * 4, vrowP);
+      const int q = 2 * NP + (u - NP);
       v2i bits;
-      bits[0] = __double2loint(accP[NQ - 1][t]);
-      bits[1] = __double2hiint(accP[NQ - 1][t]);
-      raw_buffer_store_b64(bits, c.out, (int)((tcol < c.len && rowoff >= 0) ? (unsigned)(rowoff + tcol) * 8u : kOutOfRange), 0, 0);
+      bits[0] = __double2loint(accP[q][t]);
+      bits[1] = __double2hiint(accP[q][t]);
+      const bool on = rowP[t] >= 0 && 16 * q + l15 < rlen;
+      raw_buffer_store_b64(bits, c.out, (int)(on ? (unsigned)rowP[t] + (unsigned)(l15 * 8) : kOutOfRange), (cbase + 16 * q) * 8, 0);
     }
   };
 
   for (int i = 0; i <= c.nblocks; ++i) {  // iteration i: products of block i (discarded at i = nblocks), stores of block i - 1
     const int ic = min(i, c.nblocks - 1);
-    const int vrowC = (relrow >= 0 && i < c.nblocks && !(DBG & 2)) ? c.sbase[ic * c.nruns + (max(relrow, 0) >> 20)] + (relrow & 0xfffff) : -1;
+    const int vrowC = (relrow >= 0 && i < c.nblocks && !(DBG & 2)) ? (c.sbase[ic * c.nruns + (max(relrow, 0) >> 20)] + (relrow & 0xfffff)) * 8 : -1;
     lds_barrier();  // block i's records are in place; every wavefront has issued the stores of block i - 2
+    asm volatile("" ::: "memory");  // (the LDS has changed: without this a wavefront that does not write it hoists all its W reads out of the loop, 112 registers)
     const double *rec = c.recbuf + (i & 1) * c.recstride;
     v4d acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+    // TRIM 3 (units of two pairs): one pair of tiles sees only zero blocks of W during one half of the k-steps -- the
+    // columns of a row are sorted by global id and so are a block's elements: around a vertex dof of a hex mesh four of
+    // the eight elements reach only one end of the row.  The host classifies the unit (c.trim: 1..4 = which pair, which
+    // half; block_pattern.cpp), wave-uniform; the whole k-loop exists once per class, branch-free inside (a branch per
+    // product made hipcc copy the accumulators at every join: >1000 spilled registers).
+    // TRIM 4: any pattern by mask bit (bit s * 5 + q of c.mask): one branch per product, for shapes with registers to spare.
+    auto kloop = [&](auto cls_tag) {
+      constexpr int CLS = decltype(cls_tag)::value;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const double a = rec[aoff(s)];
-      if constexpr (!(DBG & 4)) {
+      for (int s = 0; s < KS; ++s) {
+        const double a = rec[aoff(s)];
+        if constexpr (!(DBG & 4)) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          // TRIM 3: the class is a run-time (wave-uniform) value: one instantiation serves the trimmed and the full units
-          const bool second = s >= KS / 2;
-          const int mbit = s * 5 + q;  // a constant after unrolling: the mask word stays in a scalar register
-          const unsigned mw = mbit < 32 ? c.mask[0] : (mbit < 64 ? c.mask[1] : c.mask[2]);
-          const bool zero_block = (TRIM == 3 && ((c.trim == 1 && q < NQ - 1 && second) || (c.trim == 2 && q >= 1 && !second) ||
-                                                 (c.trim == 3 && q < NQ - 1 && !second) || (c.trim == 4 && q >= 1 && second))) ||
-                                  (TRIM == 4 && !((mw >> (mbit & 31)) & 1u));  // TRIM 4: any pattern, one scalar bit test per product
-          if (!zero_block) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, c.Wl[(4 * s) * stride + 16 * q], acc[q], 0, 0, 0);
+          for (int q = 0; q < NQ; ++q) {
+            const bool second = s >= KS / 2;
+            if ((CLS == 1 && q < 2 && second) || (CLS == 2 && q >= 2 && !second) || (CLS == 3 && q < 2 && !second) ||
+                (CLS == 4 && q >= 2 && second))
+              continue;  // compile time
+            const int mbit = s * 5 + q;  // a constant after unrolling: the mask word stays in a scalar register
+            const unsigned mw = mbit < 32 ? c.mask[0] : (mbit < 64 ? c.mask[1] : c.mask[2]);
+            const bool zero_block = TRIM == 4 && !((mw >> (mbit & 31)) & 1u);
+            const double b = q < 2 * NP ? Wp[(4 * s) * stride + 32 * (q >> 1) + (q & 1)] : c.Wl[(4 * s) * stride + 16 * q];
+            if (!zero_block) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+          }
+        } else {
+          acc[0][0] += a;
         }
-      } else {
-        acc[0][0] += a;
-      }
 #pragma unroll
-      for (int j = (s * STORES) / KS; j < ((s + 1) * STORES) / KS; ++j) store_prev(j);
-      if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        for (int j = (s * STORES) / KS; j < ((s + 1) * STORES) / KS; ++j) store_prev(j);
+        if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if constexpr (TRIM == 3) {
+      switch (c.trim) {
+        case 1: kloop(std::integral_constant<int, 1>{}); break;
+        case 2: kloop(std::integral_constant<int, 2>{}); break;
+        case 3: kloop(std::integral_constant<int, 3>{}); break;
+        case 4: kloop(std::integral_constant<int, 4>{}); break;
+        default: kloop(std::integral_constant<int, 0>{}); break;
+      }
+    } else {
+      kloop(std::integral_constant<int, 0>{});
+    }
+    if (straddle) {  // wave-uniform
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v2i bits;
+        bits[0] = __double2loint(accP[2 * (NP > 0 ? NP - 1 : 0)][t]);
+        bits[1] = __double2hiint(accP[2 * (NP > 0 ? NP - 1 : 0)][t]);
+        const bool on = rowP[t] >= 0 && 32 * (NP - 1) + 2 * l15 == rlen - 1;
+        raw_buffer_store_b64(bits, c.out, (int)(on ? (unsigned)rowP[t] : kOutOfRange), (cbase + rlen - 1) * 8, 0);
+      }
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) accP[q] = acc[q];
-    vrowP = vrowC;
-    if (loader) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rowP[t] = __builtin_amdgcn_ds_bpermute(((lane >> 4) + 4 * t) * 4, vrowC);
+    if constexpr (loader) {
       // block i + 1's records (requested one iteration ago) into the other buffer -- last read during block i - 1, and
       // everybody has passed this iteration's barrier since; this iteration's stores stay in flight.  Then request
       // block i + 2's into the same registers.
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
       c.len = h[H_LEN];
       c.ct0 = __builtin_amdgcn_readfirstlane(h[H_CT0]);
 #pragma unroll
-      for (int wd = 0; wd < 3; ++wd) c.mask[wd] = (unsigned)__builtin_amdgcn_readfirstlane(h[H_MASK0 + wd]);
+      for (int wd = 0; wd < 3; ++wd) c.mask[wd] = (d.dbg & 16) ? 0xffffffffu : (unsigned)__builtin_amdgcn_readfirstlane(h[H_MASK0 + wd]);  // bit 16: no trim
       const int nct = h[H_NCT];
       const int stride = (nct % 2 == 1) ? 16 * nct : 16 * nct + 16;
       c.Wl = W + h[H_WOFF] + (lane >> 4) * stride + (lane & 15) + 16 * c.ct0;
@@ -418,35 +449,42 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
       int ks, ntile;
       bool fixed_class, tail;
       const int32_t *L = setup(p_begin, ks, ntile, fixed_class, tail);
+      c.trim = __builtin_amdgcn_readfirstlane((d.dbg & 16) ? 0 : ((d.part_hdr[(size_t)p_begin * kBpHdrInts + H_FLAGS] >> 2) & 7));  // host-computed trim class of the unit
       const int key = fixed_class ? -1 : (ks * 8 + ntile) * 2 + (tail ? 1 : 0);
       // zero-block pattern of the unit (bit s * 5 + q of c.mask set = the W block of k-step s, chain q is not zero)
       done = true;
+      // (shapes of four or five chains have no LOADER form)
+#define BP_UNIT(KS_, NT_, TAIL_, TRIM_)                                                       \
+  case (KS_ * 8 + NT_) * 2 + (TAIL_ ? 1 : 0):                                                 \
+    if constexpr (NT_ + (TAIL_ ? 1 : 0) <= 3) {                                               \
+      if (loader) run_unit<KS_, NT_, TAIL_, DBG, TRIM_, true>(c, L, lane);                    \
+      else run_unit<KS_, NT_, TAIL_, DBG, TRIM_, false>(c, L, lane);                          \
+    } else {                                                                                  \
+      if (loader) done = false;                                                               \
+      else run_unit<KS_, NT_, TAIL_, DBG, TRIM_, false>(c, L, lane);                          \
+    }                                                                                         \
+    break;
       switch (key) {
         // Q2 hexes: 8 / 4 / 2 / 1 elements around a vertex / edge / face / cell dof
-        case (14 * 8 + 4) * 2:
-          c.trim = __builtin_amdgcn_readfirstlane((d.dbg & 16) ? 0 : ((d.part_hdr[(size_t)p_begin * kBpHdrInts + H_FLAGS] >> 2) & 7));  // host-computed trim class of the unit
-          run_unit<14, 4, false, DBG, 3>(c, L, lane, loader);
-          break;
-        case (7 * 8 + 4) * 2 + 1:  // zero blocks (29 % on a hex mesh) skipped by mask bit where the register budget allows
-          if constexpr ((DBG & 32) != 0) run_unit<7, 4, true, DBG, 4>(c, L, lane, loader);
-          else run_unit<7, 4, true, DBG>(c, L, lane, loader);
-          break;
-        case (7 * 8 + 4) * 2: run_unit<7, 4, false, DBG>(c, L, lane, loader); break;
-        case (4 * 8 + 3) * 2: run_unit<4, 3, false, DBG>(c, L, lane, loader); break;
-        case (2 * 8 + 2) * 2: run_unit<2, 2, false, DBG>(c, L, lane, loader); break;
+        BP_UNIT(14, 4, false, 3)
+        BP_UNIT(7, 4, true, 0)
+        BP_UNIT(7, 4, false, 0)
+        BP_UNIT(4, 3, false, 0)
+        BP_UNIT(2, 2, false, 0)
         // Q1 hexes
-        case (14 * 8 + 2) * 2: run_unit<14, 2, false, DBG>(c, L, lane, loader); break;
-        case (7 * 8 + 2) * 2: run_unit<7, 2, false, DBG>(c, L, lane, loader); break;
-        case (4 * 8 + 0) * 2 + 1: run_unit<4, 0, true, DBG>(c, L, lane, loader); break;
-        case (2 * 8 + 0) * 2 + 1: run_unit<2, 0, true, DBG>(c, L, lane, loader); break;
+        BP_UNIT(14, 2, false, 0)
+        BP_UNIT(7, 2, false, 0)
+        BP_UNIT(4, 0, true, 0)
+        BP_UNIT(2, 0, true, 0)
         // quads (one k-step per element)
-        case (4 * 8 + 2) * 2: run_unit<4, 2, false, DBG>(c, L, lane, loader); break;
-        case (4 * 8 + 4) * 2: run_unit<4, 4, false, DBG>(c, L, lane, loader); break;
-        case (2 * 8 + 3) * 2: run_unit<2, 3, false, DBG>(c, L, lane, loader); break;
-        case (1 * 8 + 2) * 2: run_unit<1, 2, false, DBG>(c, L, lane, loader); break;
-        case (1 * 8 + 0) * 2 + 1: run_unit<1, 0, true, DBG>(c, L, lane, loader); break;
+        BP_UNIT(4, 2, false, 0)
+        BP_UNIT(4, 4, false, 0)
+        BP_UNIT(2, 3, false, 0)
+        BP_UNIT(1, 2, false, 0)
+        BP_UNIT(1, 0, true, 0)
         default: done = false; break;
       }
+#undef BP_UNIT
     }
     if (!done && !loader && out.overwrite && !(DBG & 1) && p_end > p_begin && p_end - p_begin <= kMaxFixedUnits) {
       bool all_fixed = true;
