@@ -459,6 +459,21 @@ def main():
     ap.add_argument("--cpu-sample-layers", type=int, default=0, help="z-layers of the CPU sample of config 2 (0 = all)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as given: start the N ranks as fresh children (one per GPU, torch.distributed.run on
+        # 127.0.0.1) BEFORE anything here touches the GPU, relay rank 0's JSON line and the children's exit code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("spawning %d ranks: %s" % (args.gpus, " ".join(cmd)))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
     import mrhyde_amd
@@ -466,7 +481,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus)
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the MI355X path has no CPU fallback"
     # MHA_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- lets the N>1 code path run on a
     # one-GPU box; the numbers of such a run mean nothing.

@@ -1603,8 +1603,8 @@ void AssemblyManager::prepareBlockPattern() {
                                                   std::getenv("MHA_BP_SEGBLOCKS") ? std::atoi(std::getenv("MHA_BP_SEGBLOCKS")) : 0);
   bp.why = h.why;
   if (std::getenv("MHA_VERBOSE"))
-    fprintf(stderr, "[mrhyde_amd] block patterns: usable %d (%s), %d patterns, %d roles, %d parts, %d workgroups, %lld MFMAs per assembly\n",
-            int(h.usable), h.why.c_str(), h.num_patterns, h.num_roles, h.num_parts, h.num_wgs, (long long)h.mfma_per_assembly);
+    fprintf(stderr, "[mrhyde_amd] block patterns: usable %d (%s), %d patterns, %d roles (%d with an LDS image), %d parts, %d workgroups, %lld MFMAs per assembly\n",
+            int(h.usable), h.why.c_str(), h.num_patterns, h.num_roles, h.num_image_roles, h.num_parts, h.num_wgs, (long long)h.mfma_per_assembly);
   if (std::getenv("MHA_VERBOSE") && h.usable) {  // shapes of the units: (k-steps, tiles, tail, trim class) -> count
     std::map<std::vector<int>, int> shapes;
     for (int p = 0; p < h.num_parts; ++p) {
@@ -1623,10 +1623,16 @@ void AssemblyManager::prepareBlockPattern() {
   bp.role.upload(h.role);
   bp.seg.upload(h.seg);
   bp.wg_seg_ptr.upload(h.wg_seg_ptr);
+  bp.wg_seg_ptr_img.upload(h.wg_seg_ptr_img);
   bp.part_ptr.upload(h.part_ptr);
   bp.part_hdr.upload(h.part_hdr);
   bp.part_lane.upload(h.part_lane);
   bp.rowbase.upload(h.rowbase);
+  {
+    std::vector<int32_t> ct = h.chunk_tab;
+    if (ct.empty()) ct.assign(kBpChunkInts, 0);
+    bp.chunk_tab.upload(ct);
+  }
   bp.erec_elem.upload(h.erec_elem);
   bp.w.upload(h.w);
   bp.erec2.resize(h.erec_elem.size() * kBpRecDoubles);
@@ -1644,9 +1650,13 @@ void AssemblyManager::prepareBlockPattern() {
   d.role = bp.role.data();
   d.seg = bp.seg.data();
   d.wg_seg_ptr = bp.wg_seg_ptr.data();
+  d.wg_seg_ptr_img = bp.wg_seg_ptr_img.data();
+  d.has_direct = h.wg_seg_ptr.back() > h.wg_seg_ptr.front();
+  d.has_image = h.wg_seg_ptr_img.back() > h.wg_seg_ptr_img.front();
   d.part_ptr = bp.part_ptr.data();
   d.part_hdr = bp.part_hdr.data();
   d.part_lane = bp.part_lane.data();
+  d.chunk_tab = bp.chunk_tab.data();
   d.nnz = h_rowptr_[nrows_];
   d.timing = bp.timing.empty() ? nullptr : bp.timing.data();
   MHA_HIP(hipStreamSynchronize(stream_));

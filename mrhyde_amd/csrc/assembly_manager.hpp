@@ -193,7 +193,7 @@ class AssemblyManager {
     int num_patterns = 0, num_roles = 0, num_blocks = 0;
     int64_t mfma_per_assembly = 0;
     BlockPatternDev dev;
-    DeviceBuffer<int32_t> role, seg, wg_seg_ptr, part_ptr, part_hdr, part_lane, rowbase, erec_elem;
+    DeviceBuffer<int32_t> role, seg, wg_seg_ptr, part_ptr, part_hdr, part_lane, rowbase, erec_elem, chunk_tab, wg_seg_ptr_img;
     DeviceBuffer<double> w, erec2;
     DeviceBuffer<long long> timing;
   } bpat_;

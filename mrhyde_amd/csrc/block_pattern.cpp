@@ -19,9 +19,12 @@ namespace {
 
 // role record (kBpRoleInts ints)
 enum { R_EREC_LO = 0, R_EREC_HI, R_ESTRIDE, R_ROWB_LO, R_ROWB_HI, R_NRUNS, R_NBLOCKS, R_COST, R_WOFF_LO, R_WOFF_HI,
-       R_WDOUBLES, R_PATTERN, R_NELEMS };
+       R_WDOUBLES, R_PATTERN, R_NELEMS,
+       R_IMG,        // image roles: doubles of a block's LDS image (0: rows are stored straight from the registers)
+       R_WLDS,       // doubles of the role's W image that live in LDS (the rest belongs to REGW units)
+       R_NCHUNK, R_CHUNK_LO, R_CHUNK_HI };
 // part header (kBpHdrInts ints)
-enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_CT0, H_NTILE, H_FLAGS, H_CLASS, H_MASK0, H_MASK1, H_MASK2 };  // flags: 1 rows of fixed dofs, 2 a plain tail tile follows the group, 4 / 8 trim class (see the mask loop)
+enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_CT0, H_NTILE, H_FLAGS, H_CLASS, H_MASK0, H_MASK1, H_MASK2 };  // flags: 1 rows of fixed dofs, 2 a plain tail tile follows the group, 4 / 8 / 16 trim class (see the mask loop), 32 W in registers (REGW)
 
 uint64_t fnv1a(const std::vector<uint8_t> &b) {
   uint64_t h = 1469598103934665603ull;
@@ -69,6 +72,7 @@ struct RowClass {
   std::vector<std::vector<int>> slots;   // per incidence k: slot of every column of that element
   int ks = 0, nct = 0, stride = 0, w_doubles = 0;
   int bin = 0, w_off = 0;                // role (LDS bin) and offset inside it
+  bool regw = false;                     // image roles: units of two tiles with W in registers
 };
 
 inline int stride_for(int nct) { return (nct % 2 == 1) ? 16 * nct : 16 * nct + 16; }
@@ -116,6 +120,8 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
   struct RoleBuild {
     int pattern, bin, R, T, nruns;
     int w_doubles = 0;
+    int img_doubles = 0, w_lds = 0, nchunk = 0;  // image roles (block_pattern.hpp)
+    int64_t chunk_off = 0;
     int64_t w_off = 0;             // start of the role's LDS image inside pl.w
     int64_t cost = 0;              // per block
     std::vector<std::vector<int32_t>> wave_parts;  // [kBpWaves] -> part indices (global)
@@ -196,20 +202,74 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
         for (const Inc &i : v) ts.push_back(i.t);
       classes[c].inst_t.push_back(std::move(ts));
     }
-    // LDS bins: first fit, largest W first
+    // ---- image form?  (block_pattern.hpp)  The block's runs, each in a slot of whole 16-entry lines with room for its
+    // global offset mod 16; all W that stays in LDS in ONE bin beside the image; at most kBpStreamWaves units, one per
+    // wavefront; no rows of fixed dofs (their zeros would need a unit kind of their own) ----
+    std::vector<int> run_len(nruns, 0), run_slot(nruns + 1, 0);
+    for (int o = 0; o < R; ++o) run_len[run_of[o]] += rowptr[rb.rows[r0 + o] + 1] - rowptr[rb.rows[r0 + o]];
+    for (int r = 0; r < nruns; ++r) run_slot[r + 1] = run_slot[r] + (run_len[r] + 15 + 15) / 16 * 16;
+    const int img_doubles = run_slot[nruns];
+    // (opt-in, MHA_BP_IMAGE=1: at the end of round 3 the image kernel is correct but slower than the direct stores --
+    // 253 us for the interior blocks of config 2 against ~235 -- see DESIGN.md)
+    bool image = std::getenv("MHA_BP_IMAGE") && std::string(std::getenv("MHA_BP_IMAGE")) == "1" && !classes.empty();
+    {
+      int w_lds = 0, units = 0, nchunk = 0;
+      for (const RowClass &rc : classes) { w_lds += rc.w_doubles; image = image && !rc.fixed; }
+      image = image && w_lds <= budget_doubles;  // (in accumulate mode the role runs the plain form with all of W in LDS)
+      for (int r = 0; r < nruns; ++r) nchunk += (run_len[r] + 15 + 127) / 128;
+      image = image && nchunk <= 64 * kBpStreamWaves && img_doubles < (1 << 16) && nruns < 256;
+      while (image && w_lds + img_doubles + 64 > budget_doubles) {  // largest W first into registers
+        int best = -1;
+        for (size_t c = 0; c < classes.size(); ++c)
+          if (!classes[c].regw && classes[c].nct % 2 == 0 && classes[c].ks * 2 <= 28 && (best < 0 || classes[c].w_doubles > classes[best].w_doubles))
+            best = static_cast<int>(c);
+        if (best < 0) { image = false; break; }
+        classes[best].regw = true;
+        w_lds -= classes[best].w_doubles;
+      }
+      for (const RowClass &rc : classes) {
+        const int ntile = (static_cast<int>(rc.inst_row.size()) + 15) / 16;
+        const int ng = rc.nct / 4, rem = rc.nct % 4;
+        units += ntile * (rc.regw ? rc.nct / 2 : ng + ((rem >= 2 || (ng == 0 && rem == 1)) ? 1 : 0));
+      }
+      if (std::getenv("MHA_BP_STATS")) {
+        int nfixed_rows = 0, nfixed_cls = 0, prod_units = 0;
+        for (const RowClass &rc : classes) {
+          const int ntile = (static_cast<int>(rc.inst_row.size()) + 15) / 16;
+          const int ng = rc.nct / 4, rem = rc.nct % 4;
+          if (rc.fixed) { nfixed_rows += static_cast<int>(rc.inst_row.size()); ++nfixed_cls; }
+          else prod_units += ntile * (rc.regw ? rc.nct / 2 : ng + ((rem >= 2 || (ng == 0 && rem == 1)) ? 1 : 0));
+        }
+        fprintf(stderr, "pattern %d: %zu blocks, R %d T %d runs %d image %d doubles, W %d doubles, classes %zu (fixed %d, %d rows), product units %d, image %d\n",
+                pat, members[pat].size(), R, T, nruns, img_doubles, w_lds, classes.size(), nfixed_cls, nfixed_rows, prod_units, int(image));
+      }
+      image = image && units <= kBpStreamWaves;
+      if (!image)
+        for (RowClass &rc : classes) rc.regw = false;
+    }
+    // LDS bins: first fit, largest W first (an image role: one bin, the REGW classes behind the part that is copied to LDS)
     std::vector<int> order(classes.size());
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return classes[a].w_doubles > classes[c].w_doubles; });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+      if (classes[a].regw != classes[c].regw) return !classes[a].regw;
+      return classes[a].w_doubles > classes[c].w_doubles;
+    });
     std::vector<int> bin_fill;
+    int w_lds_image = 0;
     for (int c : order) {
       RowClass &rc = classes[c];
       int bin = -1;
-      for (size_t k = 0; k < bin_fill.size(); ++k)
-        if (bin_fill[k] + rc.w_doubles <= budget_doubles) { bin = static_cast<int>(k); break; }
+      if (image) {
+        if (bin_fill.empty()) bin_fill.push_back(0);
+        bin = 0;
+      }
+      for (size_t k = 0; k < bin_fill.size() && bin < 0; ++k)
+        if (bin_fill[k] + rc.w_doubles <= budget_doubles) bin = static_cast<int>(k);
       if (bin < 0) { bin = static_cast<int>(bin_fill.size()); bin_fill.push_back(0); }
       rc.bin = bin;
       rc.w_off = bin_fill[bin];
       bin_fill[bin] += rc.w_doubles;
+      if (image && !rc.regw) w_lds_image = bin_fill[bin];
     }
     if (bin_fill.empty()) bin_fill.push_back(0);
     const int first_role = static_cast<int>(roles.size());
@@ -217,8 +277,20 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
     for (size_t k = 0; k < bin_fill.size(); ++k) {
       role_woff[k] = pl.w.size();
       pl.w.resize(pl.w.size() + 2 * static_cast<size_t>(bin_fill[k]), 0.0);  // stiffness rows | mass rows
-      pl.max_w_doubles = std::max(pl.max_w_doubles, bin_fill[k]);
+      pl.max_w_doubles = std::max(pl.max_w_doubles, image ? w_lds_image + img_doubles + 64 : bin_fill[k]);  // (+ 64: the trash slot behind the image)
       RoleBuild rbld;
+      if (image) {
+        rbld.img_doubles = img_doubles;
+        rbld.w_lds = w_lds_image;
+        rbld.chunk_off = static_cast<int64_t>(pl.chunk_tab.size() / kBpChunkInts);
+        for (int r = 0; r < nruns; ++r)
+          for (int kk = 0; kk < (run_len[r] + 15 + 127) / 128; ++kk) {
+            const int32_t ch[kBpChunkInts] = {r, run_slot[r] + 128 * kk, 128 * kk, run_len[r]};
+            pl.chunk_tab.insert(pl.chunk_tab.end(), ch, ch + kBpChunkInts);
+            ++rbld.nchunk;
+          }
+        ++pl.num_image_roles;
+      }
       rbld.pattern = pat;
       rbld.bin = static_cast<int>(k);
       rbld.R = R;
@@ -263,6 +335,10 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
       std::vector<PartBuild> parts;
       for (const Tile &t : tiles[k]) {
         const RowClass &rc = classes[t.cls];
+        if (rc.regw) {  // units of one tile pair, W in registers
+          for (int g = 0; g < rc.nct / 2; ++g) parts.push_back({t.cls, t.tile, 2 * g, 2, 0, static_cast<double>(2 * (rc.ks + 1))});
+          continue;
+        }
         const int ng = rc.nct / 4, rem = rc.nct % 4;
         for (int g = 0; g < ng; ++g) {
           const int tail = (g == ng - 1 && rem == 1) ? 1 : 0;
@@ -304,9 +380,10 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
         if (wv < 0) {
           // a product unit: a wavefront of its own while there are free ones, on the SIMD (wavefront id mod 4: the four
           // SIMDs of a CU take a workgroup's wavefronts round robin) whose matrix pipe has the least work so far
-          for (int w = 0; w < kBpWaves; ++w)
+          const int w0 = role.img_doubles > 0 ? 1 : 0;  // image roles: wave 0 is the record loader
+          for (int w = w0; w < kBpWaves; ++w)
             if (load[w] == 0.0 && (wv < 0 || simd_load[w % 4] < simd_load[wv % 4])) wv = w;
-          if (wv < 0) wv = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+          if (wv < 0) wv = static_cast<int>(std::min_element(load.begin() + w0, load.end()) - load.begin());
           simd_load[wv % 4] += pb.cost;
         }
         load[wv] += pb.cost;
@@ -321,7 +398,7 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
         hdr[H_LEN] = rc.len;
         hdr[H_CT0] = pb.ct0;
         hdr[H_NTILE] = pb.ntile;
-        hdr[H_FLAGS] = (rc.fixed ? 1 : 0) | (pb.tail ? 2 : 0);
+        hdr[H_FLAGS] = (rc.fixed ? 1 : 0) | (pb.tail ? 2 : 0) | (rc.regw ? 32 : 0);
         hdr[H_CLASS] = pl.num_classes + pb.cls;
         if (!rc.fixed) {  // which 4 x 16 blocks of the unit's part of W hold anything: the kernel skips the products of the others
           const double *Wk = pl.w.data() + role_woff[rc.bin] + rc.w_off, *Wm = Wk + bin_fill[rc.bin];
@@ -341,7 +418,8 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
           const int nq = pb.ntile + pb.tail;
           if (nq >= 2 && rc.ks >= 2) {
             bool t[5] = {false, true, true, true, true};
-            if (pb.ntile != 4 || pb.tail) t[1] = t[2] = t[3] = t[4] = false;
+            if (pb.ntile == 2 && rc.regw) t[2] = t[4] = false;  // one pair: classes 1 (second half zero) and 3 (first half zero)
+            else if (pb.ntile != 4 || pb.tail) t[1] = t[2] = t[3] = t[4] = false;
             for (int sidx = 0; sidx < rc.ks; ++sidx)
               for (int q = 0; q < nq; ++q) {
                 const int bit = sidx * 5 + q;
@@ -406,6 +484,7 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
               packed = (run_of[o] << 20) | (rowptr[rb.rows[r0 + o]] - rowptr[rb.rows[r0 + run_first[run_of[o]]]]);
             }
             L[20 * 64 + lane] = packed;
+            L[21 * 64 + lane] = packed < 0 ? -1 : run_slot[packed >> 20] + (packed & 0xfffff);
           }
         }
       }
@@ -419,6 +498,17 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
         const int32_t *h = &pl.part_hdr[static_cast<size_t>(role.wave_parts[wv][0]) * kBpHdrInts];
         return (h[H_FLAGS] & 1) ? 0 : h[H_NTILE] + ((h[H_FLAGS] & 2) ? 1 : 0);
       };
+      // ... or better none at all: a loader that stores nothing never waits for write acknowledgements (kernel:
+      // run_loader_only), so an idle wavefront changes places with wave 0
+      if (!role.wave_parts[0].empty()) {
+        int idle = -1;
+        for (int wv = kBpWaves - 1; wv >= 1 && idle < 0; --wv)
+          if (role.wave_parts[wv].empty()) idle = wv;
+        if (idle > 0 && (role.img_doubles > 0 || std::getenv("MHA_BP_LOADER_IDLE"))) { std::swap(role.wave_parts[0], role.wave_parts[idle]); continue; }
+        if (role.img_doubles > 0) return fail("an image role has no free wavefront for the record loader");
+      } else {
+        continue;
+      }
       if (chains(0) <= 3) continue;
       int best = -1;
       for (int wv = 1; wv < kBpWaves; ++wv) {
@@ -462,51 +552,62 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
   //         pieces of equal cost; a piece that crosses a role boundary becomes several SEGMENTS (the workgroup reloads
   //         the LDS image between them), so small roles cost no extra workgroup and nobody waits for a free CU.
   //         Starting a role costs about three blocks (image load, pipeline fill), continuing it in a new segment one ----
+  //         Roles with an LDS image run in a kernel of their own (the two families of unit code do not fit one register
+  //         budget): two cuts, one segment array ----
   {
     const int nwg = std::max(1, num_cus);
     auto block_cost = [&](int k) { return static_cast<double>(std::max<int64_t>(1, roles[k].cost)); };
-    double total_cost = 0.0;
-    for (int k = 0; k < pl.num_roles; ++k) total_cost += (static_cast<double>(members[roles[k].pattern].size()) + 3.0) * block_cost(k);
-    for (double target = total_cost / nwg;; target *= 1.02) {
-      pl.seg.clear();
-      pl.wg_seg_ptr.assign(1, 0);
-      int wg = 0;
-      double load = 0.0;  // of the current workgroup
-      int last_role = -1;
-      bool fits = true;
-      for (int k = 0; k < pl.num_roles && fits; ++k) {
-        const double c = block_cost(k);
-        const int nb = static_cast<int>(members[roles[k].pattern].size());
-        int seg_cap = std::max(1, kBpSegInts / roles[k].nruns);
-        if (seg_blocks > 0) seg_cap = std::min(seg_cap, seg_blocks);
-        int first = 0;
-        while (first < nb) {
-          const double start = (last_role == k ? 1.0 : 3.0) * c;
-          int take = static_cast<int>(std::floor((target - load - start) / c + 0.5));
-          if (take < 1 && load > 0.0) {  // no room for another segment: next workgroup
-            if (wg == nwg - 1) { fits = false; break; }
-            pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
-            ++wg;
-            load = 0.0;
-            last_role = -1;
-            continue;
+    pl.seg.clear();
+    auto cut = [&](bool img, std::vector<int32_t> &wg_seg_ptr) {
+      const size_t seg0 = pl.seg.size();
+      double total_cost = 0.0;
+      for (int k = 0; k < pl.num_roles; ++k)
+        if ((roles[k].img_doubles > 0) == img) total_cost += (static_cast<double>(members[roles[k].pattern].size()) + 3.0) * block_cost(k);
+      if (total_cost == 0.0) { wg_seg_ptr.assign(static_cast<size_t>(nwg) + 1, static_cast<int32_t>(seg0 / 4)); return; }
+      for (double target = total_cost / nwg;; target *= 1.02) {
+        pl.seg.resize(seg0);
+        wg_seg_ptr.assign(1, static_cast<int32_t>(seg0 / 4));
+        int wg = 0;
+        double load = 0.0;  // of the current workgroup
+        int last_role = -1;
+        bool fits = true;
+        for (int k = 0; k < pl.num_roles && fits; ++k) {
+          if ((roles[k].img_doubles > 0) != img) continue;
+          const double c = block_cost(k);
+          const int nb = static_cast<int>(members[roles[k].pattern].size());
+          int seg_cap = std::max(1, kBpSegInts / roles[k].nruns);
+          if (seg_blocks > 0) seg_cap = std::min(seg_cap, seg_blocks);
+          int first = 0;
+          while (first < nb) {
+            const double start = (last_role == k ? 1.0 : 3.0) * c;
+            int take = static_cast<int>(std::floor((target - load - start) / c + 0.5));
+            if (take < 1 && load > 0.0) {  // no room for another segment: next workgroup
+              if (wg == nwg - 1) { fits = false; break; }
+              wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
+              ++wg;
+              load = 0.0;
+              last_role = -1;
+              continue;
+            }
+            take = std::max(1, std::min(std::min(take, nb - first), seg_cap));
+            pl.seg.push_back(k);
+            pl.seg.push_back(first);
+            pl.seg.push_back(take);
+            pl.seg.push_back(0);
+            first += take;
+            load += start + take * c;
+            last_role = k;
           }
-          take = std::max(1, std::min(std::min(take, nb - first), seg_cap));
-          pl.seg.push_back(k);
-          pl.seg.push_back(first);
-          pl.seg.push_back(take);
-          pl.seg.push_back(0);
-          first += take;
-          load += start + take * c;
-          last_role = k;
+        }
+        if (fits) {
+          while (static_cast<int>(wg_seg_ptr.size()) < nwg + 1) wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
+          wg_seg_ptr.back() = static_cast<int32_t>(pl.seg.size() / 4);
+          break;
         }
       }
-      if (fits) {
-        while (static_cast<int>(pl.wg_seg_ptr.size()) < nwg + 1) pl.wg_seg_ptr.push_back(static_cast<int32_t>(pl.seg.size() / 4));
-        pl.wg_seg_ptr.back() = static_cast<int32_t>(pl.seg.size() / 4);
-        break;
-      }
-    }
+    };
+    cut(false, pl.wg_seg_ptr);
+    cut(true, pl.wg_seg_ptr_img);
     pl.num_wgs = nwg;
   }
   // ---- 5b. order of a role's blocks inside its block-major tables.  A workgroup walks a contiguous range of them
@@ -557,6 +658,11 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
     ro[R_WDOUBLES] = r.w_doubles;
     ro[R_PATTERN] = r.pattern;
     ro[R_NELEMS] = r.T;
+    ro[R_IMG] = r.img_doubles;
+    ro[R_WLDS] = r.img_doubles > 0 ? r.w_lds : r.w_doubles;
+    ro[R_NCHUNK] = r.nchunk;
+    ro[R_CHUNK_LO] = static_cast<int32_t>(r.chunk_off & 0xffffffffll);
+    ro[R_CHUNK_HI] = static_cast<int32_t>(r.chunk_off >> 32);
     for (int32_t b : blocks) {
       for (int t = rb.elem_ptr[b]; t < rb.elem_ptr[b + 1]; ++t) pl.erec_elem.push_back(rb.elems[t]);
       pl.erec_elem.push_back(-1);
@@ -582,8 +688,9 @@ void block_patterns_host_apply(const BlockPatternPlan &pl, const double *factors
   MHA_REQUIRE(pl.usable, MHA_ERR_STATE, "block patterns not usable: " << pl.why);
   const int ke = pl.ke;
   std::vector<double> rec;
+  for (int family = 0; family < 2; ++family)
   for (int wg = 0; wg < pl.num_wgs; ++wg)
-  for (int sg = pl.wg_seg_ptr[wg]; sg < pl.wg_seg_ptr[wg + 1]; ++sg) {
+  for (int sg = (family ? pl.wg_seg_ptr_img : pl.wg_seg_ptr)[wg]; sg < (family ? pl.wg_seg_ptr_img : pl.wg_seg_ptr)[wg + 1]; ++sg) {
     const int role = pl.seg[4 * sg], first = pl.seg[4 * sg + 1], nseg = pl.seg[4 * sg + 2];
     const int32_t *ro = &pl.role[static_cast<size_t>(role) * kBpRoleInts];
     const int64_t erec_base = (static_cast<int64_t>(ro[R_EREC_HI]) << 32) | static_cast<uint32_t>(ro[R_EREC_LO]);
@@ -623,7 +730,7 @@ void block_patterns_host_apply(const BlockPatternPlan &pl, const double *factors
                 for (int lc = 0; lc < 16; ++lc)
                   if (bp_unit_col(h[H_CT0], h[H_NTILE], q, lc) == c) { qc = q; break; }
               MHA_REQUIRE(qc >= 0, MHA_ERR_STATE, "a column of a unit belongs to none of its chains");
-              const int trim = (h[H_NTILE] == 4 && !(h[H_FLAGS] & 2)) ? (h[H_FLAGS] >> 2) & 7 : 0;
+              const int trim = ((h[H_NTILE] == 4 && !(h[H_FLAGS] & 2)) || (h[H_NTILE] == 2 && (h[H_FLAGS] & 32))) ? (h[H_FLAGS] >> 2) & 7 : 0;
               for (int s = 0; s < ks; ++s) {
                 const bool second = s >= ks / 2;
                 if ((trim == 1 && qc < 2 && second) || (trim == 2 && qc >= 2 && !second) || (trim == 3 && qc < 2 && !second) ||

@@ -22,6 +22,15 @@
 // All per-block data the kernel reads are block-major with a stride fixed per role (element records, CRS offsets of
 // the rows): every address is computed from the block's ordinal, there are no dependent loads.
 //
+// IMAGE ROLES (round 3).  The CRS rows of a block are odd-length neighbours in memory, so row pieces stored straight
+// from the MFMA registers share their first and last cache line with another wavefront's piece: measured at 3.4 TB/s
+// against 5.3-6.2 TB/s for whole aligned lines (profiles/micro/write_shape.hip).  Where the LDS has room, a role
+// therefore assembles every block as an IMAGE -- the block's runs of consecutive rows, each at its global offset mod
+// 16 entries inside a slot of its own -- and streams it out in aligned 1 KB chunks (one 16-byte store instruction each);
+// only the first and last line of a run are partial.  The LDS for the image comes from keeping the largest W (the
+// rows around a vertex dof) in REGISTERS: its class is cut into units of two column tiles whose 4 x 16 blocks of W sit in
+// at most 56 registers for the life of the segment (REGW units).  Wave 0 of such a role only loads element records.
+//
 // Nothing here assumes a structured mesh: patterns are found by hashing.  A mesh whose blocks share too few patterns
 // reports !usable and the caller keeps the LDS-accumulator row-block kernel.
 #pragma once
@@ -35,9 +44,11 @@ namespace mha {
 
 constexpr int kBpWaves = 12;       // wavefronts of a persistent workgroup (768 threads, 168 registers each: one workgroup per CU)
 constexpr int kBpMaxKSteps = 16;   // GEMM depth held in registers: 64 = 9 hexes x 7 or 16 quads x 4
-constexpr int kBpLaneRows = 24;    // per part and lane: [0..15] A offsets (doubles), [16..19] result rows of the lane's registers, [20] tile row lane & 15: run << 20 | CRS offset inside the run
+constexpr int kBpLaneRows = 24;    // per part and lane: [0..15] A offsets (doubles), [16..19] result rows of the lane's registers, [20] tile row lane & 15: run << 20 | CRS offset inside the run, [21] the same row's entry offset inside the block's LDS image (image roles)
+constexpr int kBpStreamWaves = kBpWaves - 1;  // image roles: wave 0 loads the element records, the others stream the image out
+constexpr int kBpChunkInts = 4;    // per 128-entry chunk of an image: run, LDS entry of lane 0, entry of lane 0 relative to the run's aligned start, entries of the run
 constexpr int kBpHdrInts = 12;     // per unit: LDS offset of W, k-steps, column tiles, row length, first tile, tiles, flags, class, 3 words: bit s * 5 + q set = W block (k-step s, tile q) is not zero
-constexpr int kBpRoleInts = 16;    // see block_pattern.cpp
+constexpr int kBpRoleInts = 24;    // see block_pattern.cpp
 constexpr int kBpSegInts = 2048;    // (blocks of one segment) x (runs of consecutive rows per block): their CRS offsets sit in LDS
 constexpr int kBpRecDoubles = 8;   // element record: g_0..g_{nsym-1}, detJ, zero padding
 
@@ -62,13 +73,16 @@ struct BlockPatternPlan {
   int max_rec_doubles = 0;             // doubles of the largest block's element records
   std::vector<int32_t> role;           // [num_roles][kBpRoleInts]
   std::vector<int32_t> seg;            // [num_segs][4]: role, first block (inside the role), blocks, 0
-  std::vector<int32_t> wg_seg_ptr;     // [num_wgs + 1] -> segments of a workgroup
+  std::vector<int32_t> wg_seg_ptr;     // [num_wgs + 1] -> segments of a workgroup (roles that store from the registers)
+  std::vector<int32_t> wg_seg_ptr_img; // the same for the image roles (a kernel of their own)
   std::vector<int32_t> part_ptr;       // [num_roles][kBpWaves + 1] -> parts of (role, wave)
   std::vector<int32_t> part_hdr;       // [num_parts][kBpHdrInts]
   std::vector<int32_t> part_lane;      // [num_parts][kBpLaneRows][64]
   std::vector<double> w;               // LDS images of the roles: per role [stiffness rows | mass rows], each w_doubles long
   std::vector<int32_t> erec_elem;      // role-major, block-major [T + 1] element ids; -1 = the block's zero record
   std::vector<int32_t> rowbase;        // role-major, block-major [runs]: CRS offset of the first row of every run of consecutive owned rows
+  std::vector<int32_t> chunk_tab;      // image roles: [chunks][kBpChunkInts], role-major
+  int num_image_roles = 0;
   int64_t mfma_per_assembly = 0;       // diagnostics
 };
 

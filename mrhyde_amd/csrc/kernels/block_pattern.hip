@@ -41,7 +41,7 @@ namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 enum { R_EREC_LO = 0, R_EREC_HI, R_ESTRIDE, R_ROWB_LO, R_ROWB_HI, R_NRUNS, R_NBLOCKS, R_COST, R_WOFF_LO, R_WOFF_HI,
-       R_WDOUBLES, R_PATTERN, R_NELEMS };
+       R_WDOUBLES, R_PATTERN, R_NELEMS, R_IMG, R_WLDS, R_NCHUNK, R_CHUNK_LO, R_CHUNK_HI };
 enum { H_WOFF = 0, H_KS, H_NCT, H_LEN, H_CT0, H_NTILE, H_FLAGS, H_CLASS, H_MASK0, H_MASK1, H_MASK2 };
 
 __global__ __launch_bounds__(256) void build_erec2_kernel(int64_t total, int nsym, const int32_t *__restrict__ erec_elem,
@@ -73,6 +73,9 @@ __device__ __forceinline__ v4i make_rsrc(const void *p, unsigned bytes) {
   return r;
 }
 constexpr unsigned kOutOfRange = 0x80000000u;  // offset of a lane that must not store
+#ifndef MHA_BP_STORE_AUX
+#define MHA_BP_STORE_AUX 0  // cache policy bits of the row stores (experiments: 1 sc0, 2 nt, 16 sc1)
+#endif
 // the raw buffer store intrinsic with the descriptor as four ints (a store hipcc tracks like any other: it never waits for it)
 __device__ void raw_buffer_store_b64(v2i data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
 __device__ void raw_buffer_store_b128(v4i data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4i32");
@@ -109,6 +112,13 @@ struct UnitCtx {
   double *recbuf;          // LDS: two images of a block's element records, recstride doubles apart
   int recstride;
   long long *tlog;         // profiling (DBG & 8): 8 wall-clock stamps of this wavefront
+  // image roles (block_pattern.hpp)
+  double *img;             // LDS: the block's image
+  int trash;               // entry offset (from img) of 64 doubles nobody reads
+  const int32_t *chunks;   // the role's chunk table [nchunk][kBpChunkInts]
+  int nchunk, sidx;        // chunks of a block; this wavefront's index among the streaming ones (wave - 1)
+  const double *wk, *wm;   // the unit's class in the role's global W image: stiffness rows, mass rows (REGW units)
+  double su, st;
 };
 
 // Element records of a block: (T + 1) x 8 doubles, contiguous in memory.  One wavefront (the loader: wave 0) fetches
@@ -208,14 +218,14 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
       // needs no wait state before a VALU write of its data registers (GCNHazardRecognizer::createsVALUHazard) and reuses
       // the first data register for the next address at once -- on gfx950 lanes 12..15 of every row then stored that
       // address in place of the low half of their first value (found as a 4e-7 relative error in 48 entries, first launch only)
-      raw_buffer_store_b128(bits, c.out, (int)(on ? (unsigned)rowP[t] + (unsigned)(l15 * 16) + (unsigned)((cbase + 32 * u) * 8) : kOutOfRange), 0, 0);
+      raw_buffer_store_b128(bits, c.out, (int)(on ? (unsigned)rowP[t] + (unsigned)(l15 * 16) + (unsigned)((cbase + 32 * u) * 8) : kOutOfRange), 0, MHA_BP_STORE_AUX);
     } else {
       const int q = 2 * NP + (u - NP);
       v2i bits;
       bits[0] = __double2loint(accP[q][t]);
       bits[1] = __double2hiint(accP[q][t]);
       const bool on = rowP[t] >= 0 && 16 * q + l15 < rlen;
-      raw_buffer_store_b64(bits, c.out, (int)(on ? (unsigned)rowP[t] + (unsigned)(l15 * 8) : kOutOfRange), (cbase + 16 * q) * 8, 0);
+      raw_buffer_store_b64(bits, c.out, (int)(on ? (unsigned)rowP[t] + (unsigned)(l15 * 8) : kOutOfRange), (cbase + 16 * q) * 8, MHA_BP_STORE_AUX);
     }
   };
 
@@ -296,6 +306,281 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
   }
 }
 
+// The record loader as a wavefront of its own (wave 0 without a unit: what the planner arranges whenever a pattern has
+// fewer units than wavefronts).  It issues no stores, so its loads never queue behind any in the in-order vmcnt: a
+// loader that also stores waits for the write acknowledgements of its previous block before its records count as
+// landed, and with it the whole workgroup at the next barrier -- the stores of consecutive blocks did not overlap
+// (stores alone 314 us for 1.08 GB against 170-200 us for the same volume from a plain persistent store loop,
+// profiles/micro/write_bw.hip).  Two register sets: the records of blocks i + 1 and i + 2 are in flight during block i.
+template <int DBG>
+__device__ __forceinline__ void run_loader_only(const UnitCtx &c, int lane) {
+  const int rec_doubles = c.estride * kBpRecDoubles;
+  constexpr int RL = kRecLoads;
+  double Ra[RL], Rb[RL];
+  auto fetch = [&](int i, double (&dst)[RL]) {  // past the end: the last block again (in bounds)
+    const int boff = __builtin_amdgcn_readfirstlane((c.first + min(i, c.nblocks - 1)) * rec_doubles * 8);
+#pragma unroll
+    for (int k = 0; k < RL; ++k) dst[k] = asm_load_f64(c.erec, (unsigned)min(k * 64 + lane, rec_doubles - 1) * 8u, boff);
+  };
+  auto deposit = [&](double (&src)[RL], double *buf) {
+#pragma unroll
+    for (int k = 0; k < RL; ++k) {
+      asm volatile("" : "+v"(src[k]));
+      if (k * 64 + lane < rec_doubles) buf[k * 64 + lane] = src[k];
+    }
+  };
+  fetch(0, Ra);
+  asm_wait_vmcnt<0>();
+  deposit(Ra, c.recbuf);  // block 0: visible after the first barrier
+  fetch(1, Ra);
+  fetch(2, Rb);
+  for (int i = 0; i <= c.nblocks; i += 2) {
+    lds_barrier();  // iteration i: the units read buffer i & 1
+    asm_wait_vmcnt<RL>();  // block i + 1 has landed (i + 2 may still be in flight)
+    deposit(Ra, c.recbuf + ((i + 1) & 1) * c.recstride);  // last read during block i - 1
+    fetch(i + 3, Ra);
+    if (i + 1 > c.nblocks) break;
+    lds_barrier();  // iteration i + 1
+    asm_wait_vmcnt<RL>();
+    deposit(Rb, c.recbuf + (i & 1) * c.recstride);
+    fetch(i + 4, Rb);
+  }
+  asm_wait_vmcnt<0>();  // nothing of this wavefront's may land after it has moved on
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// IMAGE ROLES (block_pattern.hpp): results go to an LDS image of the block's rows and leave in aligned 512-byte chunks.
+// Per block two barriers: [products of block i  ||  stream-out of block i - 1] B1 [results of block i -> image] B2.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// This wavefront's chunks m = 0 .. ncw - 1 (chunk sidx + kBpStreamWaves m of the block), descriptors one per lane.
+// A chunk = 128 entries (1 KB) of a run, starting on a multiple of 128 entries from the run's ALIGNED start (its global
+// offset rounded down to 16 entries): lane l moves entries 2l and 2l + 1 with one 16-byte store, whole 128-byte lines
+// except where the run begins or ends; a lane that holds only one entry of the run (odd begin or end) stores it with
+// an 8-byte instruction of its own, issued for those chunks only.  (A CU's store path takes about 40 cycles per
+// instruction, masked lanes or not: 8-byte chunks alone kept the kernel at 109 us without any products or data.)
+struct StreamCtx {
+  int pk, lds0;    // lane m: chunk m -- run | chunk index inside the run << 8 | entries of the run << 16; LDS entry of its lane 0
+  int vb, lo, hi;  // lane m, per block: byte offset of the chunk's first entry in the CRS values; entries lo <= e < hi of the chunk belong to the run
+  int ncw;
+};
+__device__ __forceinline__ StreamCtx make_stream(const UnitCtx &c, int lane) {
+  StreamCtx s;
+  s.ncw = c.sidx < c.nchunk ? (c.nchunk - c.sidx + kBpStreamWaves - 1) / kBpStreamWaves : 0;
+  const int j = min(c.sidx + kBpStreamWaves * lane, c.nchunk - 1);
+  const int32_t *t = c.chunks + (size_t)j * kBpChunkInts;
+  s.pk = t[0] | ((t[2] >> 7) << 8) | (t[3] << 16);  // (the host checks: < 256 runs, < 256 chunks per run, < 65536 entries)
+  s.lds0 = t[1];
+  s.vb = s.lo = s.hi = 0;
+  return s;
+}
+// block ip is about to be streamed: where its runs lie in the CRS values (c.sbase), for all of this wavefront's chunks at once
+__device__ __forceinline__ void stream_block(const UnitCtx &c, StreamCtx &s, int ip) {
+  const unsigned pk = (unsigned)s.pk;
+  const int run = pk & 0xff, e0 = ((pk >> 8) & 0xff) << 7, len = pk >> 16;
+  const int goff = c.sbase[max(ip, 0) * c.nruns + run];
+  const int a = goff & 15;
+  s.vb = (goff - a + e0) * 8;
+  s.lo = ip >= 0 ? a - e0 : 128;  // (no block: no entry)
+  s.hi = a + len - e0;
+}
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2d stream_read(const UnitCtx &c, const StreamCtx &s, int m, int lane) {
+  return *reinterpret_cast<const v2d *>(c.img + __builtin_amdgcn_readlane(s.lds0, m) + 2 * lane);
+}
+// chunk m of the block: 128 entries from the image (already read: v) to the CRS values
+template <int DBG>
+__device__ __forceinline__ void stream_store(const UnitCtx &c, const StreamCtx &s, int m, v2d v, int lane) {
+  const int vb = __builtin_amdgcn_readlane(s.vb, m), lo = __builtin_amdgcn_readlane(s.lo, m), hi = __builtin_amdgcn_readlane(s.hi, m);
+  const int e = 2 * lane;
+  const bool on0 = e >= lo && e < hi && !(DBG & 2), on1 = e + 1 >= lo && e + 1 < hi && !(DBG & 2);
+  v4i bits;
+  bits[0] = __double2loint(v[0]);
+  bits[1] = __double2hiint(v[0]);
+  bits[2] = __double2loint(v[1]);
+  bits[3] = __double2hiint(v[1]);
+  raw_buffer_store_b128(bits, c.out, (int)((on0 && on1) ? (unsigned)(vb + lane * 16) : kOutOfRange), 0, 0);  // (soffset: the constant 0, see run_unit)
+  if (((lo & 1) && lo > 0 && lo < 128) || ((hi & 1) && hi > 0 && hi < 128)) {  // wave-uniform: a lane with one entry of the run
+    v2i b1;
+    b1[0] = on0 ? bits[0] : bits[2];
+    b1[1] = on0 ? bits[1] : bits[3];
+    raw_buffer_store_b64(b1, c.out, (int)((on0 != on1) ? (unsigned)(vb + lane * 16 + (on0 ? 0 : 8)) : kOutOfRange), 0, 0);
+  }
+}
+// chunks m0 .. m1 - 1, the image read of chunk m + 1 in flight while chunk m is stored
+template <int DBG>
+__device__ __forceinline__ void stream_range(const UnitCtx &c, const StreamCtx &s, int m0, int m1, int lane) {
+  if (m0 >= m1) return;
+  v2d v = stream_read(c, s, m0, lane);
+  for (int m = m0; m < m1; ++m) {
+    const v2d vn = stream_read(c, s, min(m + 1, m1 - 1), lane);
+    stream_store<DBG>(c, s, m, v, lane);
+    v = vn;
+  }
+}
+
+// wave 0 of an image role: element records only (no stores: its loads never queue behind any)
+template <int DBG>
+__device__ __forceinline__ void run_loader_img(const UnitCtx &c, int lane) {
+  const int rec_doubles = c.estride * kBpRecDoubles;
+  constexpr int RL = kRecLoads;
+  double Ra[RL], Rb[RL];
+  auto fetch = [&](int i, double (&dst)[RL]) {  // past the end: the last block again (in bounds)
+    const int boff = __builtin_amdgcn_readfirstlane((c.first + min(i, c.nblocks - 1)) * rec_doubles * 8);
+#pragma unroll
+    for (int k = 0; k < RL; ++k) dst[k] = asm_load_f64(c.erec, (unsigned)min(k * 64 + lane, rec_doubles - 1) * 8u, boff);
+  };
+  auto deposit = [&](double (&src)[RL], double *buf) {
+#pragma unroll
+    for (int k = 0; k < RL; ++k) {
+      asm volatile("" : "+v"(src[k]));
+      if (k * 64 + lane < rec_doubles) buf[k * 64 + lane] = src[k];
+    }
+  };
+  fetch(0, Ra);
+  asm_wait_vmcnt<0>();
+  deposit(Ra, c.recbuf);
+  fetch(1, Ra);
+  fetch(2, Rb);
+  lds_barrier();  // B0: block 0's records are in place
+  for (int i = 0; i <= c.nblocks; i += 2) {
+    lds_barrier();  // B1 of iteration i
+    asm_wait_vmcnt<RL>();
+    deposit(Ra, c.recbuf + ((i + 1) & 1) * c.recstride);  // block i + 1: that buffer was last read during iteration i - 1
+    fetch(i + 3, Ra);
+    lds_barrier();  // B2
+    if (i + 1 > c.nblocks) break;
+    lds_barrier();  // B1 of iteration i + 1
+    asm_wait_vmcnt<RL>();
+    deposit(Rb, c.recbuf + (i & 1) * c.recstride);
+    fetch(i + 4, Rb);
+    lds_barrier();  // B2
+  }
+  asm_wait_vmcnt<0>();
+}
+
+// a streaming wavefront without a unit
+template <int DBG>
+__device__ __forceinline__ void run_stream_only(const UnitCtx &c, int lane) {
+  StreamCtx sc = make_stream(c, lane);
+  lds_barrier();  // B0
+  for (int i = 0; i <= c.nblocks; ++i) {
+    stream_block(c, sc, i - 1);
+    stream_range<DBG>(c, sc, 0, sc.ncw, lane);
+    lds_barrier();  // B1
+    lds_barrier();  // B2
+  }
+}
+
+// One unit of an image role over all blocks of the segment.  REGW: the unit's blocks of W live in registers (loaded from
+// the role's global image once per segment), else they are read from LDS as in run_unit.  TRIM 3 as in run_unit.
+template <int KS, int NT, bool TAIL, int DBG, int TRIM, bool REGW>
+__device__ __forceinline__ void run_unit_img(const UnitCtx &c, const int32_t *__restrict__ L, int lane) {
+  constexpr int NPK = (KS + 1) / 2;
+  constexpr int NQ = NT + (TAIL ? 1 : 0);
+  constexpr int NP = NT / 2;
+  static_assert(!REGW || (NT == 2 && !TAIL), "REGW units are one tile pair");
+  unsigned apk[NPK];
+#pragma unroll
+  for (int q = 0; q < NPK; ++q) {
+    const unsigned lo = (unsigned)L[(2 * q) * 64 + lane];
+    const unsigned hi = (2 * q + 1 < KS) ? (unsigned)L[(2 * q + 1) * 64 + lane] : 0u;
+    apk[q] = lo | (hi << 16);
+  }
+  const int relrow = L[20 * 64 + lane];  // tile row (lane & 15): run << 20 | CRS offset inside the run, -1 = no row
+  const int imgrow = L[21 * 64 + lane];  // the same row's entry offset inside the image, before the run's alignment shift
+  const int nct_all = (c.len + 15) / 16;
+  const int stride = (nct_all % 2 == 1) ? 16 * nct_all : 16 * nct_all + 16;
+  auto aoff = [&](int s) { return (s & 1) ? (apk[s >> 1] >> 16) : (apk[s >> 1] & 0xffffu); };
+  const int l15 = lane & 15;
+  const double *Wp = c.Wl + l15;
+  const int cbase = __builtin_amdgcn_readfirstlane(16 * c.ct0), rlen = __builtin_amdgcn_readfirstlane(c.len - 16 * c.ct0);
+  // REGW: B operands of the whole unit
+  double Wr[REGW ? KS : 1][2];
+  if constexpr (REGW) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const size_t idx = (size_t)(4 * s + (lane >> 4)) * stride + 16 * c.ct0 + 2 * l15 + q;
+        Wr[s][q] = c.su * c.wk[idx] + c.st * c.wm[idx];
+      }
+      if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (all 56 loads at once would need twice the registers)
+    }
+  }
+  StreamCtx sc = make_stream(c, lane);
+  // image entries of this lane inside a row, a trash slot for the lanes that have none (branch-free writes)
+  const int trash = c.trash + lane;
+  lds_barrier();  // B0
+  for (int i = 0; i <= c.nblocks; ++i) {
+    const int ic = min(i, c.nblocks - 1);
+    stream_block(c, sc, i - 1);
+    // image offset of tile row (lane & 15) of block i: the run's slot + its global offset mod 16
+    const int irowC = (relrow >= 0 && i < c.nblocks) ? imgrow + (c.sbase[ic * c.nruns + (max(relrow, 0) >> 20)] & 15) : -1;
+    asm volatile("" ::: "memory");  // (the LDS has changed)
+    const double *rec = c.recbuf + (i & 1) * c.recstride;
+    v4d acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+    auto kloop = [&](auto cls_tag) {
+      constexpr int CLS = decltype(cls_tag)::value;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const double a = rec[aoff(s)];
+        if constexpr (!(DBG & 4)) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const bool second = s >= KS / 2;
+            if ((CLS == 1 && q < 2 && second) || (CLS == 2 && q >= 2 && !second) || (CLS == 3 && q < 2 && !second) ||
+                (CLS == 4 && q >= 2 && second))
+              continue;  // compile time
+            double b;
+            if constexpr (REGW) b = Wr[s][q];
+            else b = q < 2 * NP ? Wp[(4 * s) * stride + 32 * (q >> 1) + (q & 1)] : c.Wl[(4 * s) * stride + 16 * q];
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+          }
+        } else {
+          acc[0][0] += a;
+        }
+        // this wavefront's share of the previous block's image, spread over the k-steps
+        stream_range<DBG>(c, sc, (s * sc.ncw) / KS, ((s + 1) * sc.ncw) / KS, lane);
+      }
+    };
+    if constexpr (TRIM == 3) {
+      switch (c.trim) {
+        case 1: kloop(std::integral_constant<int, 1>{}); break;
+        case 2: kloop(std::integral_constant<int, 2>{}); break;
+        case 3: kloop(std::integral_constant<int, 3>{}); break;
+        case 4: kloop(std::integral_constant<int, 4>{}); break;
+        default: kloop(std::integral_constant<int, 0>{}); break;
+      }
+    } else {
+      kloop(std::integral_constant<int, 0>{});
+    }
+    lds_barrier();  // B1: the image has been read out
+    // results of block i -> image (every lane writes: those without an entry into the trash slot)
+    int ro[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ro[t] = __builtin_amdgcn_ds_bpermute(((lane >> 4) + 4 * t) * 4, irowC);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rb = ro[t] + cbase;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int col = 32 * p + 2 * l15;
+        c.img[(ro[t] >= 0 && col < rlen) ? rb + col : trash] = acc[2 * p][t];
+        c.img[(ro[t] >= 0 && col + 1 < rlen) ? rb + col + 1 : trash] = acc[2 * p + 1][t];
+      }
+#pragma unroll
+      for (int q = 2 * NP; q < NQ; ++q) {
+        const int col = 16 * q + l15;
+        c.img[(ro[t] >= 0 && col < rlen) ? rb + col : trash] = acc[q][t];
+      }
+    }
+    lds_barrier();  // B2: the image is complete
+  }
+}
+
 // Units of fixed dofs (isFixedDOF rows: the scatter skips them, assemblyManager.cpp:4075, 4120): zeros when storing.  A
 // wavefront takes up to kMaxFixedUnits of them; no loads, one row per store instruction.
 constexpr int kMaxFixedUnits = 6;
@@ -366,7 +651,9 @@ __device__ __forceinline__ void unit_generic(const UnitCtx &c, const int32_t *__
 
 // DBG (profiling launches only, env MHA_BP_DBG): 1 plain-load form of every unit, 2 no stores, 4 no products, 8 wall-clock
 // stamps of every wavefront
-template <int DBG>
+// IMAGE: the launch for the roles with an LDS image (d.wg_seg_ptr_img); the two families of unit code do not fit one
+// register budget, so each gets a kernel of its own.
+template <int DBG, bool IMAGE = false>
 __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(BlockPatternDev d, RowOut out, double su, double st) {
   extern __shared__ double W[];  // [max_w_doubles] the role's image, [kBpSegInts] ints: the segment's run offsets, 2 x element records of a block
   int *sbase = reinterpret_cast<int *>(W + d.max_w_doubles);
@@ -389,7 +676,8 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
     }
   };
   stamp();
-  const int sg_begin = d.wg_seg_ptr[blockIdx.x], sg_end = d.wg_seg_ptr[blockIdx.x + 1];
+  const int32_t *wsp = IMAGE ? d.wg_seg_ptr_img : d.wg_seg_ptr;
+  const int sg_begin = wsp[blockIdx.x], sg_end = wsp[blockIdx.x + 1];
   int cur_role = -1;
   for (int sg = sg_begin; sg < sg_end; ++sg) {
     const int role = d.seg[4 * sg];
@@ -403,7 +691,7 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
       const double2 *srck = reinterpret_cast<const double2 *>(d.w + woff);
       const double2 *srcm = reinterpret_cast<const double2 *>(d.w + woff + ro[R_WDOUBLES]);
       double2 *dst = reinterpret_cast<double2 *>(W);
-      const int n2 = ro[R_WDOUBLES] / 2;
+      const int n2 = (IMAGE ? ro[R_WLDS] : ro[R_WDOUBLES]) / 2;  // (image kernel: the REGW classes behind R_WLDS stay in memory)
       for (int i = tid; i < n2; i += kBpWaves * 64) {
         const double2 a = srck[i], b = srcm[i];
         dst[i] = make_double2(su * a.x + st * b.x, su * a.y + st * b.y);
@@ -445,7 +733,64 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
     // barrier per block inside).  Everything else goes block by block through the plain form.
     bool done = false;
     const bool loader = wave == 0;
-    if (p_end - p_begin == 1 && out.overwrite && !(DBG & 1)) {
+    if constexpr (IMAGE) {
+      // ---- image role: wave 0 loads records, every other wavefront runs its unit (if any) and streams ----
+      c.img = W + ro[R_WLDS];
+      c.trash = ro[R_IMG];  // (behind the image: the launcher adds the 512 bytes)
+      c.chunks = d.chunk_tab + ((((long long)ro[R_CHUNK_HI]) << 32) | (unsigned)ro[R_CHUNK_LO]) * kBpChunkInts;
+      c.nchunk = ro[R_NCHUNK];
+      c.sidx = wave - 1;
+      c.su = su;
+      c.st = st;
+      if (loader) {
+        run_loader_img<DBG>(c, lane);
+      } else if (p_end == p_begin) {
+        run_stream_only<DBG>(c, lane);
+      } else {
+        int ks, ntile;
+        bool fixed_class, tail;
+        const int32_t *L = setup(p_begin, ks, ntile, fixed_class, tail);
+        const int32_t *h = d.part_hdr + (size_t)p_begin * kBpHdrInts;
+        const bool regw = (h[H_FLAGS] & 32) != 0;
+        c.trim = __builtin_amdgcn_readfirstlane((d.dbg & 16) ? 0 : ((h[H_FLAGS] >> 2) & 7));
+        const long long woff = ((long long)ro[R_WOFF_HI] << 32) | (unsigned)ro[R_WOFF_LO];
+        c.wk = d.w + woff + h[H_WOFF];
+        c.wm = c.wk + ro[R_WDOUBLES];
+        const int key = ((ks * 8 + ntile) * 2 + (tail ? 1 : 0)) * 2 + (regw ? 1 : 0);
+#define BP_IMG(KS_, NT_, TAIL_, TRIM_, REGW_)                                                \
+  case ((KS_ * 8 + NT_) * 2 + (TAIL_ ? 1 : 0)) * 2 + (REGW_ ? 1 : 0):                        \
+    run_unit_img<KS_, NT_, TAIL_, DBG, TRIM_, REGW_>(c, L, lane);                            \
+    break;
+        switch (key) {
+          // Q2 hexes
+          BP_IMG(14, 2, false, 0, true)
+          BP_IMG(14, 4, false, 3, false)
+          BP_IMG(7, 4, true, 0, false)
+          BP_IMG(7, 4, false, 0, false)
+          BP_IMG(4, 3, false, 0, false)
+          BP_IMG(2, 2, false, 0, false)
+          // Q1 hexes
+          BP_IMG(14, 2, false, 0, false)
+          BP_IMG(7, 2, false, 0, false)
+          BP_IMG(4, 0, true, 0, false)
+          BP_IMG(2, 0, true, 0, false)
+          // quads
+          BP_IMG(4, 2, false, 0, false)
+          BP_IMG(4, 4, false, 0, false)
+          BP_IMG(2, 3, false, 0, false)
+          BP_IMG(1, 2, false, 0, false)
+          BP_IMG(1, 0, true, 0, false)
+          default: __builtin_trap();  // the planner only makes image roles of shapes listed here (kBpImageShapes)
+        }
+#undef BP_IMG
+      }
+      done = true;
+    } else {
+    if (!done && loader && p_end == p_begin && out.overwrite && !(DBG & 1)) {
+      run_loader_only<DBG>(c, lane);
+      done = true;
+    }
+    if (!done && p_end - p_begin == 1 && out.overwrite && !(DBG & 1)) {
       int ks, ntile;
       bool fixed_class, tail;
       const int32_t *L = setup(p_begin, ks, ntile, fixed_class, tail);
@@ -512,6 +857,7 @@ __global__ __launch_bounds__(kBpWaves * 64) void block_pattern_jacobian_kernel(B
         }
       }
     }
+    }
     stamp();
   }
   if constexpr (TIMING) { tslot = 7; stamp(); }
@@ -532,25 +878,44 @@ void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, 
   if (d.num_wgs <= 0 || !out.vals) return;
   const size_t lds = sizeof(double) * (size_t)d.max_w_doubles + sizeof(int) * kBpSegInts + 2 * sizeof(double) * (size_t)d.max_rec_doubles;
   MHA_REQUIRE(lds <= 160 * 1024, MHA_ERR_INVALID, "pattern matrices of " << lds << " B do not fit the LDS");
-  auto go = [&](auto kern) {
+  auto go = [&](auto kern, const BlockPatternDev &dd) {
     MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(kern, dim3(d.num_wgs), dim3(kBpWaves * 64), lds, stream, d, out, su, st);
+    hipLaunchKernelGGL(kern, dim3(dd.num_wgs), dim3(kBpWaves * 64), lds, stream, dd, out, su, st);
   };
   // (bit 16 is a run-time switch: no k-step trim of the 14 x 4 units; 32 selects the small-record build)
   const int small_rec = (d.max_rec_doubles <= 384 && (d.dbg & 15) == 0 && !d.timing && !(d.dbg & 32)) ? 32 : 0;
-  switch ((d.dbg & 15) | (d.timing ? 8 : 0) | small_rec) {
-    case 32: go(block_pattern_jacobian_kernel<32>); break;
-    case 0: go(block_pattern_jacobian_kernel<0>); break;
-    case 1: go(block_pattern_jacobian_kernel<1>); break;
-    case 2: go(block_pattern_jacobian_kernel<2>); break;
-    case 4: go(block_pattern_jacobian_kernel<4>); break;
-    case 6: go(block_pattern_jacobian_kernel<6>); break;
-    case 8: go(block_pattern_jacobian_kernel<8>); break;
-    case 10: go(block_pattern_jacobian_kernel<10>); break;
-    case 12: go(block_pattern_jacobian_kernel<12>); break;
-    case 14: go(block_pattern_jacobian_kernel<14>); break;
-    default: MHA_REQUIRE(false, MHA_ERR_INVALID, "MHA_BP_DBG: unsupported combination");
+  auto direct = [&](const BlockPatternDev &dd) {
+    switch ((d.dbg & 15) | (d.timing ? 8 : 0) | small_rec) {
+      case 32: go(block_pattern_jacobian_kernel<32>, dd); break;
+      case 0: go(block_pattern_jacobian_kernel<0>, dd); break;
+      case 1: go(block_pattern_jacobian_kernel<1>, dd); break;
+      case 2: go(block_pattern_jacobian_kernel<2>, dd); break;
+      case 4: go(block_pattern_jacobian_kernel<4>, dd); break;
+      case 6: go(block_pattern_jacobian_kernel<6>, dd); break;
+      case 8: go(block_pattern_jacobian_kernel<8>, dd); break;
+      case 10: go(block_pattern_jacobian_kernel<10>, dd); break;
+      case 12: go(block_pattern_jacobian_kernel<12>, dd); break;
+      case 14: go(block_pattern_jacobian_kernel<14>, dd); break;
+      default: MHA_REQUIRE(false, MHA_ERR_INVALID, "MHA_BP_DBG: unsupported combination");
+    }
+  };
+  // the image roles first (most of a mesh: its interior), in the kernel of their own when rows are overwritten; when they
+  // are accumulated (or on request, bit 1) through the plain form of the other kernel
+  if (d.has_image) {
+    if (out.overwrite && !(d.dbg & 1) && !d.timing) {
+      switch (d.dbg & 6) {
+        case 0: go(block_pattern_jacobian_kernel<0, true>, d); break;
+        case 2: go(block_pattern_jacobian_kernel<2, true>, d); break;
+        case 4: go(block_pattern_jacobian_kernel<4, true>, d); break;
+        default: go(block_pattern_jacobian_kernel<6, true>, d); break;
+      }
+    } else {
+      BlockPatternDev d2 = d;
+      d2.wg_seg_ptr = d.wg_seg_ptr_img;
+      direct(d2);
+    }
   }
+  if (d.has_direct) direct(d);
   MHA_HIP(hipGetLastError());
 }
 

@@ -257,6 +257,9 @@ struct BlockPatternDev {
   const int32_t *rowbase = nullptr;    // role-major, block-major CRS offsets of the owned rows [R]
   const double *w = nullptr;           // LDS images of the roles
   const int32_t *role = nullptr, *seg = nullptr, *wg_seg_ptr = nullptr, *part_ptr = nullptr, *part_hdr = nullptr, *part_lane = nullptr;
+  const int32_t *wg_seg_ptr_img = nullptr;  // segments of the image roles' kernel
+  bool has_direct = true, has_image = false;
+  const int32_t *chunk_tab = nullptr;  // image roles: 64-entry chunks of a block's LDS image (block_pattern.hpp)
   long long nnz = 0;                   // CRS entries (the kernel addresses them with 32-bit byte offsets: nnz < 2^28)
   long long *timing = nullptr;         // profiling aid (env MHA_BP_TIMING): [num_wgs][16 waves][8] wall-clock stamps (10 ns)
 };
