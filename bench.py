@@ -16,7 +16,9 @@ shape (SURVEY.md section 8(d) inputs and bytes per element):
   5  shallowwaterHybridized HDG on 256^2 quads: side blocks + volume + static condensation + flux->trace scatter
                                                         11 056 B/element
 N>1: one block of the configuration's size per GPU (weak scaling), stacked in z so that neighbouring ranks share
-one dof plane (configs 2 and 4; configs 3 and 5 need explicit shared-row lists: not wired).
+one dof plane (configs 2 and 4), the HDIV z-face dofs (config 3) or -- strips stacked in y -- the HFACE trace rows of
+the horizontal edges between two strips (config 5): explicit shared-row lists from the global ids (SharedRowExport).
+`python bench.py --gpus N` without a launcher spawns its own N ranks (torch.distributed.run on 127.0.0.1).
 
 Prints ONE JSON line on rank 0.
 """
@@ -340,9 +342,12 @@ def setup_block(kind, args, torch, mrhyde_amd, rank, world, dev):
     vals = torch.zeros(nnz, dtype=torch.float64, device=dev)
     exch = None
     if world > 1:
-        assert kind == "ns", "config 3 at N>1 needs explicit shared-row lists (HDIV face dofs): not wired"
-        P = int(sum((o * nc + 1) ** 2 for o in orders))
-        exch = SlabExchange(rowptr, colind, P, nrows, rank, world, dev)
+        if kind == "ns":
+            P = int(sum((o * nc + 1) ** 2 for o in orders))
+            exch = SlabExchange(rowptr, colind, P, nrows, rank, world, dev)
+        else:  # porousMixed: the shared dofs are the HDIV z-faces between two slabs -- explicit lists from the global ids
+            from mrhyde_amd.shared_rows import SharedRowExport, porous_slab_gids
+            exch = SharedRowExport(porous_slab_gids(nc, [nc] * world, rank), rowptr, colind, rank, world, dev)
 
     def step():
         blk.assemble_jacres(u, res, vals, compute_jacobian=True, overwrite=True)
@@ -380,9 +385,10 @@ def setup_block(kind, args, torch, mrhyde_amd, rank, world, dev):
 def setup_hdg(args, torch, mrhyde_amd, rank, world, dev):
     """config 5: shallowwaterHybridized HDG on nc^2 quads (Q1 interior, HFACE-1 traces): side blocks of all four sides
     (boundaryResidual / computeFlux) + volume element matrices + static condensation + flux->trace scatter."""
-    assert world == 1, "config 5 at N>1 needs the trace rows shared between strips: not wired (DESIGN.md section 5)"
     nc = args.ncell or 256
-    m = mrhyde_amd.mesh_multi(2, (nc, nc), [HGRAD] * 3, [1, 1, 1])
+    # N > 1: strips of nc element rows stacked in y, one per GPU; neighbouring strips share the HFACE trace rows of the
+    # horizontal edges between them -> Export(ADD) of the condensed trace system (SharedRowExport)
+    m = mrhyde_amd.mesh_multi(2, (nc, nc), [HGRAD] * 3, [1, 1, 1], [0.0, float(rank), 0.0], [1.0, float(rank + 1), 1.0])
     E = m["nelem"]
     blk = mrhyde_amd.Block(2, quadrature=2, physics="shallowwaterHybridized", variables=[(HGRAD, 1)] * 3, device=dev.index)
     blk.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -397,18 +403,14 @@ def setup_hdg(args, torch, mrhyde_amd, rank, world, dev):
     lr = torch.zeros((E, 12), dtype=torch.float64, device=dev)
     off = torch.tensor(m["offsets"], device=dev, dtype=torch.long)
     eye = 10.0 * torch.eye(12, dtype=torch.float64, device=dev)  # mass-like shift a transient run contributes
-    # macro trace system: HFACE edge numbering of the nc x nc mesh
-    nvert = (nc + 1) * nc
-    ii, jj = np.meshgrid(np.arange(nc), np.arange(nc), indexing="xy")
-    ii, jj = ii.ravel(), jj.ravel()
-    edges = np.stack([jj * (nc + 1) + ii, nvert + jj * nc + ii, jj * (nc + 1) + ii + 1, nvert + (jj + 1) * nc + ii], axis=1)
-    lids = np.zeros((E, 24), np.int32)
-    for v in range(3):
-        for k in range(4):
-            for f in range(2):
-                lids[:, (v * 4 + k) * 2 + f] = (edges[:, k] * 3 + v) * 2 + f
-    nrows_t = (nvert + nc * (nc + 1)) * 6
+    # macro trace system: HFACE edge numbering of the strip's nc x nc mesh
+    from mrhyde_amd.shared_rows import SharedRowExport, hdg_strip_gids, hdg_trace_lids
+    lids, nrows_t = hdg_trace_lids(nc, nc)
     plan = mrhyde_amd.ScatterPlan(lids, nrows_t)
+    exch = None
+    if world > 1:
+        t_rowptr, t_colind = plan.graph()
+        exch = SharedRowExport(hdg_strip_gids(nc, [nc] * world, rank), t_rowptr, t_colind, rank, world, dev)
     tv = torch.zeros(plan.nnz, dtype=torch.float64, device=dev)
     tr_ = torch.zeros(nrows_t, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -420,6 +422,8 @@ def setup_hdg(args, torch, mrhyde_amd, rank, world, dev):
         res[:, :12] += lr[:, off]
         S, gv, du, ns = mrhyde_amd.batched_condense(12, 24, blocks, res)
         plan.apply(S, gv, tr_, tv, overwrite=True, stream=stream)
+        if exch is not None:
+            exch.export_add(tr_, tv)
 
     def kernel_ms(reps):
         ts = []
@@ -440,7 +444,7 @@ def setup_hdg(args, torch, mrhyde_amd, rank, world, dev):
         log("cpu baseline (1 thread, bounded sample)")
         return cpu_baseline_hdg(512, 6)  # ~10 s of one core
 
-    return dict(step=step, kernel_ms=kernel_ms, E=E, b_elem=11056, info=info, cpu=cpu, exch=None, nrows=m["ndof"], nnz=plan.nnz,
+    return dict(step=step, kernel_ms=kernel_ms, E=E, b_elem=11056, info=info, cpu=cpu, exch=exch, nrows=m["ndof"], nnz=plan.nnz,
                 workload="shallowwaterHybridized HDG on %d^2 quads (Q1 interior, HFACE-1 traces): side blocks + volume + "
                          "static condensation + flux->trace scatter" % nc)
 
@@ -523,10 +527,11 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     log("timed %d steps: %.3f s" % (args.steps, elapsed))
+    wire = w["exch"].bytes_on_wire() if w["exch"] else 0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, float(wire)], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, wire = float(tt[0].item()), int(tt[1].item())  # (the owner of a shared row -- the lowest rank -- sends nothing)
 
     # dominant-kernel duration, measured live with HIP events on the context's stream
     kernel_ms = w["kernel_ms"](max(3, min(args.steps, 10)))
@@ -537,8 +542,8 @@ def main():
         pname, kern, extra = w["info"]()
         cfg = {"workload": w["workload"], "baseline_config": args.config, "elements_per_gpu": E, "dofs_per_gpu": w["nrows"],
                "nnz_per_gpu": w["nnz"], "path": pname,
-               "partition": "z-slabs, 1 per GPU" if world > 1 else "single block",
-               "shared_row_bytes_per_step": w["exch"].bytes_on_wire() if w["exch"] else 0}
+               "partition": ("strips of element rows, 1 per GPU" if args.config == 5 else "z-slabs, 1 per GPU") if world > 1 else "single block",
+               "shared_row_bytes_per_step": wire}
         cfg.update(extra)
         out = {
             "metric": "assembled elements/sec (vol Jacobian+residual)",

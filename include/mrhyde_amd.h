@@ -402,7 +402,9 @@ int mha_swhdg_element_blocks(mha_context *ctx, const double *u_dev, const double
  * u += du, reassemble, scaled = |res_u|_inf / resnorm_initial.  u_dev is updated in place.  Outputs: iters_dev[E] =
  * assemblies the element's loop performed (the reference's `iter`), resnorm_scaled_dev[E], and -- from one closing
  * assembly at the final state -- schur_dev[E][24][24], gvec_dev[E][24] as mha_batched_condense defines them (either may
- * be NULL: no closing pass), *num_singular_dev = singular interior blocks met.  Everything is enqueued on the context's
+ * be NULL: no closing pass), *num_singular_dev = singular interior blocks met, CUMULATIVE over all max_iter + 1
+ * condensation passes (an element that stays singular is counted once per pass, also after it has left its loop):
+ * zero means no pass met one; it is not a count of elements.  Everything is enqueued on the context's
  * stream: NO host synchronisation and NO allocation inside (workspace_dev of mha_swhdg_subgrid_workspace_bytes bytes is
  * the caller's; side tables are built on the first call).  Elements that have converged are still swept by the remaining
  * passes and ignored: the uniform schedule is what keeps the host out of the loop.                                   */
@@ -493,13 +495,17 @@ void mha_row_partition_destroy(mha_row_partition *p);
  * mha_export_pack / mha_export_unpack_add are the device halves (the caller moves the buffers, e.g. with
  * torch.distributed P2P, whose "nccl" backend is RCCL); mha_export_add does pack + ncclSend / ncclRecv with every
  * neighbour in one group + unpack on this library's own RCCL communicator (mha_comm_*; librccl.so is loaded on first
- * use).  Neighbours are unpacked in the order given: the sum is reproducible.                                        */
+ * use).  Neighbours are unpacked in the order given: the sum is reproducible.
+ * nnz / nrows are the sizes of the value array and the residual the lists index: every index is range-checked at plan
+ * creation and the receive targets of one neighbour must be distinct (MHA_ERR_INVALID otherwise).  vals_dev == NULL in
+ * pack / unpack_add / export_add means a residual-only exchange (assembleRes, solverManager.cpp:1552-1556): the value
+ * segments are skipped, on the wire too; res_dev == NULL likewise.                                                     */
 typedef struct mha_export_plan mha_export_plan;
 typedef struct mha_comm mha_comm;
 int mha_export_plan_create(int num_neighbors, const int32_t *neighbor_ranks, const int64_t *send_val_ptr,
                            const int32_t *send_val_index, const int64_t *send_row_ptr, const int32_t *send_row_index,
                            const int64_t *recv_val_ptr, const int32_t *recv_val_target, const int64_t *recv_row_ptr,
-                           const int32_t *recv_row_target, mha_export_plan **out);
+                           const int32_t *recv_row_target, int64_t nnz, int64_t nrows, mha_export_plan **out);
 void mha_export_plan_destroy(mha_export_plan *p);
 int mha_export_pack(const mha_export_plan *p, const double *vals_dev, const double *res_dev, void *hip_stream);
 int mha_export_unpack_add(const mha_export_plan *p, double *vals_dev, double *res_dev, void *hip_stream);

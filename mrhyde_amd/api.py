@@ -515,7 +515,12 @@ class Block:
         nb = C.c_int64()
         _check(load_library().mha_swhdg_subgrid_workspace_bytes(self._h, C.byref(nb)))
         E = lam.shape[0]
-        ws = torch.empty(nb.value, dtype=torch.uint8, device=u.device)
+        # one workspace per Block, reallocated only when the size changes (a new mesh): a time loop that calls this once
+        # per macro step must not grow the heap (0.8 GB per call at 256^2 elements)
+        ws = getattr(self, "_subgrid_ws", None)
+        if ws is None or ws.numel() != nb.value or ws.device != u.device:
+            ws = torch.empty(nb.value, dtype=torch.uint8, device=u.device)
+            self._subgrid_ws = ws
         out = dict(iters=torch.zeros(E, dtype=torch.int32, device=u.device), resnorm=torch.zeros(E, dtype=torch.float64, device=u.device),
                    num_singular=torch.zeros(1, dtype=torch.int32, device=u.device))
         if want_condensed:
@@ -526,7 +531,6 @@ class Block:
                                                       None if ff is None else ff.ctypes.data_as(C.c_void_p), int(max_iter),
                                                       float(tol), _ptr(ws), nb.value, _ptr(out.get("schur")), _ptr(out.get("gvec")),
                                                       _ptr(out["iters"]), _ptr(out["resnorm"]), _ptr(out["num_singular"])))
-        self._keep.append(ws)
         return out
 
     def scatter_local(self, local_J, local_res, res, crs_vals):

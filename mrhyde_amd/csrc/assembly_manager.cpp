@@ -531,7 +531,10 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
           const char *m = std::getenv("MHA_GATHER_ORDER"), *k = std::getenv("MHA_POROUS_KERNEL");
           return (m && m[0] == 'p') || (k && k[0] == 'e');  // the point engine writes LID-position order only
         }();
-        dof_order = !by_pos && !adjoint && !lump_mass && physics_->label == "porousMixed";
+        // (the same predicate launch_row_gather has for dof-ordered arrays -- short rows, one-byte slots: a porousMixed
+        // block with a wider caller graph or 16-bit slots keeps the position order instead of failing)
+        dof_order = !by_pos && !adjoint && !lump_mass && physics_->label == "porousMixed" && max_row_ <= 32 && n_ <= 16 &&
+                    elem_slot_bytes_ == 1;
         o.local_dof_order = dof_order ? 1 : 0;
         launchPointEngine(compute_jacobian, o, 0, nelem_);
       }

@@ -596,13 +596,14 @@ int mha_test_block_patterns_host_apply(int dim, int num_rows, int num_elems, int
 int mha_export_plan_create(int num_neighbors, const int32_t *neighbor_ranks, const int64_t *send_val_ptr,
                            const int32_t *send_val_index, const int64_t *send_row_ptr, const int32_t *send_row_index,
                            const int64_t *recv_val_ptr, const int32_t *recv_val_target, const int64_t *recv_row_ptr,
-                           const int32_t *recv_row_target, mha_export_plan **out) {
+                           const int32_t *recv_row_target, int64_t nnz, int64_t nrows, mha_export_plan **out) {
   return guarded([&] {
     MHA_REQUIRE(out != nullptr, MHA_ERR_INVALID, "null argument");
     *out = nullptr;
     auto p = std::make_unique<mha_export_plan>();
     p->plan = std::make_unique<mha::ExportPlan>(num_neighbors, neighbor_ranks, send_val_ptr, send_val_index, send_row_ptr,
-                                                send_row_index, recv_val_ptr, recv_val_target, recv_row_ptr, recv_row_target);
+                                                send_row_index, recv_val_ptr, recv_val_target, recv_row_ptr, recv_row_target,
+                                                nnz, nrows);
     *out = p.release();
   });
 }

@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -12,7 +13,8 @@ namespace mha {
 
 ExportPlan::ExportPlan(int nnb, const int32_t *ranks, const int64_t *sv_ptr, const int32_t *sv_idx, const int64_t *sr_ptr,
                        const int32_t *sr_idx, const int64_t *rv_ptr, const int32_t *rv_tgt, const int64_t *rr_ptr,
-                       const int32_t *rr_tgt) {
+                       const int32_t *rr_tgt, int64_t nnz, int64_t nrows) {
+  MHA_REQUIRE(nnz >= 0 && nrows >= 0, MHA_ERR_INVALID, "export plan: negative array size");
   MHA_REQUIRE(nnb >= 0, MHA_ERR_INVALID, "export plan: negative neighbour count");
   if (nnb > 0)
     MHA_REQUIRE(ranks && sv_ptr && sr_ptr && rv_ptr && rr_ptr, MHA_ERR_INVALID, "export plan: null list");
@@ -29,9 +31,26 @@ ExportPlan::ExportPlan(int nnb, const int32_t *ranks, const int64_t *sv_ptr, con
   take(rr_ptr, rr_ptr_);
   MHA_REQUIRE((sv_ptr_.back() == 0 || sv_idx) && (sr_ptr_.back() == 0 || sr_idx) && (rv_ptr_.back() == 0 || rv_tgt) &&
                   (rr_ptr_.back() == 0 || rr_tgt), MHA_ERR_INVALID, "export plan: null index list");
-  for (int64_t i = 0; i < sv_ptr_.back(); ++i) MHA_REQUIRE(sv_idx[i] >= 0, MHA_ERR_INVALID, "export plan: negative send index");
-  for (int64_t i = 0; i < sr_ptr_.back(); ++i) MHA_REQUIRE(sr_idx[i] >= 0, MHA_ERR_INVALID, "export plan: negative send row");
-  for (int64_t i = 0; i < rr_ptr_.back(); ++i) MHA_REQUIRE(rr_tgt[i] >= 0, MHA_ERR_INVALID, "export plan: negative receive row");
+  for (int64_t i = 0; i < sv_ptr_.back(); ++i)
+    MHA_REQUIRE(sv_idx[i] >= 0 && sv_idx[i] < nnz, MHA_ERR_INVALID, "export plan: send index " << sv_idx[i] << " outside the value array (" << nnz << " entries)");
+  for (int64_t i = 0; i < sr_ptr_.back(); ++i)
+    MHA_REQUIRE(sr_idx[i] >= 0 && sr_idx[i] < nrows, MHA_ERR_INVALID, "export plan: send row " << sr_idx[i] << " outside the residual (" << nrows << " rows)");
+  for (int64_t i = 0; i < rv_ptr_.back(); ++i)
+    MHA_REQUIRE(rv_tgt[i] >= -1 && rv_tgt[i] < nnz, MHA_ERR_INVALID, "export plan: receive target " << rv_tgt[i] << " outside the value array (" << nnz << " entries)");
+  for (int64_t i = 0; i < rr_ptr_.back(); ++i)
+    MHA_REQUIRE(rr_tgt[i] >= 0 && rr_tgt[i] < nrows, MHA_ERR_INVALID, "export plan: receive row " << rr_tgt[i] << " outside the residual (" << nrows << " rows)");
+  {  // the targets of ONE neighbour are added by one kernel launch with plain read-modify-write: they must be distinct
+    std::vector<int32_t> t;
+    for (int k = 0; k < nnb; ++k) {
+      t.assign(rv_tgt + rv_ptr_[k], rv_tgt + rv_ptr_[k + 1]);
+      t.erase(std::remove(t.begin(), t.end(), -1), t.end());
+      std::sort(t.begin(), t.end());
+      MHA_REQUIRE(std::adjacent_find(t.begin(), t.end()) == t.end(), MHA_ERR_INVALID, "export plan: neighbour " << ranks[k] << " lists a value target twice");
+      t.assign(rr_tgt + rr_ptr_[k], rr_tgt + rr_ptr_[k + 1]);
+      std::sort(t.begin(), t.end());
+      MHA_REQUIRE(std::adjacent_find(t.begin(), t.end()) == t.end(), MHA_ERR_INVALID, "export plan: neighbour " << ranks[k] << " lists a residual row twice");
+    }
+  }
   sv_idx_.upload(sv_idx, static_cast<size_t>(sv_ptr_.back()));
   sr_idx_.upload(sr_idx, static_cast<size_t>(sr_ptr_.back()));
   rv_tgt_.upload(rv_tgt, static_cast<size_t>(rv_ptr_.back()));
@@ -63,28 +82,23 @@ int64_t ExportPlan::bytesOnWire() const {
 void ExportPlan::pack(const double *vals, const double *res, hipStream_t stream) const {
   for (int k = 0; k < numNeighbors(); ++k) {
     const int64_t nv = sv_ptr_[k + 1] - sv_ptr_[k], nr = sr_ptr_[k + 1] - sr_ptr_[k];
-    if (nv > 0) {
-      MHA_REQUIRE(vals != nullptr, MHA_ERR_INVALID, "export plan: value entries listed but no value array given");
-      launch_export_pack(vals, sv_idx_.data() + sv_ptr_[k], nv, send_[k].data(), stream);
-    }
-    if (nr > 0) {
-      MHA_REQUIRE(res != nullptr, MHA_ERR_INVALID, "export plan: residual rows listed but no residual given");
-      launch_export_pack(res, sr_idx_.data() + sr_ptr_[k], nr, send_[k].data() + nv, stream);
-    }
+    if (nv > 0 && vals) launch_export_pack(vals, sv_idx_.data() + sv_ptr_[k], nv, send_[k].data(), stream);
+    if (nr > 0 && res) launch_export_pack(res, sr_idx_.data() + sr_ptr_[k], nr, send_[k].data() + nv, stream);
   }
 }
 
 void ExportPlan::unpackAdd(double *vals, double *res, hipStream_t stream) const {
   for (int k = 0; k < numNeighbors(); ++k) {  // one neighbour after the other: two may add into the same row
     const int64_t nv = rv_ptr_[k + 1] - rv_ptr_[k], nr = rr_ptr_[k + 1] - rr_ptr_[k];
-    if (nv > 0) launch_export_unpack_add(recv_[k].data(), rv_tgt_.data() + rv_ptr_[k], nv, vals, stream);
-    if (nr > 0) launch_export_unpack_add(recv_[k].data() + nv, rr_tgt_.data() + rr_ptr_[k], nr, res, stream);
+    if (nv > 0 && vals) launch_export_unpack_add(recv_[k].data(), rv_tgt_.data() + rv_ptr_[k], nv, vals, stream);
+    if (nr > 0 && res) launch_export_unpack_add(recv_[k].data() + nv, rr_tgt_.data() + rr_ptr_[k], nr, res, stream);
   }
 }
 
 void ExportPlan::exportAdd(Comm &comm, double *vals, double *res, hipStream_t stream) const {
+  MHA_REQUIRE(vals || res, MHA_ERR_INVALID, "export plan: nothing to exchange (no value array, no residual)");
   pack(vals, res, stream);
-  comm.sendRecv(*this, stream);
+  comm.sendRecv(*this, stream, vals != nullptr, res != nullptr);
   unpackAdd(vals, res, stream);
 }
 
@@ -155,14 +169,17 @@ Comm::~Comm() {
   if (comm_) (void)rccl().CommDestroy(comm_);
 }
 
-void Comm::sendRecv(const ExportPlan &plan, hipStream_t stream) {
+void Comm::sendRecv(const ExportPlan &plan, hipStream_t stream, bool values, bool residual) {
   Rccl &r = rccl();
   check(r.GroupStart(), "ncclGroupStart");
   for (int k = 0; k < plan.numNeighbors(); ++k) {
     int64_t ns = 0, nr = 0;
     double *s = plan.sendBuffer(k, &ns), *v = plan.recvBuffer(k, &nr);
-    if (ns > 0) check(r.Send(s, static_cast<size_t>(ns), kNcclFloat64, plan.rank(k), comm_, stream), "ncclSend");
-    if (nr > 0) check(r.Recv(v, static_cast<size_t>(nr), kNcclFloat64, plan.rank(k), comm_, stream), "ncclRecv");
+    // the buffers are [values | residual entries]: a residual-only (or values-only) exchange moves its half
+    const int64_t sv = plan.sendValues(k), rv = plan.recvValues(k);
+    const int64_t s0 = values ? 0 : sv, s1 = residual ? ns : sv, r0 = values ? 0 : rv, r1 = residual ? nr : rv;
+    if (s1 > s0) check(r.Send(s + s0, static_cast<size_t>(s1 - s0), kNcclFloat64, plan.rank(k), comm_, stream), "ncclSend");
+    if (r1 > r0) check(r.Recv(v + r0, static_cast<size_t>(r1 - r0), kNcclFloat64, plan.rank(k), comm_, stream), "ncclRecv");
   }
   check(r.GroupEnd(), "ncclGroupEnd");
 }

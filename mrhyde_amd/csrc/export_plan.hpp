@@ -24,12 +24,16 @@ class Comm;  // RCCL communicator (export_plan.cpp), loaded on first use
 class ExportPlan {
  public:
   // CSR-like per-neighbour lists (host): *_ptr have num_neighbors + 1 entries
+  // nnz / nrows: sizes of the value array and the residual the lists index (every index is checked against them, and
+  // the receive targets of one neighbour must be distinct: unpackAdd adds with plain read-modify-write)
   ExportPlan(int num_neighbors, const int32_t *ranks, const int64_t *send_val_ptr, const int32_t *send_val_index,
              const int64_t *send_row_ptr, const int32_t *send_row_index, const int64_t *recv_val_ptr,
-             const int32_t *recv_val_target, const int64_t *recv_row_ptr, const int32_t *recv_row_target);
+             const int32_t *recv_val_target, const int64_t *recv_row_ptr, const int32_t *recv_row_target, int64_t nnz,
+             int64_t nrows);
   int numNeighbors() const { return static_cast<int>(ranks_.size()); }
   int rank(int k) const { return ranks_[k]; }
-  // my non-owned rows -> send buffers
+  // my non-owned rows -> send buffers.  vals == nullptr: a residual-only exchange (the value segments are skipped here,
+  // in unpackAdd and on the wire of exportAdd); res == nullptr likewise
   void pack(const double *vals, const double *res, hipStream_t stream) const;
   // receive buffers -> my owned rows (+=), neighbours in the order given (deterministic)
   void unpackAdd(double *vals, double *res, hipStream_t stream) const;
@@ -37,6 +41,8 @@ class ExportPlan {
   double *sendBuffer(int k, int64_t *count) const;
   double *recvBuffer(int k, int64_t *count) const;
   int64_t bytesOnWire() const;
+  int64_t sendValues(int k) const { return sv_ptr_[k + 1] - sv_ptr_[k]; }
+  int64_t recvValues(int k) const { return rv_ptr_[k + 1] - rv_ptr_[k]; }
   // pack + ncclSend / ncclRecv with every neighbour in one group + unpackAdd
   void exportAdd(Comm &comm, double *vals, double *res, hipStream_t stream) const;
 
@@ -53,7 +59,7 @@ class Comm {
   static void uniqueId(char id[128]);
   Comm(int nranks, int rank, const char id[128]);
   ~Comm();
-  void sendRecv(const ExportPlan &plan, hipStream_t stream);
+  void sendRecv(const ExportPlan &plan, hipStream_t stream, bool values = true, bool residual = true);
   int rank() const { return rank_; }
   int size() const { return nranks_; }
 

@@ -52,6 +52,7 @@ class SharedRowExport:
         colind = np.asarray(colind)
         n = len(gid)
         assert len(rowptr) == n + 1 and len(np.unique(gid)) == n, "one global id per local row"
+        self._nrows, self._nnz = n, int(rowptr[-1])
         self.neighbors, self.send_val, self.send_row, self.recv_val, self.recv_row = [], {}, {}, {}, {}
         self._plan = None
         if world == 1:
@@ -143,11 +144,11 @@ class SharedRowExport:
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         ranks = np.ascontiguousarray(nb, dtype=np.int32)
         self._plan = C.c_void_p()
-        lib.mha_export_plan_create.argtypes = [C.c_int] + [C.c_void_p] * 10
+        lib.mha_export_plan_create.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int64, C.c_int64, C.c_void_p]
         args = [vp(ranks)]
         for ptr, flat in self._lists:
             args += [vp(ptr), vp(flat)]
-        _check(lib.mha_export_plan_create(len(nb), *args, C.byref(self._plan)))
+        _check(lib.mha_export_plan_create(len(nb), *args, self._nnz, self._nrows, C.byref(self._plan)))
         self._send, self._recv = {}, {}
         lib.mha_export_buffers.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
         for i, k in enumerate(nb):
@@ -193,7 +194,11 @@ class SharedRowExport:
             from .api import _check, load_library
             lib = load_library()
             assert res.is_cuda and (vals is None or vals.is_cuda), "the plan lives on the GPU"
-            s = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+            cur = torch.cuda.current_stream().cuda_stream
+            # the staging copies below run on torch's current stream: a foreign stream would race them against the pack /
+            # unpack kernels
+            assert stream is None or int(stream) == int(cur), "export_add: pass torch's current stream (or none)"
+            s = C.c_void_p(cur)
             vptr = C.c_void_p(vals.data_ptr()) if vals is not None else None
             if self._comm is not None:  # the library's own RCCL communicator: pack + ncclSend / ncclRecv + unpack
                 _check(lib.mha_export_add(self._plan, self._comm, vptr, C.c_void_p(res.data_ptr()), s))
@@ -202,30 +207,33 @@ class SharedRowExport:
         else:
             for k in self.neighbors:
                 sv, sr, _, _ = self._t[k]
-                self._send[k][:len(sv)] = vals[sv] if vals is not None else 0.0
+                if vals is not None:
+                    self._send[k][:len(sv)] = vals[sv]
                 self._send[k][len(sv):] = res[sr]
         # The plan's buffers are the library's (seen by torch through __cuda_array_interface__).  gloo (rehearsal of N > 1
-        # on one GPU) moves host copies; RCCL moves torch-owned device copies of the few MB involved -- collectives on
-        # memory the caching allocator does not own are legal but have never run on hardware here, and a device copy costs
-        # microseconds (MHA_EXPORT_ZERO_COPY=1 hands the library's buffers to RCCL directly).
+        # on one GPU) moves host copies; with RCCL the buffers go on the wire as they are (MHA_EXPORT_STAGED=1 restores the
+        # torch-owned device copies of round 2).  A residual-only exchange (vals is None) moves the residual halves only.
         gloo = self._on_gpu and dist.get_backend() == "gloo"
-        staged = self._on_gpu and (gloo or os.environ.get("MHA_EXPORT_ZERO_COPY", "0") != "1")
+        staged = self._on_gpu and (gloo or os.environ.get("MHA_EXPORT_STAGED", "0") == "1")
         ops, keep = [], []
         for k in self.neighbors:
-            if len(self._send[k]):
-                b = (self._send[k].cpu() if gloo else self._send[k].clone()) if staged else self._send[k]
+            s0 = 0 if vals is not None else len(self.send_val[k])
+            r0 = 0 if vals is not None else len(self.recv_val[k])
+            sb, rb = self._send[k][s0:], self._recv[k][r0:]
+            if len(sb):
+                b = (sb.cpu() if gloo else sb.clone()) if staged else sb
                 keep.append(b)
                 ops.append(dist.P2POp(dist.isend, b, k))
-            if len(self._recv[k]):
-                b = (self._recv[k].cpu() if gloo else torch.empty_like(self._recv[k])) if staged else self._recv[k]
-                keep.append((k, b))
+            if len(rb):
+                b = (rb.cpu() if gloo else torch.empty_like(rb)) if staged else rb
+                keep.append((rb, b))
                 ops.append(dist.P2POp(dist.irecv, b, k))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         if staged:
             for item in keep:
                 if isinstance(item, tuple):
-                    self._recv[item[0]].copy_(item[1])
+                    item[0].copy_(item[1])
         if self._on_gpu:
             _check(lib.mha_export_unpack_add(self._plan, vptr, C.c_void_p(res.data_ptr()), s))
         else:
@@ -253,6 +261,48 @@ def slab_gids(nrows, plane_rows, rank):
     last `plane_rows` rows of a slab (lexicographic node numbering, z slowest; any set of HGRAD variables numbered
     lattice-site-major): the slabs' numberings overlap by one plane."""
     return np.arange(nrows, dtype=np.int64) + rank * (nrows - plane_rows)
+
+
+def porous_slab_gids(nxy, nz, rank):
+    """porousMixed (HVOL p + HDIV u) on z-slabs of nz[rank] layers of nxy x nxy hexes: global ids (numbering of the
+    single-domain mesh_multi: cells, x-faces, y-faces, z-faces) of a slab's dofs, in the slab's local order.  The shared
+    dofs are the z-faces between two slabs: not a leading / trailing run of rows."""
+    nzt, k0, nzl = int(sum(nz)), int(sum(nz[:rank])), int(nz[rank])
+    ne_g = nxy * nxy * nzt
+    cells = np.arange(nxy * nxy * nzl, dtype=np.int64) + nxy * nxy * k0
+    fx = ne_g + np.arange((nxy + 1) * nxy * nzl, dtype=np.int64) + (nxy + 1) * nxy * k0
+    fy = ne_g + (nxy + 1) * nxy * nzt + np.arange(nxy * (nxy + 1) * nzl, dtype=np.int64) + nxy * (nxy + 1) * k0
+    fz = ne_g + 2 * (nxy + 1) * nxy * nzt + np.arange(nxy * nxy * (nzl + 1), dtype=np.int64) + nxy * nxy * k0
+    return np.concatenate([cells, fx, fy, fz])
+
+
+def hdg_trace_lids(ncx, ncy, nvar=3, per_edge=2):
+    """Trace LIDs [E][4 * nvar * per_edge] of an ncx x ncy quad mesh with HFACE traces: edges numbered vertical ones first
+    (row by row), then the horizontal ones; local edge order left, bottom, right, top (Intrepid2_HFACE_QUAD_In_FEM);
+    dof = ((edge * nvar + var) * per_edge + f), element-local slot ((var * 4 + k) * per_edge + f).  Returns (lids, nrows)."""
+    nvert = (ncx + 1) * ncy
+    ii, jj = np.meshgrid(np.arange(ncx), np.arange(ncy), indexing="xy")
+    ii, jj = ii.ravel(), jj.ravel()
+    edges = np.stack([jj * (ncx + 1) + ii, nvert + jj * ncx + ii, jj * (ncx + 1) + ii + 1, nvert + (jj + 1) * ncx + ii], axis=1)
+    lids = np.zeros((ncx * ncy, 4 * nvar * per_edge), np.int32)
+    for v in range(nvar):
+        for k in range(4):
+            for f in range(per_edge):
+                lids[:, (v * 4 + k) * per_edge + f] = (edges[:, k] * nvar + v) * per_edge + f
+    return lids, (nvert + ncx * (ncy + 1)) * nvar * per_edge
+
+
+def hdg_strip_gids(ncx, ncy, rank, nvar=3, per_edge=2):
+    """Strips of ncy[rank] element rows stacked in y (config 5: 8 strips of 32 rows): global id of every local trace
+    row of strip `rank`, numbering of hdg_trace_lids on the whole ncx x sum(ncy) mesh.  Neighbouring strips share the
+    horizontal edges between them (the HDG trace rows of SubGridDtN_Solver::updateFlux, subgridDtN_solver.cpp:1542-1616)."""
+    nyt, j0, nyl = int(sum(ncy)), int(sum(ncy[:rank])), int(ncy[rank])
+    nvert_l, nvert_g = (ncx + 1) * nyl, (ncx + 1) * nyt
+    e_loc = np.arange(nvert_l + ncx * (nyl + 1), dtype=np.int64)
+    vert = e_loc < nvert_l
+    ge = np.where(vert, e_loc + j0 * (ncx + 1), nvert_g + (e_loc - nvert_l) + j0 * ncx)
+    d = np.arange(nvar * per_edge, dtype=np.int64)
+    return (ge[:, None] * (nvar * per_edge) + d[None, :]).ravel()
 
 
 class SlabExchange(SharedRowExport):

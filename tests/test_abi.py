@@ -66,3 +66,34 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(mrhyde_amd.MhaError) as ei:
         mrhyde_amd.Block(2, 1)
     assert ei.value.code == 3 and "no CPU fallback" in str(ei.value)
+
+
+def test_export_plan_rejects_bad_lists():
+    """mha_export_plan_create range-checks every index against the array sizes and refuses duplicate receive targets of
+    one neighbour (the unpack kernel adds with plain read-modify-write) -- before anything touches a device."""
+    import ctypes as C
+    import numpy as np
+    import mrhyde_amd
+    lib = mrhyde_amd.load_library()
+    lib.mha_export_plan_create.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int64, C.c_int64, C.c_void_p]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    ranks = np.array([1], np.int32)
+    one, zero = np.array([0, 1], np.int64), np.array([0, 0], np.int64)
+    two = np.array([0, 2], np.int64)
+
+    def create(sv, sr, rv, rr, nnz, nrows, svp=one, srp=one, rvp=one, rrp=one):
+        h = C.c_void_p()
+        a = lambda x: np.array(x, np.int32)
+        rc = lib.mha_export_plan_create(1, vp(ranks), vp(svp), vp(a(sv)), vp(srp), vp(a(sr)), vp(rvp), vp(a(rv)), vp(rrp),
+                                        vp(a(rr)), nnz, nrows, C.byref(h))
+        return rc, lib.mha_last_error().decode() if rc else ""
+
+    lib.mha_last_error.restype = C.c_char_p
+    rc, msg = create([10], [0], [0], [0], 10, 4)
+    assert rc == 1 and "outside the value array" in msg
+    rc, msg = create([0], [4], [0], [0], 10, 4)
+    assert rc == 1 and "outside the residual" in msg
+    rc, msg = create([0], [0], [-2], [0], 10, 4)
+    assert rc == 1 and "receive target" in msg
+    rc, msg = create([0, 1], [0], [3, 3], [0], 10, 4, svp=two, rvp=two)
+    assert rc == 1 and "twice" in msg

@@ -268,3 +268,90 @@ def test_two_unequal_slabs_porous_mixed_explicit_lists(oracle):
             assert abs(res[r] - ref["res"][gid[r]]) <= 1e-12 * np.abs(ref["res"]).max()
             seen[gid[r]] = True
     assert seen.all()
+
+
+# ---- HDG trace rows shared between strips (config 5: the condensed trace system of SubGridDtN_Solver::updateFlux,
+# ---- subgridDtN_solver.cpp:1542-1616, exported with ADD as linearAlgebraInterface.hpp:296-337 does) ----
+
+def _trace_scatter(lids, nrows, S, g):
+    """Plain COO accumulation of condensed element blocks into the trace system (what mha_scatter_plan_apply computes)."""
+    n = lids.shape[1]
+    rows = np.repeat(lids, n, axis=1).ravel()
+    cols = np.tile(lids, (1, n)).ravel()
+    J = sp.coo_matrix((S.ravel(), (rows, cols)), shape=(nrows, nrows)).tocsr()
+    J.sort_indices()
+    r = np.zeros(nrows)
+    np.add.at(r, lids.ravel(), g.ravel())
+    return J, r
+
+
+def _worker_hdg(rank, world, port, ncx, ncy, residual_only, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    from mrhyde_amd.shared_rows import SharedRowExport, hdg_strip_gids, hdg_trace_lids
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lids, nrows = hdg_trace_lids(ncx, ncy[rank])
+        gid = hdg_strip_gids(ncx, ncy, rank)
+        E0 = ncx * sum(ncy[:rank])
+        rng = np.random.default_rng(66)
+        Sg = rng.uniform(-1, 1, (ncx * sum(ncy), 24, 24))  # one block per element of the WHOLE mesh: a strip takes its own
+        gg = rng.uniform(-1, 1, (ncx * sum(ncy), 24))
+        S, g = Sg[E0:E0 + lids.shape[0]], gg[E0:E0 + lids.shape[0]]
+        J, r = _trace_scatter(lids, nrows, S, g)
+        vals, res = torch.tensor(J.data.copy()), torch.tensor(r)
+        ex = SharedRowExport(gid, J.indptr, J.indices, rank, world, torch.device("cpu"))
+        ex.export_add(res, None if residual_only else vals)
+        q.put((rank, gid, J.indptr.copy(), J.indices.copy(), vals.numpy(), res.numpy(), J.data.copy(), ex.bytes_on_wire()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("residual_only", [False, True])
+def test_two_strips_hdg_trace_rows(residual_only):
+    """Strips of 3 and 2 element rows: the trace rows of the horizontal edges between them are summed into the owner
+    (the lower strip); every owned row equals the single-domain trace system.  residual_only: the exchange of
+    assembleRes (no value array) moves and adds the residual halves only."""
+    from mrhyde_amd.shared_rows import hdg_trace_lids
+    ncx, ncy, world = 4, (3, 2), 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hdg, args=(r, world, port, ncx, ncy, residual_only, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=180)
+        got[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lg, ng = hdg_trace_lids(ncx, sum(ncy))
+    rng = np.random.default_rng(66)
+    Sg = rng.uniform(-1, 1, (ncx * sum(ncy), 24, 24))
+    gg = rng.uniform(-1, 1, (ncx * sum(ncy), 24))
+    Jg, rg = _trace_scatter(lg, ng, Sg, gg)
+    Jg = Jg.toarray()
+    seen = np.zeros(ng, bool)
+    shared = np.intersect1d(got[0][1], got[1][1])
+    assert len(shared) == ncx * 6  # one row of horizontal edges, 3 variables x 2 dofs each
+    for rank in range(world):
+        _, gid, rowptr, colind, vals, res, vals0, wire = got[rank]
+        n = len(gid)
+        Jl = sp.csr_matrix((vals, colind, rowptr), shape=(n, n)).toarray()
+        owned = ~np.isin(gid, got[0][1]) if rank > 0 else np.ones(n, bool)
+        for r in np.flatnonzero(owned):
+            assert abs(res[r] - rg[gid[r]]) <= 1e-12 * np.abs(rg).max()
+            if not residual_only:
+                assert np.abs(Jl[r] - Jg[gid[r]][gid]).max() <= 1e-12 * np.abs(Jg).max(), (rank, r)
+            seen[gid[r]] = True
+        if residual_only:
+            assert np.array_equal(vals, vals0)  # the value array is not touched
+        assert wire == (0 if rank == 0 else 8 * (len(shared) + sum(rowptr[r + 1] - rowptr[r] for r in np.flatnonzero(np.isin(gid, shared)))))
+    assert seen.all()

@@ -100,3 +100,83 @@ def test_two_slabs_on_one_gpu_equal_single_domain(oracle, order, nxy, nz_per):
         for r in owned:
             assert np.abs(Jl[r] - Jg[r + off][off:off + nrows]).max() <= 1e-12 * scale, (rank, r)
             assert abs(res[r] - ref["res"][r + off]) <= 1e-12 * np.abs(ref["res"]).max()
+
+
+# ---- HDG trace rows (config 5): per-strip flux -> trace scatter on the device (mha_scatter_plan_apply), Export(ADD) of
+# ---- the trace rows between the strips through the library's pack / unpack kernels, against the single-domain scatter ----
+
+def _worker_hdg(rank, world, port, ncx, ncy, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import torch
+    import torch.distributed as dist
+    import mrhyde_amd
+    from mrhyde_amd.shared_rows import SharedRowExport, hdg_strip_gids, hdg_trace_lids
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        lids, nrows = hdg_trace_lids(ncx, ncy[rank])
+        gid = hdg_strip_gids(ncx, ncy, rank)
+        E0 = ncx * sum(ncy[:rank])
+        rng = np.random.default_rng(66)
+        Sg = rng.uniform(-1, 1, (ncx * sum(ncy), 24, 24))
+        gg = rng.uniform(-1, 1, (ncx * sum(ncy), 24))
+        S = torch.tensor(Sg[E0:E0 + lids.shape[0]], device=dev)
+        g = torch.tensor(gg[E0:E0 + lids.shape[0]], device=dev)
+        plan = mrhyde_amd.ScatterPlan(lids, nrows)
+        rowptr, colind = plan.graph()
+        vals = torch.zeros(plan.nnz, dtype=torch.float64, device=dev)
+        res = torch.zeros(nrows, dtype=torch.float64, device=dev)
+        plan.apply(S, g, res, vals, overwrite=True, stream=torch.cuda.current_stream().cuda_stream)
+        ex = SharedRowExport(gid, rowptr, colind, rank, world, dev)
+        assert ex._plan is not None
+        ex.export_add(res, vals)
+        res2 = res.clone()
+        ex.export_add(res2, None)  # residual-only exchange on the device path: the value array stays as it is
+        torch.cuda.synchronize()
+        q.put((rank, gid, rowptr, colind, vals.cpu().numpy(), res.cpu().numpy()))
+        dist.barrier()
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_strips_hdg_trace_rows_on_one_gpu():
+    import torch.multiprocessing as mp
+    from mrhyde_amd.shared_rows import hdg_trace_lids
+    ncx, ncy, world = 6, (4, 3), 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hdg, args=(r, world, port, ncx, ncy, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        got[item[0]] = item
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lg, ng = hdg_trace_lids(ncx, sum(ncy))
+    rng = np.random.default_rng(66)
+    Sg = rng.uniform(-1, 1, (ncx * sum(ncy), 24, 24))
+    gg = rng.uniform(-1, 1, (ncx * sum(ncy), 24))
+    n = lg.shape[1]
+    Jg = sp.coo_matrix((Sg.ravel(), (np.repeat(lg, n, axis=1).ravel(), np.tile(lg, (1, n)).ravel())), shape=(ng, ng)).toarray()
+    rg = np.zeros(ng)
+    np.add.at(rg, lg.ravel(), gg.ravel())
+    seen = np.zeros(ng, bool)
+    for rank in range(world):
+        _, gid, rowptr, colind, vals, res = got[rank]
+        nl = len(gid)
+        Jl = sp.csr_matrix((vals, colind, rowptr), shape=(nl, nl)).toarray()
+        owned = ~np.isin(gid, got[0][1]) if rank > 0 else np.ones(nl, bool)
+        for r in np.flatnonzero(owned):
+            assert np.abs(Jl[r] - Jg[gid[r]][gid]).max() <= 1e-12 * np.abs(Jg).max(), (rank, r)
+            assert abs(res[r] - rg[gid[r]]) <= 1e-12 * np.abs(rg).max()
+            seen[gid[r]] = True
+    assert seen.all()
