@@ -413,6 +413,19 @@ int mha_swhdg_subgrid_solve(mha_context *ctx, double *u_dev, const double *u_pre
                             const double *lambda_dev, const uint8_t *side_types_dev, const double *farfield_host,
                             int max_iter, double tol, void *workspace_dev, int64_t workspace_bytes, double *schur_dev,
                             double *gvec_dev, int32_t *iters_dev, double *resnorm_scaled_dev, int32_t *num_singular_dev);
+/* The element step of the HDG subgrid in ONE kernel: side terms (mha_swhdg_element_blocks) + volume terms
+ * (shallowwaterHybridized::volumeResidual, src/physics/shallowwaterHybridized.cpp:113-184) + static condensation
+ * (mha_batched_condense), one wavefront per element -- the [36 x 36] block of SubGridDtN_Solver::assembleJacobianResidual
+ * (src/subgrid/subgridDtN_solver.cpp:681-903) and updateFlux (:1542-1616) never leaves the chip.  Outputs as
+ * mha_batched_condense defines them: schur_dev[E][24][24], gvec_dev[E][24], du_dev[E][12] (flattened (variable, dof));
+ * any may be NULL, not all.  *num_singular_dev += singular interior blocks (device counter, may be NULL).  Enqueued on
+ * the context's stream: no synchronisation, no allocation (side tables are built on the first call).  Sources given as
+ * deck strings are refused (MHA_ERR_INVALID): the unfused entry points take those.  mha_swhdg_subgrid_solve runs this
+ * kernel once per pass with the loop bookkeeping and sol += du inside (MHA_SUBGRID_UNFUSED=1 keeps the four-kernel
+ * pipeline, the independent implementation the tests compare with).                                                 */
+int mha_swhdg_condensed_element(mha_context *ctx, const double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
+                                const double *lambda_dev, const uint8_t *side_types_dev, const double *farfield_host,
+                                double *schur_dev, double *gvec_dev, double *du_dev, int32_t *num_singular_dev);
 /* Batched static condensation of element blocks: eliminates the n_int interior unknowns of every element.
  * replaces: the element-local direct solve of the subgrid solver and its forward sensitivities d u / d lambda
  * (SubGridDtN_Solver, src/subgrid/subgridDtN_solver.cpp:681-903, 1542-1616) in Schur-complement form.

@@ -19,7 +19,7 @@ EXPORTS = [
     "mha_set_mesh", "mha_set_graph", "mha_get_graph_sizes", "mha_get_graph", "mha_physics_select",
     "mha_set_function", "mha_set_time_integration", "mha_assemble_jacres", "mha_compute_local_jacres",
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
-    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_mesh_multi_sizes", "mha_mesh_structured_multi", "mha_export_plan_create", "mha_export_plan_destroy", "mha_export_pack", "mha_export_unpack_add", "mha_export_buffers", "mha_export_bytes_on_wire", "mha_comm_unique_id", "mha_comm_create", "mha_comm_destroy", "mha_export_add", "mha_get_info", "mha_set_timing",
+    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_mesh_multi_sizes", "mha_mesh_structured_multi", "mha_swhdg_condensed_element", "mha_export_plan_create", "mha_export_plan_destroy", "mha_export_pack", "mha_export_unpack_add", "mha_export_buffers", "mha_export_bytes_on_wire", "mha_comm_unique_id", "mha_comm_create", "mha_comm_destroy", "mha_export_add", "mha_get_info", "mha_set_timing",
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_scatter_plan_create", "mha_scatter_plan_nnz",
     "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
@@ -506,6 +506,17 @@ class Block:
         w = None if masswts is None else _np(masswts, np.float64)
         _check(load_library().mha_apply_mass_matrix_free(self._h, mode, None if w is None else w.ctypes.data_as(C.c_void_p),
                                                          _ptr(mass), None if sparse is None else sparse._h, _ptr(x), _ptr(y)))
+
+    def swhdg_condensed_element(self, u, lam, schur=None, gvec=None, du=None, num_singular=None, side_types=None,
+                                farfield=None, u_prev=None, u_stage=None):
+        """Side + volume assembly + static condensation of every HDG element in one kernel (mha_swhdg_condensed_element):
+        fills the given CUDA tensors schur [E][24][24], gvec [E][24], du [E][12]; nothing else leaves the chip."""
+        ff = None if farfield is None else _np(farfield, np.float64)
+        lib = load_library()
+        lib.mha_swhdg_condensed_element.argtypes = [C.c_void_p] * 11
+        _check(lib.mha_swhdg_condensed_element(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(lam), _ptr(side_types),
+                                               None if ff is None else ff.ctypes.data_as(C.c_void_p), _ptr(schur), _ptr(gvec),
+                                               _ptr(du), _ptr(num_singular)))
 
     def swhdg_subgrid_solve(self, u, lam, max_iter, tol, side_types=None, farfield=None, u_prev=None, u_stage=None,
                             want_condensed=True):

@@ -743,6 +743,41 @@ void AssemblyManager::swhdgElementBlocks(const double *u, const double *u_prev, 
   timedEnd();
 }
 
+// The fused element step (kernels/swhdg_fused.hip): side + volume assembly + static condensation, nothing but S, g, du
+// (and the loop state) leaves the chip.  Deck-string sources are the one thing it does not take.
+bool AssemblyManager::swhdgFusedUsable() const {
+  const shallowwaterHybridized *sw = dynamic_cast<const shallowwaterHybridized *>(physics_.get());
+  if (!sw || std::getenv("MHA_SUBGRID_UNFUSED")) return false;
+  for (const char *k : {"source H", "source Hux", "source Huy"})
+    if (functions_.has(k) && functions_.evaluate(k).kind == MHA_FUNC_EXPRESSION) return false;
+  return dim_ == 2 && n_ == 12;
+}
+
+void AssemblyManager::swhdgCondensedElement(const double *u, const double *u_prev, const double *u_stage, const double *lambda,
+                                            const uint8_t *side_types, const double *farfield, SwhFusedOut o) {
+  requireReady(false);
+  shallowwaterHybridized *sw = dynamic_cast<shallowwaterHybridized *>(physics_.get());
+  MHA_REQUIRE(sw != nullptr, MHA_ERR_INVALID, "the block's physics module is not shallowwaterHybridized");
+  MHA_REQUIRE(lambda != nullptr, MHA_ERR_INVALID, "null trace values");
+  for (const auto &vi : vars_) MHA_REQUIRE(vi.order == 1, MHA_ERR_INVALID, "the HDG element is built for order-1 variables");
+  bindState(u, u_prev, u_stage);
+  prepareSideTables();
+  SwhElementDev a;
+  a.lambda = lambda;
+  a.side_types = side_types;
+  if (farfield) for (int i = 0; i < 3; ++i) a.farfield[i] = farfield[i];
+  a.g = sw->gravity;
+  a.roe = sw->roestab ? 1 : 0;
+  PhysParamsDev pp;
+  pp.physics = MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED;
+  const char *names[3] = {"source H", "source Hux", "source Huy"};
+  for (int k = 0; k < 3; ++k) pp.f[k] = functions_.evaluate(names[k]);
+  pp.p[0] = sw->gravity;
+  timedBegin();
+  launch_swhdg_fused(blockDev(), sideTablesDev(), a, time_, pp, o, stream_);
+  timedEnd();
+}
+
 // Workspace of subgridSolve (doubles unless noted): blocks [E][36][36], res [E][36], local_J [E][12][12], local_res
 // [E][12], du [E][12], rn0 [E], then int32 active [E].
 size_t AssemblyManager::subgridWorkspaceBytes() const {
@@ -783,6 +818,30 @@ void AssemblyManager::subgridSolve(double *u, const double *u_prev, const double
   double *res = blocks + E * n * n, *lJ = res + E * n, *lr = lJ + E * ni * ni, *du = lr + E * ni, *rn0 = du + E * ni;
   int32_t *active = reinterpret_cast<int32_t *>(rn0 + E);
   MHA_HIP(hipMemsetAsync(num_singular, 0, sizeof(int32_t), stream_));
+  if (swhdgFusedUsable()) {
+    // one kernel per pass: assembly, bookkeeping, element-local solve and sol += du fused (kernels/swhdg_fused.hip); the
+    // [36 x 36] blocks never reach memory
+    SwhFusedOut o;
+    o.singular = num_singular;
+    o.tol = tol;
+    o.rn0 = rn0;
+    o.scaled = resnorm_scaled;
+    o.iters = iters;
+    o.active = active;
+    for (int pass = 0; pass < max_iter; ++pass) {
+      o.pass = pass;
+      o.update_u = u;
+      swhdgCondensedElement(u, u_prev, u_stage, lambda, side_types, farfield, o);
+    }
+    if (schur || gvec) {
+      o.pass = -1;
+      o.update_u = nullptr;
+      o.schur = schur;
+      o.gvec = gvec;
+      swhdgCondensedElement(u, u_prev, u_stage, lambda, side_types, farfield, o);
+    }
+    return;
+  }
   auto assemble = [&](int pass) {
     swhdgElementBlocks(u, u_prev, u_stage, lambda, side_types, farfield, res, blocks);
     MHA_HIP(hipMemsetAsync(lJ, 0, sizeof(double) * E * (ni * ni + ni), stream_));  // local_J and local_res are contiguous

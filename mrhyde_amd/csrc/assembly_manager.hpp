@@ -52,6 +52,10 @@ class AssemblyManager {
                           const uint8_t *side_types, const double *farfield, double *res, double *blocks);
   // SubGridDtN_Solver::nonlinearSolver for HDG elements with element-local interior unknowns (subgridDtN_solver.cpp:909-1041)
   size_t subgridWorkspaceBytes() const;
+  // fused element step of the HDG subgrid (side + volume assembly + static condensation in one kernel)
+  bool swhdgFusedUsable() const;
+  void swhdgCondensedElement(const double *u, const double *u_prev, const double *u_stage, const double *lambda,
+                             const uint8_t *side_types, const double *farfield, SwhFusedOut out);
   void subgridSolve(double *u, const double *u_prev, const double *u_stage, const double *lambda, const uint8_t *side_types,
                     const double *farfield, int max_iter, double tol, void *workspace, size_t workspace_bytes, double *schur,
                     double *gvec, int32_t *iters, double *resnorm_scaled, int32_t *num_singular);

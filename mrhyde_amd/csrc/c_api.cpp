@@ -351,6 +351,20 @@ int mha_swhdg_subgrid_solve(mha_context *ctx, double *u, const double *u_prev, c
   });
 }
 
+int mha_swhdg_condensed_element(mha_context *ctx, const double *u, const double *u_prev, const double *u_stage,
+                                const double *lambda, const uint8_t *side_types, const double *farfield_host, double *schur,
+                                double *gvec, double *du, int32_t *num_singular) {
+  return guarded([&] {
+    MHA_REQUIRE(schur || gvec || du, MHA_ERR_INVALID, "no output requested");
+    mha::SwhFusedOut o;
+    o.schur = schur;
+    o.gvec = gvec;
+    o.du = du;
+    o.singular = num_singular;
+    mgr(ctx).swhdgCondensedElement(u, u_prev, u_stage, lambda, side_types, farfield_host, o);
+  });
+}
+
 int mha_swhdg_eigendecomp(double g, int64_t npts, const double *Shat, const double *normals, double *L, double *lam,
                           double *R, void *hip_stream) {
   return guarded([&] {

@@ -16,21 +16,13 @@
 
 #include <cstdint>
 
+#include "condense_core.hpp"
 #include "launch.hpp"
 
 namespace mha {
 namespace {
 
 constexpr int kCondMaxInt = 32, kCondWaves = 4;
-
-// Value of lane `src` (wave-uniform index) for every lane: v_readlane_b32 x2 into scalar registers.  The generic
-// __shfl goes through the LDS crossbar (ds_bpermute); the elimination does ~1500 of these per element.
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-
-constexpr int kCondMaxTrace = 32;  // trace rows held in registers (more: read row by row in the Schur loop)
 
 template <int MAXI>
 __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int nt, int64_t nelem,
@@ -59,57 +51,16 @@ __global__ __launch_bounds__(64 * kCondWaves) void condense_kernel(int ni, int n
     if (regs && a < nt && lane < ncol) v = lane < n ? B[(size_t)(ni + a) * n + lane] : r[ni + a];
     low[a] = v;
   }
-  bool bad = false;
-  for (int k = 0; k < ni; ++k) {
-    // partial pivoting on column k (held by lane k): the pivot row is the same for every lane
-    double best = -1.0;
-    int piv = k;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-      const double a = fabs(readlane_f64(col[i], k));
-      if (i >= k && i < ni && a > best) { best = a; piv = i; }
-    }
-    if (!(best > 0.0)) { bad = true; break; }
-    // swap rows k and piv of this lane's column (dynamic index -> select chain)
-    double ck = 0.0, cp = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) { if (i == k) ck = col[i]; if (i == piv) cp = col[i]; }
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) { if (i == k) col[i] = cp; else if (i == piv) col[i] = ck; }
-    // eliminate: row_i -= (a_ik / a_kk) row_k for all i != k, row_k /= a_kk
-    double pk = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) if (i == k) pk = col[i];
-    const double akk = readlane_f64(pk, k);
-    const double rk = pk / akk;  // this lane's entry of the normalised pivot row
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-      const double aik = readlane_f64(col[i], k);  // multiplier source: column k before the update
-      if (i < ni) col[i] = (i == k) ? rk : col[i] - aik * rk;
-    }
-  }
-  if (bad) { if (lane == 0 && singular) atomicAdd(singular, 1); return; }
+  if (!gauss_jordan_columns<MAXI>(ni, col)) { if (lane == 0 && singular) atomicAdd(singular, 1); return; }
   // lanes ni..n-1 now hold X_ul columns, lane n holds x_r = A_uu^{-1} r_u
-  if (du && lane == n)
-    for (int i = 0; i < ni; ++i) du[e * ni + i] = col[i];
-  // S[:, b] for trace column b = lane - ni; g through the last lane
   if (regs) {
-    const int b = lane - ni;
-#pragma unroll
-    for (int a = 0; a < kCondMaxTrace; ++a) {
-      if (a < nt) {  // uniform
-        const double rowv = low[a];
-        double sacc = rowv;
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-          const double m = readlane_f64(rowv, i);  // A_lu[a][i], executed by every lane
-          if (i < ni) sacc -= m * col[i];
-        }
-        if (lane >= ni && lane < n) { if (schur) schur[(e * nt + a) * nt + b] = sacc; }
-        else if (lane == n && gvec) gvec[e * nt + a] = sacc;
-      }
-    }
+    schur_from_registers<MAXI>(ni, nt, lane, e, col, low, schur, gvec, du);
   } else if (lane >= ni && lane < ncol) {
+    if (du && lane == n) {
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i)
+        if (i < ni) du[e * ni + i] = col[i];
+    }
     const int b = lane - ni;
     for (int a = 0; a < nt; ++a) {
       const double *Alu = B + (size_t)(ni + a) * n;  // row a of [A_lu | A_ll]

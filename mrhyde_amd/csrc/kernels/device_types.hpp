@@ -248,6 +248,19 @@ struct SwhElementDev {
   double *blocks = nullptr;              // [E][36][36] res(r).dx(c), stored
 };
 
+// Outputs and loop state of the fused HDG element step (kernels/swhdg_fused.hip); every pointer may be null.
+struct SwhFusedOut {
+  double *schur = nullptr;    // [E][24][24] S = A_ll - A_lu A_uu^-1 A_ul
+  double *gvec = nullptr;     // [E][24]     g = r_l - A_lu A_uu^-1 r_u
+  double *du = nullptr;       // [E][12]     A_uu^-1 r_u, flattened (variable, dof)
+  int *singular = nullptr;    // += 1 per element whose interior block is singular
+  double *update_u = nullptr; // [nrows]: sol += du for the elements still in their loop (active, or all when active is null)
+  int pass = -1;              // >= 0: bookkeeping of nonlinearSolver's loop for this pass (subgrid.hip)
+  double tol = 0.0;
+  double *rn0 = nullptr, *scaled = nullptr;
+  int32_t *iters = nullptr, *active = nullptr;
+};
+
 // Row blocks keyed by assembly pattern (block_pattern.hpp) for the matrix-core row-owner Jacobian.
 struct BlockPatternDev {
   int num_wgs = 0, max_w_doubles = 0;

@@ -127,6 +127,9 @@ void launch_swhdg_element(const BlockDev &b, const SideTablesDev &st, const SwhE
                           hipStream_t stream);
 
 // condense.hip: batched static condensation of element blocks (one wavefront per element)
+// swhdg_fused.hip: side + volume assembly + static condensation of the HDG element in one kernel
+void launch_swhdg_fused(const BlockDev &b, const SideTablesDev &st, const SwhElementDev &a, const TimeDev &tm,
+                        const PhysParamsDev &pp, const SwhFusedOut &o, hipStream_t stream);
 void launch_condense(int n_int, int n_trace, int64_t nelem, const double *blocks, const double *res, double *schur,
                      double *gvec, double *du, int *singular, hipStream_t stream);
 

@@ -424,3 +424,71 @@ def test_subgrid_sub_iteration_at_config5_size(oracle):
     u_ref, it_ref, _ = oracle.subgrid_nonlinear_solver(sub, 2, u[:12 * k], lam[:k], st[:k], ff, max_iter, tol, transient=trs)
     assert np.array_equal(out["iters"][:k], it_ref)
     assert np.abs(u_gpu[:12 * k] - u_ref).max() < 1e-10 * np.abs(u_ref).max()
+
+
+@pytest.mark.parametrize("steady", [False, True])
+def test_fused_element_step_equals_the_unfused_pipeline(oracle, steady, monkeypatch):
+    """mha_swhdg_condensed_element (side + volume assembly + static condensation in one kernel, the 36 x 36 block never
+    leaves the chip) against the independent four-kernel pipeline -- mha_swhdg_element_blocks + mha_compute_local_jacres +
+    the combine + mha_batched_condense -- and against the oracle's blocks condensed with numpy: S, g, du per element, on a
+    warped mesh with mixed side types, transient (2-stage tableau, BDF-2: mass term and history) and steady.  The
+    sub-iteration driver run with MHA_SUBGRID_UNFUSED=1 gives the same final state as the fused default."""
+    torch = _torch()
+    import mrhyde_amd
+    from test_multi_gpu import make_block
+    m, u, lam, st, ff, tr = dg_hdg_case(oracle, (6, 5), 27)
+    E = m["nelem"]
+    blk = make_block(m, "shallowwaterHybridized", 2)
+    blk.set_physics_parameter("g", 7.3)
+    blk.set_function("source Hux", ("sinprod", 0.3, [1.3, 0.7, 0.0]))
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")
+    kw = {}
+    if not steady:
+        blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+        kw = dict(u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]))
+    ud, ld, sd = t(u), t(lam), t(st)
+    # fused
+    S = torch.zeros((E, 24, 24), dtype=torch.float64, device="cuda")
+    g = torch.zeros((E, 24), dtype=torch.float64, device="cuda")
+    du = torch.zeros((E, 12), dtype=torch.float64, device="cuda")
+    ns = torch.zeros(1, dtype=torch.int32, device="cuda")
+    blk.swhdg_condensed_element(ud, ld, schur=S, gvec=g, du=du, num_singular=ns, side_types=sd, farfield=ff, **kw)
+    torch.cuda.synchronize()
+    assert int(ns[0]) == 0
+    # unfused pipeline
+    res = torch.zeros((E, 36), dtype=torch.float64, device="cuda")
+    blocks = torch.zeros((E, 36, 36), dtype=torch.float64, device="cuda")
+    blk.swhdg_element_blocks(ud, ld, res, blocks, side_types=sd, farfield=ff, **kw)
+    lJ = torch.zeros((E, 12, 12), dtype=torch.float64, device="cuda")
+    lr = torch.zeros((E, 12), dtype=torch.float64, device="cuda")
+    blk.compute_local_jacres(ud, lJ, lr, **kw)
+    off = torch.tensor(m["offsets"], device="cuda", dtype=torch.long)
+    blocks[:, :12, :12] += lJ[:, off][:, :, off]
+    res[:, :12] += lr[:, off]
+    S2, g2, du2, nsing = mrhyde_amd.batched_condense(12, 24, blocks, res)
+    assert nsing == 0
+    for a, b_, name in ((S, S2, "schur"), (g, g2, "gvec"), (du, du2, "du")):
+        d = float((a - b_).abs().max() / b_.abs().max())
+        assert d < 1e-11, (name, d)
+    # oracle blocks, condensed with numpy
+    tro = None if steady else tr
+    r_o, b_o = oracle.swh_hdg_element(m, 2, u, lam, st, ff, g=7.3, transient=tro)
+    vol = oracle.assemble_block(m, oracle.PHYS_SHALLOWWATER_HYBRIDIZED, 2, u, params=[7.3], transient=tro, want_local=True,
+                                funcs={"source Hux": ("sinprod", 0.3, [1.3, 0.7, 0.0])})
+    o = m["offsets"]
+    b_o[:, :12, :12] += vol["local_J"][:, o][:, :, o]
+    r_o[:, :12] += vol["local_res"][:, o]
+    X = np.linalg.solve(b_o[:, :12, :12], np.concatenate([b_o[:, :12, 12:], r_o[:, :12, None]], axis=2))
+    S_ref = b_o[:, 12:, 12:] - b_o[:, 12:, :12] @ X[:, :, :24]
+    g_ref = r_o[:, 12:] - (b_o[:, 12:, :12] @ X[:, :, 24:])[..., 0]
+    assert np.abs(S.cpu().numpy() - S_ref).max() < 1e-10 * np.abs(S_ref).max()
+    assert np.abs(g.cpu().numpy() - g_ref).max() < 1e-10 * max(np.abs(g_ref).max(), np.abs(r_o).max())
+    assert np.abs(du.cpu().numpy() - X[:, :, 24]).max() < 1e-10 * np.abs(X[:, :, 24]).max()
+    if not steady:  # the driver through both pipelines
+        u_f, out_f = run_subgrid(blk, torch, u, lam, st, ff, tr, 6, 1e-9)
+        monkeypatch.setenv("MHA_SUBGRID_UNFUSED", "1")
+        u_u, out_u = run_subgrid(blk, torch, u, lam, st, ff, tr, 6, 1e-9)
+        monkeypatch.delenv("MHA_SUBGRID_UNFUSED")
+        assert np.array_equal(out_f["iters"], out_u["iters"])
+        assert np.abs(u_f - u_u).max() < 1e-11 * np.abs(u_u).max()
+        assert np.abs(out_f["schur"] - out_u["schur"]).max() < 1e-10 * np.abs(out_u["schur"]).max()
