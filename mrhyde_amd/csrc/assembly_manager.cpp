@@ -284,6 +284,30 @@ void AssemblyManager::selectPhysics(int physics_id) {
   physics_ = import_physics(physics_id);
   physics_->defineFunctions(functions_);
   physics_->setWorkset(&wkset_);
+  // names of the solution fields a deck string may read (Workset::getSolutionField, workset.cpp:314-379) -> slots of
+  // the point engine's field arrays (physics_points.hpp): HGRAD [value, d/dx, d/dy(, d/dz)], HVOL [value],
+  // HDIV [v_x, v_y(, v_z), div]; `_t` names index the time-derivative array at the value slots
+  std::map<std::string, int> fields, fields_t;
+  const char *comp[3] = {"[x]", "[y]", "[z]"};
+  int slot = 0;
+  for (size_t v = 0; v < vars_.size() && v < physics_->myvars.size(); ++v) {
+    const std::string &nm = physics_->myvars[v];
+    if (vars_[v].type == MHA_BASIS_HGRAD) {
+      fields[nm] = slot;
+      fields_t[nm + "_t"] = slot;
+      for (int d = 0; d < dim_; ++d) fields["grad(" + nm + ")" + comp[d]] = slot + 1 + d;
+      slot += 1 + dim_;
+    } else if (vars_[v].type == MHA_BASIS_HVOL) {
+      fields[nm] = slot;
+      fields_t[nm + "_t"] = slot;
+      slot += 1;
+    } else {
+      for (int d = 0; d < dim_; ++d) { fields[nm + comp[d]] = slot + d; fields_t[nm + "_t" + comp[d]] = slot + d; }
+      fields["div(" + nm + ")"] = slot + dim_;
+      slot += dim_ + 1;
+    }
+  }
+  functions_.setFieldSlots(fields, fields_t);
 }
 
 void AssemblyManager::setFunction(const std::string &name, int kind, double amp, const double *freq3,

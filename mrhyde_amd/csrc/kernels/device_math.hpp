@@ -122,6 +122,84 @@ __device__ __forceinline__ double eval_expression(const FuncDesc &f, const doubl
   return st[0];
 }
 
+}  // namespace mha
+#include "dual.hpp"
+namespace mha {
+
+// The same program on Dual numbers, with the solution fields of the point as operands (EXPR_FIELD: U[slot],
+// EXPR_FIELD_T: Ud[slot]): value and ONE directional derivative -- the chain rule through a coefficient that depends on
+// the solution, which Sacado gives the reference for free (FunctionManager<AD>::evaluate, functionManager.cpp:543-860).
+// Comparisons and abs differentiate as the reference's AD does (piecewise).
+template <int DIM>
+__device__ __forceinline__ Dual eval_expression_dual(const FuncDesc &f, const double *x, const double *nrm, double h,
+                                                     const Dual *U, const Dual *Ud) {
+  Dual st[kExprStack];
+  int sp = 0;
+  for (const int32_t *pc = f.code;; ++pc) {
+    const int op = *pc;
+    if (op == EXPR_END) break;
+    if (op == EXPR_CONST) { st[sp++] = mk(f.consts[*++pc]); continue; }
+    if (op == EXPR_FIELD) { st[sp++] = U[*++pc]; continue; }
+    if (op == EXPR_FIELD_T) { st[sp++] = Ud[*++pc]; continue; }
+    if (op <= EXPR_PI) {
+      double v = 0.0;
+      switch (op) {
+        case EXPR_X: v = x[0]; break;
+        case EXPR_Y: v = x[1]; break;
+        case EXPR_Z: v = DIM > 2 ? x[DIM - 1] : 0.0; break;
+        case EXPR_T: v = f.t; break;
+        case EXPR_NX: v = nrm ? nrm[0] : 0.0; break;
+        case EXPR_NY: v = nrm ? nrm[1] : 0.0; break;
+        case EXPR_NZ: v = (nrm && DIM > 2) ? nrm[DIM - 1] : 0.0; break;
+        case EXPR_H: v = h; break;
+        default: v = 3.141592653589793238; break;
+      }
+      st[sp++] = mk(v);
+      continue;
+    }
+    if (op <= EXPR_GE) {
+      const Dual b = st[--sp], a = st[sp - 1];
+      Dual v;
+      switch (op) {
+        case EXPR_ADD: v = a + b; break;
+        case EXPR_SUB: v = a - b; break;
+        case EXPR_MUL: v = a * b; break;
+        case EXPR_DIV: v = a / b; break;
+        case EXPR_POW: {
+          // a^b: d = a^b (b' log a + b a'/a); a constant exponent (the usual case) needs no logarithm
+          const double p = pow(a.v, b.v);
+          double d = b.v * pow(a.v, b.v - 1.0) * a.d;
+          if (b.d != 0.0) d += p * log(a.v) * b.d;
+          v = mk(p, d);
+          break;
+        }
+        case EXPR_LT: v = mk(a.v < b.v ? 1.0 : 0.0); break;
+        case EXPR_GT: v = mk(a.v > b.v ? 1.0 : 0.0); break;
+        case EXPR_LE: v = mk(a.v <= b.v ? 1.0 : 0.0); break;
+        default: v = mk(a.v >= b.v ? 1.0 : 0.0); break;
+      }
+      st[sp - 1] = v;
+      continue;
+    }
+    const Dual a = st[sp - 1];
+    Dual v;
+    switch (op) {
+      case EXPR_NEG: v = -a; break;
+      case EXPR_SIN: v = mk(sin(a.v), cos(a.v) * a.d); break;
+      case EXPR_COS: v = mk(cos(a.v), -sin(a.v) * a.d); break;
+      case EXPR_TAN: { const double t = tan(a.v); v = mk(t, (1.0 + t * t) * a.d); break; }
+      case EXPR_EXP: { const double e = exp(a.v); v = mk(e, e * a.d); break; }
+      case EXPR_LOG: v = mk(log(a.v), a.d / a.v); break;
+      case EXPR_ABS: v = a.v < 0.0 ? -a : a; break;
+      case EXPR_SQRT: v = dsqrt(a); break;
+      case EXPR_SINH: v = mk(sinh(a.v), cosh(a.v) * a.d); break;
+      default: v = mk(cosh(a.v), sinh(a.v) * a.d); break;
+    }
+    st[sp - 1] = v;
+  }
+  return st[0];
+}
+
 // Value of a named function at integration point (e,q) with physical coordinates x (nrm: unit normal on sides).
 // EXPR: whether MHA_FUNC_EXPRESSION can occur.  The interpreter is a real call with a private stack; a kernel that
 // merely contains the call pays its register budget and scratch (the affine element kernel went from 8 to 2 waves per
@@ -141,8 +219,14 @@ __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int
 }
 
 inline bool has_expression(const FuncDesc &f) { return f.kind == MHA_FUNC_EXPRESSION; }
+inline bool uses_fields(const FuncDesc &f) { return f.kind == MHA_FUNC_EXPRESSION && f.uses_fields != 0; }
 inline bool has_expression(const ThermalDev &ph) {
   return has_expression(ph.source) || has_expression(ph.diff) || has_expression(ph.cp) || has_expression(ph.rho);
+}
+inline bool uses_fields(const PhysParamsDev &pp) {
+  for (const FuncDesc &f : pp.f)
+    if (uses_fields(f)) return true;
+  return false;
 }
 inline bool has_expression(const PhysParamsDev &pp) {
   for (const FuncDesc &f : pp.f)

@@ -16,7 +16,10 @@ enum ExprOp : int32_t {
   EXPR_END = 0, EXPR_CONST,
   EXPR_X, EXPR_Y, EXPR_Z, EXPR_T, EXPR_NX, EXPR_NY, EXPR_NZ, EXPR_H, EXPR_PI,  // operands
   EXPR_ADD, EXPR_SUB, EXPR_MUL, EXPR_DIV, EXPR_POW, EXPR_LT, EXPR_GT, EXPR_LE, EXPR_GE,  // binary
-  EXPR_NEG, EXPR_SIN, EXPR_COS, EXPR_TAN, EXPR_EXP, EXPR_LOG, EXPR_ABS, EXPR_SQRT, EXPR_SINH, EXPR_COSH  // unary
+  EXPR_NEG, EXPR_SIN, EXPR_COS, EXPR_TAN, EXPR_EXP, EXPR_LOG, EXPR_ABS, EXPR_SQRT, EXPR_SINH, EXPR_COSH,  // unary
+  // solution fields at the point (an index follows, as after EXPR_CONST): slot of the point engine's field array
+  // (physics_points.hpp: per variable value, d/dx, d/dy(, d/dz) ...) and of the time-derivative array ("e_t")
+  EXPR_FIELD, EXPR_FIELD_T
 };
 constexpr int kExprStack = 12;
 
@@ -28,6 +31,7 @@ struct FuncDesc {
   const int32_t *code = nullptr;    // MHA_FUNC_EXPRESSION: postfix program (device)
   const double *consts = nullptr;   //                      its constants (device)
   double t = 0.0;                   //                      current time (Workset::setTime)
+  int uses_fields = 0;              //                      the program reads solution fields (EXPR_FIELD*): Dual evaluation
 };
 
 // Device view of one element block.

@@ -23,21 +23,41 @@ struct PointArgs {
   const PhysParamsDev *pp;
 };
 
+// a function of the module at the point as a Dual: field-dependent deck strings carry the derivative with respect to the
+// direction the point's fields are seeded with, everything else is a constant of that direction
+template <int DIM>
+__device__ __forceinline__ Dual func_dual(const FuncDesc &f, const PointArgs<DIM> &a) {
+  if (f.kind == MHA_FUNC_EXPRESSION) return eval_expression_dual<DIM>(f, a.x, nullptr, a.h, a.U, a.Ud);
+  return mk(eval_func<DIM, false>(f, a.e, a.q, a.nq, a.x));
+}
+
 // thermal (reference: src/physics/thermal.cpp:71-165); functions {source, diffusion, specific heat, density}
-template <int DIM, bool EXPR>
+// EXPR: 0 constants / closed forms / arrays, 1 deck strings in the coordinates, 2 deck strings that read the solution
+// fields ("1+e*e": a nonlinear diffusion; the reference's FunctionManager<AD> differentiates them with Sacado)
+template <int DIM, int EXPR>
 __device__ __forceinline__ void thermal_point(const PointArgs<DIM> &a, Dual *F) {
   const PhysParamsDev &pp = *a.pp;
-  const double f = eval_func<DIM, EXPR>(pp.f[0], a.e, a.q, a.nq, a.x), kap = eval_func<DIM, EXPR>(pp.f[1], a.e, a.q, a.nq, a.x);
-  const double cp = eval_func<DIM, EXPR>(pp.f[2], a.e, a.q, a.nq, a.x), rho = eval_func<DIM, EXPR>(pp.f[3], a.e, a.q, a.nq, a.x);
+  if constexpr (EXPR == 2) {
+    const Dual f = func_dual<DIM>(pp.f[0], a), kap = func_dual<DIM>(pp.f[1], a);
+    const Dual cp = func_dual<DIM>(pp.f[2], a), rho = func_dual<DIM>(pp.f[3], a);
+    F[0] = a.Ud[0] * (rho * cp) - f;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) F[1 + d] = a.U[1 + d] * kap;
+    return;
+  } else {
+  constexpr bool EX = EXPR != 0;
+  const double f = eval_func<DIM, EX>(pp.f[0], a.e, a.q, a.nq, a.x), kap = eval_func<DIM, EX>(pp.f[1], a.e, a.q, a.nq, a.x);
+  const double cp = eval_func<DIM, EX>(pp.f[2], a.e, a.q, a.nq, a.x), rho = eval_func<DIM, EX>(pp.f[3], a.e, a.q, a.nq, a.x);
   F[0] = a.Ud[0] * (rho * cp) - f;
 #pragma unroll
   for (int d = 0; d < DIM; ++d) F[1 + d] = a.U[1 + d] * kap;
   // have_advection: (b . grad e) against the value of the test function (thermal.cpp:150-160).  Not in the deck-string
   // instantiation: with the interpreter inlined the kernel is at the scratch it may use (the host refuses that mix)
-  if constexpr (!EXPR)
+  if constexpr (!EX)
   if (pp.p[0] != 0.0) {
 #pragma unroll
     for (int d = 0; d < DIM; ++d) F[0] = F[0] + a.U[1 + d] * eval_func<DIM, false>(pp.f[4 + d], a.e, a.q, a.nq, a.x);  // (no deck strings: host checks)
+  }
   }
 }
 

@@ -151,7 +151,7 @@ __host__ __device__ inline size_t engine_group_doubles(const VarLayoutDev &vl, i
 // element and only wave-level synchronisation inside the element loop; TPE = 512: the whole workgroup, block barriers).
 // NQ1 = integration points per direction when it is 2 or 3 (the loops over points then have compile-time bounds and
 // the compiler batches their LDS loads), 0 = taken from the layout at run time.
-template <int DIM, int PHYS, int TPE, int NQ1, bool EXPR>
+template <int DIM, int PHYS, int TPE, int NQ1, int EXPR>  // EXPR: 0 / 1 deck strings / 2 deck strings that read the solution fields (thermal)
 __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
                                                                       TimeDev tm, ElemOut out_all,
                                                                       const uint8_t *slot8_all, const uint16_t *slot16_all) {
@@ -310,9 +310,9 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
           for (int sl = 0; sl < ns; ++sl) F[sp + sl] = value_like(type, sl, DIM) ? U[sp + sl] * pp.p[v] : mk(0.0);
         }
       } else if constexpr (PHYS == MHA_PHYSICS_THERMAL) thermal_point<DIM, EXPR>(pa, F);
-      else if constexpr (PHYS == MHA_PHYSICS_POROUS_MIXED) porous_point<DIM, EXPR>(pa, F);
-      else if constexpr (PHYS == MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED) swhdg_point<DIM, EXPR>(pa, F);
-      else navierstokes_point<DIM, EXPR>(pa, F);
+      else if constexpr (PHYS == MHA_PHYSICS_POROUS_MIXED) porous_point<DIM, (EXPR != 0)>(pa, F);
+      else if constexpr (PHYS == MHA_PHYSICS_SHALLOWWATER_HYBRIDIZED) swhdg_point<DIM, (EXPR != 0)>(pa, F);
+      else navierstokes_point<DIM, (EXPR != 0)>(pa, F);
 #pragma unroll
       for (int v = 0; v < L::nvars; ++v) {
         const int type = L::type(v), sp = slotptr_of<L, DIM>(v), ns = slots_of(type, DIM);
@@ -551,20 +551,30 @@ void launch_typed(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev
   const int nq1 = groups < 4 ? 0 : (vl.nq == (DIM == 2 ? 4 : 8)) ? 2 : (vl.nq == (DIM == 2 ? 9 : 27)) ? 3 : 0;
   auto pick = [&](auto tpe) {
     constexpr int T = decltype(tpe)::value;
-    if (nq1 == 2) go(point_engine_kernel<DIM, PHYS, T, 2, false>);
-    else if (nq1 == 3) go(point_engine_kernel<DIM, PHYS, T, 3, false>);
-    else go(point_engine_kernel<DIM, PHYS, T, 0, false>);
+    if (nq1 == 2) go(point_engine_kernel<DIM, PHYS, T, 2, 0>);
+    else if (nq1 == 3) go(point_engine_kernel<DIM, PHYS, T, 3, 0>);
+    else go(point_engine_kernel<DIM, PHYS, T, 0, 0>);
   };
-  if (pp.physics > 0 && has_expression(pp)) {
+  if (pp.physics > 0 && uses_fields(pp)) {
+    // deck strings that read the solution fields: the Dual interpreter; built for the thermal module
+    if constexpr (PHYS == MHA_PHYSICS_THERMAL) {
+      if (groups == 8) go(point_engine_kernel<DIM, PHYS, 64, 0, 2>);
+      else if (groups == 4) go(point_engine_kernel<DIM, PHYS, 128, 0, 2>);
+      else if (groups == 2) go(point_engine_kernel<DIM, PHYS, 256, 0, 2>);
+      else go(point_engine_kernel<DIM, PHYS, 512, 0, 2>);
+    } else {
+      MHA_REQUIRE(false, MHA_ERR_INVALID, "functions of the solution fields are built for the thermal module");
+    }
+  } else if (pp.physics > 0 && has_expression(pp)) {
     // deck-string functions: the interpreter call costs registers and scratch, so only these instantiations carry it
-    if (groups == 8) go(point_engine_kernel<DIM, PHYS, 64, 0, true>);
-    else if (groups == 4) go(point_engine_kernel<DIM, PHYS, 128, 0, true>);
-    else if (groups == 2) go(point_engine_kernel<DIM, PHYS, 256, 0, true>);
-    else go(point_engine_kernel<DIM, PHYS, 512, 0, true>);
+    if (groups == 8) go(point_engine_kernel<DIM, PHYS, 64, 0, 1>);
+    else if (groups == 4) go(point_engine_kernel<DIM, PHYS, 128, 0, 1>);
+    else if (groups == 2) go(point_engine_kernel<DIM, PHYS, 256, 0, 1>);
+    else go(point_engine_kernel<DIM, PHYS, 512, 0, 1>);
   } else if (groups == 8) pick(std::integral_constant<int, 64>());
   else if (groups == 4) pick(std::integral_constant<int, 128>());
-  else if (groups == 2) go(point_engine_kernel<DIM, PHYS, 256, 0, false>);
-  else go(point_engine_kernel<DIM, PHYS, 512, 0, false>);
+  else if (groups == 2) go(point_engine_kernel<DIM, PHYS, 256, 0, 0>);
+  else go(point_engine_kernel<DIM, PHYS, 512, 0, 0>);
 }
 
 }  // namespace

@@ -21,12 +21,22 @@ namespace mha {
 // or a member of a small closed family evaluated at the physical integration points.
 class FunctionManager {
  public:
-  void addFunction(const std::string &name, const FuncDesc &f) { funcs_[name] = f; programs_.erase(name); }
-  // a deck string: compiled to a postfix program kept on the device for the life of the function (expression.hpp)
+  void addFunction(const std::string &name, const FuncDesc &f) { funcs_[name] = f; programs_.erase(name); texts_.erase(name); dirty_ = true; }
+  // a deck string: compiled to a postfix program kept on the device for the life of the function (expression.hpp).
+  // Compilation is deferred to the first evaluate(): a string may name solution fields of the block (setFieldSlots)
+  // and functions of the deck that are defined later, as FunctionManager::decomposeFunctions allows
+  // (functionManager.cpp:95-540).
   void addExpression(const std::string &name, const std::string &text);
-  bool has(const std::string &name) const { return funcs_.count(name) != 0; }
+  // names of Workset::getSolutionField -> slot of the point engine's field array; `_t` names -> time-derivative slots
+  void setFieldSlots(const std::map<std::string, int> &fields, const std::map<std::string, int> &fields_t) {
+    field_slot_ = fields;
+    field_t_slot_ = fields_t;
+    dirty_ = true;
+  }
+  bool has(const std::string &name) const { return funcs_.count(name) != 0 || texts_.count(name) != 0; }
   void setTime(double t) { time_ = t; }
   FuncDesc evaluate(const std::string &name) const {
+    if (dirty_) compileAll();
     auto it = funcs_.find(name);
     // reference: TEUCHOS_TEST_FOR_EXCEPTION "function manager could not evaluate" (functionManager.cpp:573)
     MHA_REQUIRE(it != funcs_.end(), MHA_ERR_INVALID, "function manager could not evaluate: " << name);
@@ -37,8 +47,14 @@ class FunctionManager {
 
  private:
   struct Program { DeviceBuffer<int32_t> code; DeviceBuffer<double> consts; };
-  std::map<std::string, FuncDesc> funcs_;
-  std::map<std::string, std::shared_ptr<Program>> programs_;
+  void compileAll() const;
+  void compileOne(const std::string &name, std::vector<std::string> &open, std::vector<int32_t> &code, std::vector<double> &consts,
+                  bool &fields) const;
+  mutable std::map<std::string, FuncDesc> funcs_;
+  mutable std::map<std::string, std::shared_ptr<Program>> programs_;
+  std::map<std::string, std::string> texts_;
+  std::map<std::string, int> field_slot_, field_t_slot_;
+  mutable bool dirty_ = false;
   double time_ = 0.0;
 };
 
@@ -82,7 +98,8 @@ class thermal : public PhysicsBase {
   ThermalDev device_params() const;
   double formparam = 1.0;  // settings "form_param" (reference: thermal.cpp:35)
   bool have_advection = false;  // settings "include advection" (reference: thermal.cpp:39): adds (b . grad e, v)
-  bool pointEngineOnly() const override { return have_advection; }
+  // the advection term and coefficients that depend on the solution ("1+e*e") exist in the point-engine form only
+  bool pointEngineOnly() const override;
 };
 
 // porousMixed: mixed Darcy, (K mobility)^-1 u + grad p = 0, div u = source

@@ -1,3 +1,5 @@
+#include <algorithm>
+
 #include "physics.hpp"
 
 #include "expression.hpp"
@@ -7,19 +9,71 @@
 namespace mha {
 
 void FunctionManager::addExpression(const std::string &name, const std::string &text) {
+  // syntax errors surface here; identifiers the string may name later (fields, other functions) are accepted for now
   std::vector<int32_t> code;
   std::vector<double> consts;
-  compile_expression(text, code, consts);
-  auto prog = std::make_shared<Program>();
-  prog->code.upload(code);
-  if (consts.empty()) consts.push_back(0.0);
-  prog->consts.upload(consts);
-  FuncDesc f;
-  f.kind = MHA_FUNC_EXPRESSION;
-  f.code = prog->code.data();
-  f.consts = prog->consts.data();
-  funcs_[name] = f;
-  programs_[name] = prog;
+  compile_expression(text, code, consts, [](const std::string &, std::vector<int32_t> &c, std::vector<double> &) {
+    c.push_back(EXPR_PI);  // placeholder operand
+    return true;
+  });
+  texts_[name] = text;
+  funcs_.erase(name);
+  programs_.erase(name);
+  dirty_ = true;
+}
+
+// one named expression -> program; `open` = the chain of functions being resolved (cycle detection)
+void FunctionManager::compileOne(const std::string &name, std::vector<std::string> &open, std::vector<int32_t> &code,
+                                 std::vector<double> &consts, bool &fields) const {
+  MHA_REQUIRE(std::find(open.begin(), open.end(), name) == open.end(), MHA_ERR_INVALID,
+              "function '" << name << "' refers to itself (through " << open.size() << " other functions)");
+  open.push_back(name);
+  ExprResolver resolver = [&](const std::string &id, std::vector<int32_t> &c, std::vector<double> &k) {
+    auto fs = field_slot_.find(id);
+    if (fs != field_slot_.end()) { c = {EXPR_FIELD, fs->second, EXPR_END}; return true; }
+    auto ft = field_t_slot_.find(id);
+    if (ft != field_t_slot_.end()) { c = {EXPR_FIELD_T, ft->second, EXPR_END}; return true; }
+    auto tx = texts_.find(id);
+    if (tx != texts_.end()) {  // another deck string: inlined
+      bool f2 = false;
+      compileOne(id, open, c, k, f2);
+      fields = fields || f2;
+      return true;
+    }
+    auto fn = funcs_.find(id);
+    if (fn != funcs_.end() && fn->second.kind == MHA_FUNC_CONSTANT) {  // a constant function: its value
+      c = {EXPR_CONST, 0, EXPR_END};
+      k = {fn->second.amp};
+      return true;
+    }
+    return false;
+  };
+  bool f1 = false;
+  compile_expression(texts_.at(name), code, consts, resolver, &f1);
+  fields = fields || f1;
+  open.pop_back();
+}
+
+void FunctionManager::compileAll() const {
+  for (const auto &kv : texts_) {
+    std::vector<int32_t> code;
+    std::vector<double> consts;
+    std::vector<std::string> open;
+    bool fields = false;
+    compileOne(kv.first, open, code, consts, fields);
+    auto prog = std::make_shared<Program>();
+    prog->code.upload(code);
+    if (consts.empty()) consts.push_back(0.0);
+    prog->consts.upload(consts);
+    FuncDesc f;
+    f.kind = MHA_FUNC_EXPRESSION;
+    f.code = prog->code.data();
+    f.consts = prog->consts.data();
+    f.uses_fields = fields ? 1 : 0;
+    funcs_[kv.first] = f;
+    programs_[kv.first] = prog;
+  }
+  dirty_ = false;
 }
 
 thermal::thermal() {
@@ -45,6 +99,14 @@ void thermal::setParameter(const std::string &name, double value) {
   if (name == "form_param") formparam = value;  // reference: thermal.cpp:35
   else if (name == "include advection") have_advection = value != 0.0;  // reference: thermal.cpp:39
   else PhysicsBase::setParameter(name, value);
+}
+
+bool thermal::pointEngineOnly() const {
+  if (have_advection) return true;
+  if (!functionManager) return false;
+  for (const char *k : {"thermal source", "thermal diffusion", "specific heat", "density"})
+    if (functionManager->has(k) && functionManager->evaluate(k).uses_fields) return true;
+  return false;
 }
 
 ThermalDev thermal::device_params() const {

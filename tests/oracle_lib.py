@@ -857,3 +857,158 @@ def subgrid_nonlinear_solver(m, qdeg, u, lam, side_types, farfield, max_iter, to
             iters[e] += 1
             inloop[e] = scaled[e] > tol
     return u, iters, scaled
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FunctionManager<AD>::evaluate over (elem, pt) views with Sacado-style derivative arrays (reference:
+# src/managers/functionManager.cpp:95-540 decomposeFunctions, :543-860 evaluate op by op; src/tools/vista.hpp:22-132),
+# restated with numpy: deck strings that read solution fields ("1+e*e") and other named functions of the deck.
+# Test infrastructure (the checker), small cases only.
+# ---------------------------------------------------------------------------------------------------------------------
+
+class ADView:
+    """A View<AD**>(elem, pt): val [E][q], dx [E][q][W] (W = dofs per element, the seeded slots)."""
+
+    def __init__(self, val, dx=None, W=0):
+        self.val = np.asarray(val, dtype=np.float64)
+        self.dx = np.zeros(self.val.shape + (W,)) if dx is None else dx
+
+    @staticmethod
+    def _lift(o, like):
+        return o if isinstance(o, ADView) else ADView(np.broadcast_to(np.float64(o), like.val.shape).copy(), W=like.dx.shape[-1])
+
+    def __add__(s, o):
+        o = ADView._lift(o, s)
+        return ADView(s.val + o.val, s.dx + o.dx)
+    __radd__ = __add__
+
+    def __sub__(s, o):
+        o = ADView._lift(o, s)
+        return ADView(s.val - o.val, s.dx - o.dx)
+
+    def __rsub__(s, o):
+        return ADView._lift(o, s) - s
+
+    def __neg__(s):
+        return ADView(-s.val, -s.dx)
+
+    def __mul__(s, o):
+        o = ADView._lift(o, s)
+        return ADView(s.val * o.val, s.dx * o.val[..., None] + o.dx * s.val[..., None])
+    __rmul__ = __mul__
+
+    def __truediv__(s, o):
+        o = ADView._lift(o, s)
+        q = s.val / o.val
+        return ADView(q, (s.dx - o.dx * q[..., None]) / o.val[..., None])
+
+    def __rtruediv__(s, o):
+        return ADView._lift(o, s) / s
+
+    def __pow__(s, o):
+        o = ADView._lift(o, s)
+        p = s.val ** o.val
+        dx = (o.val * s.val ** (o.val - 1.0))[..., None] * s.dx
+        if np.any(o.dx != 0.0):
+            dx = dx + (p * np.log(s.val))[..., None] * o.dx
+        return ADView(p, dx)
+
+    def __rpow__(s, o):
+        return ADView._lift(o, s) ** s
+
+    def _cmp(s, o, op):
+        o = ADView._lift(o, s)
+        return ADView(op(s.val, o.val).astype(np.float64), W=s.dx.shape[-1])
+
+    def __lt__(s, o): return s._cmp(o, np.less)
+    def __gt__(s, o): return s._cmp(o, np.greater)
+    def __le__(s, o): return s._cmp(o, np.less_equal)
+    def __ge__(s, o): return s._cmp(o, np.greater_equal)
+
+
+def _ad_unary(f, df):
+    def g(a):
+        if not isinstance(a, ADView):
+            return f(a)
+        return ADView(f(a.val), df(a.val)[..., None] * a.dx)
+    return g
+
+
+_AD_FUNCS = dict(sin=_ad_unary(np.sin, np.cos), cos=_ad_unary(np.cos, lambda v: -np.sin(v)),
+                 tan=_ad_unary(np.tan, lambda v: 1.0 + np.tan(v) ** 2), exp=_ad_unary(np.exp, np.exp),
+                 log=_ad_unary(np.log, lambda v: 1.0 / v), sqrt=_ad_unary(np.sqrt, lambda v: 0.5 / np.sqrt(v)),
+                 sinh=_ad_unary(np.sinh, np.cosh), cosh=_ad_unary(np.cosh, np.sinh),
+                 abs=_ad_unary(np.abs, np.sign))
+
+
+def deck_eval_ad(text, fields, functions=None, _open=()):
+    """Evaluate a deck string op by op on AD views.  fields: name ('e', 'grad(e)[x]', 'x', 't', ...) -> ADView or
+    array; functions: the deck's other named strings (resolved into sub-trees as decomposeFunctions does)."""
+    import re
+    functions = functions or {}
+    env = dict(_AD_FUNCS)
+    env["pi"] = np.pi
+    expr = text.replace("^", "**")
+    names = sorted(set(list(fields) + list(functions)), key=len, reverse=True)
+    for k, nm in enumerate(names):  # longest first: 'grad(e)[x]' before 'e'
+        tag = "_v%d_" % k
+        pat = re.escape(nm) if not nm.isidentifier() else r"(?<![A-Za-z0-9_])" + re.escape(nm) + r"(?![A-Za-z0-9_(\[])"
+        if not re.search(pat, expr):
+            continue
+        if nm in fields:
+            env[tag] = fields[nm]
+        else:
+            assert nm not in _open, "function '%s' refers to itself" % nm
+            env[tag] = deck_eval_ad(functions[nm], fields, functions, _open + (nm,))
+        expr = re.sub(pat, tag, expr)
+    return eval(expr, {"__builtins__": {}}, env)
+
+
+def assemble_thermal_fields(dim, order, qdeg, nodes, lids, offsets, u, funcs, *, fixed=None, rowptr=None, colind=None,
+                            functions=None):
+    """thermal::volumeResidual (src/physics/thermal.cpp:71-165, steady) with its functions given as deck strings that may
+    read the solution fields, AD arrays of width n seeded at off(j) (workset.cpp:823-859), then the scatter of
+    assemblyManager.cpp:4031-4145 (-res.val(), +res.dx(col), fixed rows skipped).  funcs: 'thermal source',
+    'thermal diffusion' -> string or number."""
+    lids = np.ascontiguousarray(lids, dtype=np.int32)
+    E, n = lids.shape
+    pb = physical_basis(dim, order, qdeg, nodes)
+    B, G, w, ip = pb["basis"], pb["basis_grad"], pb["wts"], pb["ip"]      # [E][n][q], [E][n][q][d], [E][q], [E][q][d]
+    off = np.asarray(offsets)
+    ue = u[lids[:, off]]                                                    # value of basis function j: LID position off[j]
+    nq = w.shape[1]
+    fields = {}
+    val = np.einsum("ej,ejq->eq", ue, B)
+    dx = np.zeros((E, nq, n))
+    dx[:, :, off] = np.transpose(B, (0, 2, 1))                              # d e / d u_(slot off[j]) = N_j
+    fields["e"] = ADView(val, dx)
+    for d, c in enumerate("xyz"[:dim]):
+        gd = np.zeros((E, nq, n))
+        gd[:, :, off] = np.transpose(G[..., d], (0, 2, 1))
+        fields["grad(e)[%s]" % c] = ADView(np.einsum("ej,ejq->eq", ue, G[..., d]), gd)
+        fields[c] = ADView(ip[..., d], W=n)
+    fields["t"] = ADView(np.zeros((E, nq)), W=n)
+
+    def fn(name, default):
+        v = funcs.get(name, default)
+        r = deck_eval_ad(v, fields, functions) if isinstance(v, str) else v
+        return ADView._lift(r, fields["e"])
+    src, kap = fn("thermal source", 0.0), fn("thermal diffusion", 1.0)
+    if rowptr is None:
+        rowptr, colind = build_graph(len(u), lids)
+    vals, res = np.zeros(rowptr[-1]), np.zeros(len(u))
+    for j in range(n):  # residual row of basis function j: res(e, off[j])
+        r = ADView(np.zeros((E, nq)), W=n)
+        r = r - src * B[:, j, :] * w
+        for d, c in enumerate("xyz"[:dim]):
+            r = r + kap * fields["grad(e)[%s]" % c] * (G[:, j, :, d] * w)
+        rv, rdx = r.val.sum(axis=1), r.dx.sum(axis=1)                       # [E], [E][n] (slot order)
+        rows = lids[:, off[j]]
+        for e in range(E):
+            row = rows[e]
+            if fixed is not None and fixed[row]:
+                continue
+            res[row] -= rv[e]
+            lo, hi = rowptr[row], rowptr[row + 1]
+            vals[lo + np.searchsorted(colind[lo:hi], lids[e])] += rdx[e]
+    return dict(rowptr=rowptr, colind=colind, crs_vals=vals, res=res)

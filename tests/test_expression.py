@@ -74,3 +74,34 @@ def test_unsupported_strings_are_rejected(oracle, s):
     if s not in ("x**2",):
         with pytest.raises(ValueError):
             oracle.eval_expression(s, [0.1, 0.2, 0.3])
+
+
+def test_field_dependent_deck_strings_restatement(oracle):
+    """The numpy restatement of FunctionManager<AD>::evaluate (oracle_lib.deck_eval_ad / assemble_thermal_fields) pinned on
+    the CPU: with constant strings it reproduces the C oracle's thermal assembly (itself pinned by the reference's golds);
+    with 'thermal diffusion' = "1+e*e" the Jacobian is the central difference of the residual, and a named function
+    referenced from another string ("kappa0 + e*e") gives the same result as the inlined string."""
+    dim, order, qdeg = 2, 2, 4
+    m = oracle.mesh_structured(dim, order, (3, 2))
+    rng = np.random.default_rng(12)
+    nodes = m["nodes"] + 0.03 * rng.uniform(-1, 1, m["nodes"].shape)
+    u = rng.uniform(-1, 1, m["ndof"])
+    ref = oracle.assemble_thermal(dim, order, qdeg, nodes, m["lids"], m["offsets"], u, diff=1.3, source=("const", 0.7))
+    got = oracle.assemble_thermal_fields(dim, order, qdeg, nodes, m["lids"], m["offsets"], u,
+                                         {"thermal source": "0.7", "thermal diffusion": "1.3"}, rowptr=ref["rowptr"], colind=ref["colind"])
+    assert np.abs(got["crs_vals"] - ref["crs_vals"]).max() < 1e-13 * np.abs(ref["crs_vals"]).max()
+    assert np.abs(got["res"] - ref["res"]).max() < 1e-13 * np.abs(ref["res"]).max()
+    funcs = {"thermal source": "2*sin(pi*x)*y + 0.1*e", "thermal diffusion": "1+e*e + 0.2*grad(e)[x]^2"}
+    out = oracle.assemble_thermal_fields(dim, order, qdeg, nodes, m["lids"], m["offsets"], u, funcs, rowptr=ref["rowptr"], colind=ref["colind"])
+    v = rng.uniform(-1, 1, m["ndof"])
+    eps = 1e-6
+    rp = oracle.assemble_thermal_fields(dim, order, qdeg, nodes, m["lids"], m["offsets"], u + eps * v, funcs, rowptr=ref["rowptr"], colind=ref["colind"])["res"]
+    rm = oracle.assemble_thermal_fields(dim, order, qdeg, nodes, m["lids"], m["offsets"], u - eps * v, funcs, rowptr=ref["rowptr"], colind=ref["colind"])["res"]
+    import scipy.sparse as sp
+    J = sp.csr_matrix((out["crs_vals"], out["colind"], out["rowptr"]), shape=(m["ndof"],) * 2)
+    fd = -(rp - rm) / (2 * eps)  # the vector holds -res.val()
+    assert np.abs(J @ v - fd).max() < 1e-7 * np.abs(fd).max()
+    named = oracle.assemble_thermal_fields(dim, order, qdeg, nodes, m["lids"], m["offsets"], u,
+                                           {"thermal source": funcs["thermal source"], "thermal diffusion": "kappa0 + 0.2*grad(e)[x]^2"},
+                                           rowptr=ref["rowptr"], colind=ref["colind"], functions={"kappa0": "1+e*e"})
+    assert np.abs(named["crs_vals"] - out["crs_vals"]).max() < 1e-14 * np.abs(out["crs_vals"]).max()

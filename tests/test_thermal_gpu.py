@@ -689,9 +689,57 @@ def test_deck_strings_through_the_device_interpreter(oracle):
         b2.assemble_jacres(torch.tensor(uu, device="cuda"), r2, v2, overwrite=True, path=path)
         torch.cuda.synchronize()
         assert rel_err(v2.cpu().numpy(), ref["crs_vals"]) < RTOL and rel_err(r2.cpu().numpy(), ref["res"]) < RTOL
+    # an identifier nothing defines (not a coordinate, a solution field of the block or a function of the deck) is refused
+    # when the functions are next evaluated -- the strings may name functions that are defined later
+    b2.set_function("thermal source", "2*e + grud")
     with pytest.raises(mrhyde_amd.MhaError) as e:
-        b2.set_function("thermal source", "2*e + grad(e)[x]")  # solution fields are not available to expressions
-    assert e.value.code == 1
+        b2.assemble_jacres(torch.tensor(uu, device="cuda"), r2, v2, overwrite=True)
+    assert e.value.code == 1 and "grud" in str(e.value)
+
+
+@pytest.mark.parametrize("dim,order,ncell", [(2, 2, (4, 3)), (3, 1, (3, 3, 2)), (3, 2, (2, 2, 2))])
+def test_nonlinear_diffusion_deck_string(oracle, dim, order, ncell):
+    """Deck strings that read the solution fields: 'thermal diffusion' = "1+e*e" (a nonlinear diffusion), a source that
+    depends on e and on grad(e), and a function that names another function of the deck.  The reference evaluates them
+    with FunctionManager<AD> (functionManager.cpp:95-860), so res.dx picks up d kappa / d e; here the point engine
+    interprets the program on Dual numbers.  Residual and Jacobian against the numpy restatement
+    (oracle_lib.assemble_thermal_fields) to 1e-12, per entry relative to the row's largest entry."""
+    torch = _torch()
+    import mrhyde_amd
+    qdeg = 2 * order
+    m = oracle.mesh_structured(dim, order, ncell)
+    rng = np.random.default_rng(71)
+    v = m["verts"].copy()
+    inner = np.all((v > 1e-12) & (v < 1 - 1e-12), axis=1)
+    v[inner] += 0.04 * rng.uniform(-1, 1, (int(inner.sum()), dim))
+    m["verts"], m["nodes"] = v, np.ascontiguousarray(v[m["cell2vert"]])
+    u = rng.uniform(-1, 1, m["ndof"])
+    fixed = m["boundary"]
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    funcs = {"thermal source": "2*sin(pi*x)*y + 0.1*e", "thermal diffusion": "kappa0 + 0.2*grad(e)[x]^2"}
+    ref = oracle.assemble_thermal_fields(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, funcs, fixed=fixed,
+                                         rowptr=rowptr, colind=colind, functions={"kappa0": "1+e*e"})
+    blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(rowptr, colind))
+    blk.set_function("thermal diffusion", funcs["thermal diffusion"])   # names kappa0 before it is defined
+    blk.set_function("kappa0", "1+e*e")
+    blk.set_function("thermal source", funcs["thermal source"])
+    ud = torch.tensor(u, device="cuda")
+    for path in (mrhyde_amd.PATH_AUTO, mrhyde_amd.PATH_POINT_ENGINE):
+        res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+        vals = torch.zeros(len(colind), dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(ud, res, vals, overwrite=(path == mrhyde_amd.PATH_AUTO), path=path)
+        torch.cuda.synchronize()
+        assert blk.info("last_path") in (mrhyde_amd.PATH_ROW_GATHER, mrhyde_amd.PATH_POINT_ENGINE)
+        gv, gr = vals.cpu().numpy(), res.cpu().numpy()
+        assert rel_err(gr, ref["res"]) < RTOL
+        rows = np.repeat(np.arange(m["ndof"]), np.diff(rowptr))
+        rowmax = np.zeros(m["ndof"])
+        np.maximum.at(rowmax, rows, np.abs(ref["crs_vals"]))
+        tol = RTOL * np.maximum(np.abs(ref["crs_vals"]), 1e-3 * rowmax[rows]) + 1e-300
+        assert np.all(np.abs(gv - ref["crs_vals"]) <= tol), float((np.abs(gv - ref["crs_vals"]) / tol).max())
+    # the row-owner kernels assume coefficients that do not depend on the solution: refused, not silently wrong
+    with pytest.raises(mrhyde_amd.MhaError):
+        blk.assemble_jacres(ud, res, vals, path=mrhyde_amd.PATH_ROW_OWNER)
 
 
 def test_mixed_bcs_deck_strings(oracle):
