@@ -201,9 +201,9 @@ __device__ __forceinline__ Dual eval_expression_dual(const FuncDesc &f, const do
 }
 
 // Value of a named function at integration point (e,q) with physical coordinates x (nrm: unit normal on sides).
-// EXPR: whether MHA_FUNC_EXPRESSION can occur.  The interpreter is a real call with a private stack; a kernel that
-// merely contains the call pays its register budget and scratch (the affine element kernel went from 8 to 2 waves per
-// SIMD), so kernels are instantiated both ways and the launcher picks by has_expression().
+// EXPR: whether MHA_FUNC_EXPRESSION can occur.  The interpreter is inlined (a private 96-byte stack per evaluation); a
+// kernel that merely contains it pays its register budget and scratch (the affine element kernel went from 8 to 2 waves
+// per SIMD), so kernels are instantiated both ways and the launcher picks by has_expression().
 template <int DIM, bool EXPR = false, bool SMALL_ARGS = false>
 __device__ __forceinline__ double eval_func(const FuncDesc &f, int e, int q, int nq, const double *x,
                                             const double *nrm = nullptr, double h = 0.0) {

@@ -184,6 +184,12 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
   const bool mass_mode = pp.physics < 0;  // launch_point_engine_mass: p[v] = mass weight of variable v
   const int dbg_stop = mass_mode ? 0 : (int)pp.p[7];  // profiling aid (MHA_ENGINE_STOP): leave the element after phase k
   for (int k = tid; k < vl.tables_size; k += kEngineThreads) tab[k] = vl.tables[k];
+  if (dbg_stop & 64) {
+    // diagnostic (MHA_ENGINE_STOP=64): every per-element LDS array starts as NaN, so a value that is read before the
+    // element loop has written it shows in the results (the hunt for the deck-string garbage of round 2: none found)
+    const int total = NG * (int)engine_group_doubles(vl, GEO);
+    for (int k = tid; k < total; k += kEngineThreads) tab[vl.tables_size + k] = __builtin_nan("");
+  }
   __syncthreads();
 
   // blocked element ranges per group: groups running at the same time work far apart in the mesh
