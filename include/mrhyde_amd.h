@@ -237,6 +237,48 @@ int mha_apply_dbc_diag(mha_context *ctx, double *crs_vals_dev);
 /* replaces: performGather  assemblyManager.cpp:3598-3643: out[E][n] (dof order = basis order) */
 int mha_gather(mha_context *ctx, const double *vec_dev, double *elem_vals_dev);
 
+/* ---- the nonlinear-solve protocol around the assembler --------------------------------------------------------------
+ * replaces: the loop of SolverManager::nonlinearSolver (src/managers/solverManager.cpp:1465-1709) around assembleRes /
+ * assembleJacRes, and the strong-Dirichlet lifting of SolverManager::setDirichlet (:1876-1957).  The linear solver, the
+ * Export / Import between ranks and the all-reduce of the norm stay with the caller (out of scope: SURVEY.md section 2);
+ * the driver is a state machine stepped with plain calls, no callbacks:
+ *   mha_newton_residual : zero res_dev; assembleRes (AUTOTUNE: the residual-only ScalarT path first, :1538-1552) incl. the
+ *                         boundary groups -> res_dev = -res.val()                    [caller: Export(ADD) of res_dev]
+ *   mha_newton_norm     : |res_dev|_inf of this rank's rows (:1571)                  [caller: all-reduce max]
+ *   mha_newton_decide   : iteration 0 fixes resnorm_first; resnorm_scaled = resnorm / resnorm_first (:1575-1581);
+ *                         backtracking when allowed and the scaled norm exceeds 1.1: alpha halved, u -= alpha du (the last
+ *                         update), no solve (:1591-1616); relative tolerance (scaled < nl_tol, or resnorm < 1e-100) or
+ *                         absolute tolerance ends the loop (:1617-1632); *action = MHA_NEWTON_SOLVE / _BACKTRACKED / _DONE
+ *   mha_newton_jacobian : only when a solve is needed (:1638-1641): zero res_dev, assembleJacRes (+ boundary groups) with
+ *                         the CRS values overwritten, unit diagonal on the fixed rows  [caller: Export(ADD) of the matrix,
+ *                         solve J du = res, Import du]
+ *   mha_newton_update   : u += alpha du with alpha = 1 (:1656-1672); closes the iteration (NLiter++, :1681-1685)
+ *   mha_newton_step     : residual + norm + decide (+ jacobian) in one call for a single-rank caller.
+ * autotune = 0: assembleJacRes at once, as the reference does for adjoint / multiscale runs (:1540-1547).
+ * mha_newton_state: iteration count, norms, alpha, status (1: the iteration limit was reached without convergence).
+ * mha_dirichlet_lift: u[row] = fixed_soln_dev[row] (or scalar_value when fixed_soln_dev is NULL) on the rows the mesh
+ * marks fixed -- the lifted solution carries the strong boundary condition (:1905-1935).                              */
+#define MHA_NEWTON_SOLVE 1
+#define MHA_NEWTON_BACKTRACKED 2
+#define MHA_NEWTON_DONE 3
+typedef struct mha_newton mha_newton;
+int mha_newton_create(mha_context *ctx, int max_iter, double nl_tol, double nl_abs_tol, int use_relative, int use_absolute,
+                      int allow_backtracking, int autotune, mha_newton **out);
+void mha_newton_destroy(mha_newton *nw);
+int mha_newton_reset(mha_newton *nw);
+int mha_newton_residual(mha_newton *nw, const double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
+                        double *res_dev);
+int mha_newton_norm(mha_newton *nw, const double *res_dev, double *resnorm);
+int mha_newton_decide(mha_newton *nw, double resnorm, double *u_dev, int *action);
+int mha_newton_jacobian(mha_newton *nw, const double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
+                        double *res_dev, double *crs_vals_dev);
+int mha_newton_update(mha_newton *nw, double *u_dev, const double *du_dev);
+int mha_newton_step(mha_newton *nw, double *u_dev, const double *u_prev_dev, const double *u_stage_dev, double *res_dev,
+                    double *crs_vals_dev, int *action);
+int mha_newton_state(const mha_newton *nw, int *iteration, double *resnorm, double *resnorm_scaled, double *resnorm_first,
+                     double *alpha, int *status);
+int mha_dirichlet_lift(mha_context *ctx, double *u_dev, const double *fixed_soln_dev, double scalar_value);
+
 /* ---- workset views -----------------------------------------------------------
  * replaces: updateWorkset aliasing the group's stored views (assemblyManager.cpp:6512-6596)
  * and Group::computeBasis -> getPhysicalVolumetricBasis / getPhysicalIntegrationData
@@ -299,6 +341,7 @@ int mha_workset_compute_residual(mha_context *ctx, int compute_jacobian, const d
 #define MHA_BC_NEUMANN 1
 #define MHA_BC_WEAK_DIRICHLET 2
 #define MHA_BC_FLUX 3
+#define MHA_BC_INTERFACE 5 /* thermal: the weak-Dirichlet branch with the trace, the function "aux e <sidename>", as data (thermal.cpp:227-243) */
 #define MHA_BC_DIRICHLET 4 /* strong condition (mha_add_dirichlet_group): nothing in mha_assemble_boundary, see mha_set_dirichlet */
 /* shallowwaterHybridized side types (bcs(H_num, side): "interface", "Far-field", "Slip",
  * shallowwaterHybridized.cpp:286-300, 612-620): the group's entries are element sides (all four sides of every
@@ -351,6 +394,19 @@ int mha_set_dirichlet(mha_context *ctx, int lump_mass, double *rhs_dev, double *
 int mha_num_boundary_groups(mha_context *ctx);
 int mha_assemble_boundary(mha_context *ctx, int flags, const double *u_dev, const double *u_prev_dev,
                           const double *u_stage_dev, double *res_dev, double *crs_vals_dev);
+/* computeFlux of the block's module on one boundary group: the workset's flux view (elem, auxvar, pt).
+ * replaces: AssemblyManager::computeFlux -> PhysicsInterface::computeFlux -> <module>::computeFlux
+ *   (src/managers/assemblyManager.hpp:573-727; called by SubGridDtN_Solver::updateFlux, subgridDtN_solver.cpp:1579)
+ *   thermal (src/physics/thermal.cpp:288-347):       flux = (10 / h) kappa (lambda - T) + kappa grad T . n, lambda = the
+ *                                                    function "aux e <sidename>" at the side points, h = side element size
+ *   porousMixed (src/physics/porousMixed.cpp:440-500): flux = u . n (HDIV side basis, Piola, orientation sign)
+ *   navierstokes (src/physics/navierstokes.cpp:1016-1018): empty in the reference: zeros
+ *   shallowwaterHybridized: mha_swhdg_side_terms / mha_swhdg_element_blocks (trace rows).
+ * flux_dev[num][nqs]; optional derivative arrays (what the AD type of the reference's view carries):
+ * dflux_du_dev[num][nqs][n] with respect to the element's unknowns in flattened (variable, dof) order (time-integration
+ * factor alpha_u included), dflux_daux_dev[num][nqs] with respect to the aux value at the point.                     */
+int mha_compute_flux(mha_context *ctx, int group_id, const double *u_dev, const double *u_prev_dev, const double *u_stage_dev,
+                     double *flux_dev, double *dflux_du_dev, double *dflux_daux_dev);
 int mha_boundary_update(mha_context *ctx, int group_id);
 int mha_boundary_view(mha_context *ctx, int group_id, const char *name, void **dev_ptr, int64_t extents[4],
                       int *rank);

@@ -19,7 +19,7 @@ EXPORTS = [
     "mha_set_mesh", "mha_set_graph", "mha_get_graph_sizes", "mha_get_graph", "mha_physics_select",
     "mha_set_function", "mha_set_time_integration", "mha_assemble_jacres", "mha_compute_local_jacres",
     "mha_scatter_local", "mha_apply_dbc_diag", "mha_gather", "mha_num_worksets", "mha_workset_update",
-    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_mesh_multi_sizes", "mha_mesh_structured_multi", "mha_swhdg_condensed_element", "mha_export_plan_create", "mha_export_plan_destroy", "mha_export_pack", "mha_export_unpack_add", "mha_export_buffers", "mha_export_bytes_on_wire", "mha_comm_unique_id", "mha_comm_create", "mha_comm_destroy", "mha_export_add", "mha_get_info", "mha_set_timing",
+    "mha_workset_view", "mha_mesh_sizes", "mha_mesh_structured", "mha_mesh_multi_sizes", "mha_mesh_structured_multi", "mha_swhdg_condensed_element", "mha_compute_flux", "mha_newton_create", "mha_newton_destroy", "mha_newton_reset", "mha_newton_residual", "mha_newton_norm", "mha_newton_decide", "mha_newton_jacobian", "mha_newton_update", "mha_newton_step", "mha_newton_state", "mha_dirichlet_lift", "mha_export_plan_create", "mha_export_plan_destroy", "mha_export_pack", "mha_export_unpack_add", "mha_export_buffers", "mha_export_bytes_on_wire", "mha_comm_unique_id", "mha_comm_create", "mha_comm_destroy", "mha_export_add", "mha_get_info", "mha_set_timing",
     "mha_get_last_kernel_ms", "mha_row_partition_build", "mha_row_partition_sizes", "mha_row_partition_get",
     "mha_row_partition_destroy", "mha_scatter_plan_create", "mha_scatter_plan_nnz",
     "mha_scatter_plan_graph", "mha_scatter_plan_apply", "mha_scatter_plan_destroy", "mha_add_boundary_group", "mha_clear_boundary_groups", "mha_num_boundary_groups",
@@ -37,6 +37,7 @@ PHYSICS_IDS = {"thermal": 1, "porousMixed": 2, "navierstokes": 3, "shallowwaterH
 PATH_POINT_ENGINE = 4
 PATH_ROW_GATHER = 5
 BC_NEUMANN, BC_WEAK_DIRICHLET, BC_FLUX = 1, 2, 3
+BC_INTERFACE = 5  # thermal: weak-Dirichlet terms with the trace "aux e <side>" as data
 BC_SWH_INTERFACE, BC_SWH_FARFIELD, BC_SWH_SLIP = 10, 11, 12
 
 
@@ -180,6 +181,81 @@ def batched_condense(n_int, n_trace, blocks, res, want_du=True):
     _check(load_library().mha_batched_condense(n_int, n_trace, E, _ptr(blocks), _ptr(res), _ptr(schur), _ptr(gvec), _ptr(du),
                                                C.byref(ns), None))
     return schur, gvec, du, ns.value
+
+
+NEWTON_SOLVE, NEWTON_BACKTRACKED, NEWTON_DONE = 1, 2, 3
+
+
+class Newton:
+    """The nonlinear-solve protocol of SolverManager::nonlinearSolver behind the C ABI (mha_newton_*): the caller supplies
+    the linear solve between step() and update()."""
+
+    def __init__(self, blk, max_iter=10, nl_tol=1e-6, nl_abs_tol=1e-6, use_relative=True, use_absolute=False,
+                 allow_backtracking=False, autotune=True):
+        lib = load_library()
+        self._blk, self._h = blk, C.c_void_p()
+        lib.mha_newton_create.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _check(lib.mha_newton_create(blk._h, int(max_iter), float(nl_tol), float(nl_abs_tol), int(use_relative), int(use_absolute),
+                                     int(allow_backtracking), int(autotune), C.byref(self._h)))
+
+    def step(self, u, res, vals, u_prev=None, u_stage=None):
+        lib = load_library()
+        a = C.c_int()
+        lib.mha_newton_step.argtypes = [C.c_void_p] * 7
+        _check(lib.mha_newton_step(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(res), _ptr(vals), C.byref(a)))
+        return a.value
+
+    def residual(self, u, res, u_prev=None, u_stage=None):
+        lib = load_library()
+        lib.mha_newton_residual.argtypes = [C.c_void_p] * 5
+        _check(lib.mha_newton_residual(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(res)))
+
+    def norm(self, res):
+        lib = load_library()
+        v = C.c_double()
+        lib.mha_newton_norm.argtypes = [C.c_void_p] * 3
+        _check(lib.mha_newton_norm(self._h, _ptr(res), C.byref(v)))
+        return v.value
+
+    def decide(self, resnorm, u):
+        lib = load_library()
+        a = C.c_int()
+        lib.mha_newton_decide.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        _check(lib.mha_newton_decide(self._h, float(resnorm), _ptr(u), C.byref(a)))
+        return a.value
+
+    def jacobian(self, u, res, vals, u_prev=None, u_stage=None):
+        lib = load_library()
+        lib.mha_newton_jacobian.argtypes = [C.c_void_p] * 6
+        _check(lib.mha_newton_jacobian(self._h, _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(res), _ptr(vals)))
+
+    def update(self, u, du):
+        lib = load_library()
+        lib.mha_newton_update.argtypes = [C.c_void_p] * 3
+        _check(lib.mha_newton_update(self._h, _ptr(u), _ptr(du)))
+
+    def state(self):
+        lib = load_library()
+        it, st = C.c_int(), C.c_int()
+        rn, rs, rf, al = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        lib.mha_newton_state.argtypes = [C.c_void_p] * 7
+        _check(lib.mha_newton_state(self._h, C.byref(it), C.byref(rn), C.byref(rs), C.byref(rf), C.byref(al), C.byref(st)))
+        return dict(iteration=it.value, resnorm=rn.value, resnorm_scaled=rs.value, resnorm_first=rf.value, alpha=al.value,
+                    status=st.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib = load_library()
+            lib.mha_newton_destroy.argtypes = [C.c_void_p]
+            lib.mha_newton_destroy.restype = None
+            lib.mha_newton_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ScatterPlan:
@@ -547,6 +623,12 @@ class Block:
     def scatter_local(self, local_J, local_res, res, crs_vals):
         _check(load_library().mha_scatter_local(self._h, _ptr(local_J), _ptr(local_res), _ptr(res), _ptr(crs_vals)))
 
+    def dirichlet_lift(self, u, fixed_soln=None, scalar=0.0):
+        """u[row] = fixed_soln[row] (or scalar) on the fixed rows (SolverManager::setDirichlet)."""
+        lib = load_library()
+        lib.mha_dirichlet_lift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        _check(lib.mha_dirichlet_lift(self._h, _ptr(u), _ptr(fixed_soln), float(scalar)))
+
     def apply_dbc_diag(self, crs_vals):
         _check(load_library().mha_apply_dbc_diag(self._h, _ptr(crs_vals)))
 
@@ -561,6 +643,13 @@ class Block:
                                                      e.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p),
                                                      C.byref(gid)))
         return gid.value
+
+    def compute_flux(self, group_id, u, flux, dflux_du=None, dflux_daux=None, u_prev=None, u_stage=None):
+        """<module>::computeFlux on one boundary group (mha_compute_flux): flux [num][nqs] (+ derivative arrays)."""
+        lib = load_library()
+        lib.mha_compute_flux.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        _check(lib.mha_compute_flux(self._h, int(group_id), _ptr(u), _ptr(u_prev), _ptr(u_stage), _ptr(flux), _ptr(dflux_du),
+                                    _ptr(dflux_daux)))
 
     def add_flux_group(self, sidename, varname, elem_ids, side_ids):
         """The "Flux" condition of PhysicsInterface::fluxConditions for one variable; data = function "Flux <var> <side>"."""

@@ -891,6 +891,13 @@ void AssemblyManager::scatterLocal(const double *local_J, const double *local_re
   timedEnd();
 }
 
+void AssemblyManager::dirichletLift(double *u, const double *vals, double scalar) {
+  MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
+  MHA_REQUIRE(u != nullptr, MHA_ERR_INVALID, "solution vector is null");
+  if (!has_fixed_) return;
+  launch_dirichlet_lift(nrows_, d_fixed_.data(), vals, scalar, u, stream_);
+}
+
 void AssemblyManager::applyDbcDiag(double *crs_vals) {
   requireReady(true);
   MHA_REQUIRE(crs_vals != nullptr, MHA_ERR_INVALID, "crs_vals is null");
@@ -1155,7 +1162,7 @@ BoundaryDev AssemblyManager::boundaryDev(const BoundaryGroupData &g) const {
 int AssemblyManager::addBoundaryGroup(const std::string &sidename, int bc_type, int num, const int32_t *elem_ids,
                                       const int32_t *side_ids) {
   MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "no mesh: call mha_set_mesh first");
-  MHA_REQUIRE(bc_type == MHA_BC_NEUMANN || bc_type == MHA_BC_WEAK_DIRICHLET ||
+  MHA_REQUIRE(bc_type == MHA_BC_NEUMANN || bc_type == MHA_BC_WEAK_DIRICHLET || bc_type == MHA_BC_INTERFACE ||
                   (bc_type >= MHA_BC_SWH_INTERFACE && bc_type <= MHA_BC_SWH_SLIP),
               MHA_ERR_INVALID, "boundary-condition type must be one of MHA_BC_*");
   MHA_REQUIRE(num >= 0 && (num == 0 || (elem_ids && side_ids)), MHA_ERR_INVALID, "bad boundary entry arrays");
@@ -1363,6 +1370,32 @@ void AssemblyManager::assembleBoundary(int flags, const double *u, const double 
     physics_->boundaryResidual();
   }
   timedEnd();
+}
+
+// reference: AssemblyManager::computeFlux -> PhysicsInterface::computeFlux -> the module's computeFlux on a boundary
+// group (src/managers/assemblyManager.hpp:573-727, subgridDtN_solver.cpp:1579): fills the workset's flux view
+// (elem, auxvar, pt) -- here [num][nqs] of the module's one aux variable -- and, on request, its derivative arrays
+void AssemblyManager::computeFlux(int group, const double *u, const double *u_prev, const double *u_stage, double *flux,
+                                  double *dflux_du, double *dflux_daux) {
+  requireReady(false);
+  MHA_REQUIRE(group >= 0 && group < numBoundaryGroups(), MHA_ERR_INVALID, "boundary group id out of range");
+  MHA_REQUIRE(flux != nullptr, MHA_ERR_INVALID, "flux array is null");
+  const auto &g = boundary_groups_[group];
+  bindState(u, u_prev, u_stage);
+  if (physics_id_ != MHA_PHYSICS_NAVIERSTOKES) prepareSideTables();
+  wkset_.sidename = g->sidename;
+  wkset_.current_bc = g->bc_type;
+  wkset_.bnd = boundaryDev(*g);
+  wkset_.bnd.flux = flux;
+  wkset_.bnd.dflux_du = dflux_du;
+  wkset_.bnd.dflux_daux = dflux_daux;
+  wkset_.side_tables = sideTablesDev();
+  wkset_.layout = layout_;
+  wkset_.layout.orient = has_orient_ ? d_orient_.data() : nullptr;
+  timedBegin();
+  physics_->computeFlux();
+  timedEnd();
+  wkset_.bnd.flux = nullptr;
 }
 
 // reference: BoundaryGroup::computeBasis -> getPhysicalBoundaryIntegrationData / getPhysicalBoundaryBasis

@@ -25,6 +25,10 @@ class AssemblyManager {
   ~AssemblyManager();
 
   void setStream(hipStream_t s) { stream_ = s; wkset_.stream = s; }
+  hipStream_t stream() const { return stream_; }
+  // strong-Dirichlet lifting: u[row] = vals[row] (or `scalar` when vals is null) on the fixed rows
+  // (SolverManager::setDirichlet, solverManager.cpp:1876-1957)
+  void dirichletLift(double *u, const double *vals, double scalar);
   // modules whose volume term only exists as a point function (multi-variable blocks; thermal with advection)
   bool engineOnly() const { return physics_id_ != MHA_PHYSICS_THERMAL || (physics_ && physics_->pointEngineOnly()); }
   void setMesh(int nelem, const double *nodes, const int32_t *lids, const int32_t *offsets, int nrows,
@@ -75,6 +79,8 @@ class AssemblyManager {
   int numBoundaryGroups() const { return static_cast<int>(boundary_groups_.size()); }
   void assembleBoundary(int flags, const double *u, const double *u_prev, const double *u_stage, double *res,
                         double *crs_vals);
+  void computeFlux(int group, const double *u, const double *u_prev, const double *u_stage, double *flux, double *dflux_du,
+                   double *dflux_daux);
   void boundaryUpdate(int group);
   View boundaryView(int group, const std::string &name) const;
   void setPhysicsParameter(const std::string &name, double value);

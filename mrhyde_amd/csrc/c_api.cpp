@@ -9,6 +9,7 @@
 #include "mesh.hpp"
 #include "row_blocks.hpp"
 #include "block_pattern.hpp"
+#include "newton.hpp"
 #include "test_hooks.h"
 #include "scatter_plan.hpp"
 #include "export_plan.hpp"
@@ -271,6 +272,79 @@ int mha_num_boundary_groups(mha_context *ctx) { return ctx ? ctx->mgr.numBoundar
 int mha_assemble_boundary(mha_context *ctx, int flags, const double *u, const double *u_prev, const double *u_stage,
                           double *res, double *crs_vals) {
   return guarded([&] { mgr(ctx).assembleBoundary(flags, u, u_prev, u_stage, res, crs_vals); });
+}
+
+struct mha_newton {
+  std::unique_ptr<mha::NewtonDriver> drv;
+  mha_context *ctx = nullptr;
+};
+
+int mha_newton_create(mha_context *ctx, int max_iter, double nl_tol, double nl_abs_tol, int use_relative, int use_absolute,
+                      int allow_backtracking, int autotune, mha_newton **out) {
+  return guarded([&] {
+    MHA_REQUIRE(out != nullptr, MHA_ERR_INVALID, "null argument");
+    *out = nullptr;
+    mha::NewtonSettings s;
+    s.max_iter = max_iter;
+    s.nl_tol = nl_tol;
+    s.nl_abs_tol = nl_abs_tol;
+    s.use_relative = use_relative;
+    s.use_absolute = use_absolute;
+    s.allow_backtracking = allow_backtracking;
+    s.autotune = autotune;
+    auto p = std::make_unique<mha_newton>();
+    p->drv = std::make_unique<mha::NewtonDriver>(mgr(ctx), s);
+    p->ctx = ctx;
+    *out = p.release();
+  });
+}
+void mha_newton_destroy(mha_newton *nw) { delete nw; }
+int mha_newton_reset(mha_newton *nw) {
+  return guarded([&] { MHA_REQUIRE(nw, MHA_ERR_INVALID, "null driver"); nw->drv->reset(); });
+}
+int mha_newton_residual(mha_newton *nw, const double *u, const double *u_prev, const double *u_stage, double *res) {
+  return guarded([&] { MHA_REQUIRE(nw, MHA_ERR_INVALID, "null driver"); mgr(nw->ctx); nw->drv->residual(u, u_prev, u_stage, res); });
+}
+int mha_newton_norm(mha_newton *nw, const double *res, double *resnorm) {
+  return guarded([&] { MHA_REQUIRE(nw && resnorm, MHA_ERR_INVALID, "null argument"); mgr(nw->ctx); *resnorm = nw->drv->norm(res); });
+}
+int mha_newton_decide(mha_newton *nw, double resnorm, double *u, int *action) {
+  return guarded([&] { MHA_REQUIRE(nw && action, MHA_ERR_INVALID, "null argument"); mgr(nw->ctx); *action = nw->drv->decide(resnorm, u); });
+}
+int mha_newton_jacobian(mha_newton *nw, const double *u, const double *u_prev, const double *u_stage, double *res,
+                        double *crs_vals) {
+  return guarded([&] { MHA_REQUIRE(nw, MHA_ERR_INVALID, "null driver"); mgr(nw->ctx); nw->drv->jacobian(u, u_prev, u_stage, res, crs_vals); });
+}
+int mha_newton_update(mha_newton *nw, double *u, const double *du) {
+  return guarded([&] { MHA_REQUIRE(nw, MHA_ERR_INVALID, "null driver"); mgr(nw->ctx); nw->drv->update(u, du); });
+}
+int mha_newton_step(mha_newton *nw, double *u, const double *u_prev, const double *u_stage, double *res, double *crs_vals,
+                    int *action) {
+  return guarded([&] {
+    MHA_REQUIRE(nw && action, MHA_ERR_INVALID, "null argument");
+    mgr(nw->ctx);
+    *action = nw->drv->step(u, u_prev, u_stage, res, crs_vals);
+  });
+}
+int mha_newton_state(const mha_newton *nw, int *iteration, double *resnorm, double *resnorm_scaled, double *resnorm_first,
+                     double *alpha, int *status) {
+  return guarded([&] {
+    MHA_REQUIRE(nw, MHA_ERR_INVALID, "null driver");
+    if (iteration) *iteration = nw->drv->iteration();
+    if (resnorm) *resnorm = nw->drv->resnorm();
+    if (resnorm_scaled) *resnorm_scaled = nw->drv->resnormScaled();
+    if (resnorm_first) *resnorm_first = nw->drv->resnormFirst();
+    if (alpha) *alpha = nw->drv->alpha();
+    if (status) *status = nw->drv->status();
+  });
+}
+int mha_dirichlet_lift(mha_context *ctx, double *u, const double *fixed_soln, double scalar_value) {
+  return guarded([&] { mgr(ctx).dirichletLift(u, fixed_soln, scalar_value); });
+}
+
+int mha_compute_flux(mha_context *ctx, int group_id, const double *u, const double *u_prev, const double *u_stage,
+                     double *flux, double *dflux_du, double *dflux_daux) {
+  return guarded([&] { mgr(ctx).computeFlux(group_id, u, u_prev, u_stage, flux, dflux_du, dflux_daux); });
 }
 
 int mha_boundary_update(mha_context *ctx, int group_id) {

@@ -138,6 +138,11 @@ struct BoundaryDev {
   FuncDesc data;         // "Neumann e <side>" or "Dirichlet e <side>" at the side ip: ip array is [num][nqs]
   FuncDesc diff;         // "thermal diffusion" at the side ip (constant or closed form)
   double form_param = 1.0;
+  // computeFlux (src/physics/thermal.cpp:288-347, porousMixed.cpp:440-500): wkset->flux(elem, auxvar, pt) of the group's
+  // entries and its derivative arrays; null = the launch is a boundaryResidual
+  double *flux = nullptr;        // [num][nqs]
+  double *dflux_du = nullptr;    // [num][nqs][n]: d flux / d u_j, j in flattened (variable, dof) order (may be null)
+  double *dflux_daux = nullptr;  // [num][nqs]:    d flux / d (aux value at the point) (may be null)
 };
 
 // Side views of one boundary group (getPhysicalBoundaryIntegrationData / getPhysicalBoundaryBasis).

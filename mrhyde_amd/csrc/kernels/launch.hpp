@@ -104,6 +104,8 @@ void launch_thermal_boundary(const BlockDev &b, const SideTablesDev &st, const B
                              const ElemOut &out, hipStream_t stream);
 
 // porous_boundary.hip: porousMixed::boundaryResidual (weak Dirichlet on p)
+void launch_porous_flux(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const VarLayoutDev &vl,
+                        const TimeDev &tm, hipStream_t stream);
 void launch_porous_boundary(const BlockDev &b, const SideTablesDev &st, const BoundaryDev &bd, const VarLayoutDev &vl,
                             const ElemOut &out, hipStream_t stream);
 
@@ -127,6 +129,10 @@ void launch_swhdg_element(const BlockDev &b, const SideTablesDev &st, const SwhE
                           hipStream_t stream);
 
 // condense.hip: batched static condensation of element blocks (one wavefront per element)
+// newton.hip: vector kernels of the Newton driver (newton.hpp)
+void launch_norm_inf(int64_t n, const double *v, unsigned long long *out_bits, hipStream_t stream);
+void launch_axpy(int64_t n, double alpha, const double *x, double *y, hipStream_t stream);
+void launch_dirichlet_lift(int64_t n, const uint8_t *fixed, const double *vals, double scalar, double *u, hipStream_t stream);
 // swhdg_fused.hip: side + volume assembly + static condensation of the HDG element in one kernel
 void launch_swhdg_fused(const BlockDev &b, const SideTablesDev &st, const SwhElementDev &a, const TimeDev &tm,
                         const PhysParamsDev &pp, const SwhFusedOut &o, hipStream_t stream);

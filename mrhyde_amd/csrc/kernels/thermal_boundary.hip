@@ -6,7 +6,8 @@
 //   AssemblyManager::performBoundaryGather, updateWorksetBoundary, the boundary loop of assembleJacRes
 //       src/managers/assemblyManager.cpp:3650-3700, 5646-5710, 2518-2638
 //   Workset::getSideElementSize                         src/tools/workset.cpp:2682-2696
-//   thermal::boundaryResidual (Neumann + weak Dirichlet) src/physics/thermal.cpp:172-281
+//   thermal::boundaryResidual (Neumann, weak Dirichlet, interface) src/physics/thermal.cpp:172-281
+//   thermal::computeFlux                                  src/physics/thermal.cpp:288-347
 //
 // One wave per boundary entry.  A side has at most 16 integration points and an element at most 32 dofs, so the
 // whole entry lives in a few KB of LDS; the Sacado derivative array is produced in closed form:
@@ -72,7 +73,9 @@ __global__ __launch_bounds__(64 * kBndWaves) void thermal_boundary_kernel(BlockD
   const bool active = k < bd.num;  // inactive waves still take part in the block barriers
   const int n = b.n, nqs = st.nqs;
   const int e = active ? bd.elem[k] : 0, s = active ? bd.side[k] : 0;
-  const bool weak = bd.bc_type == MHA_BC_WEAK_DIRICHLET;
+  // "interface" is the weak-Dirichlet branch with the trace ("aux e") as the data (thermal.cpp:227-243); computeFlux
+  // needs the same side fields
+  const bool weak = bd.bc_type == MHA_BC_WEAK_DIRICHLET || bd.bc_type == MHA_BC_INTERFACE || bd.flux != nullptr;
   const int32_t *L = b.lids + (size_t)e * n;
 
   // A. side geometry + data (lane = side point); gather + seeding value (lane = basis dof)
@@ -138,6 +141,22 @@ __global__ __launch_bounds__(64 * kBndWaves) void thermal_boundary_kernel(BlockD
   }
   if (!active) return;
   const double epen = 10.0, sf = bd.form_param;
+  if (bd.flux) {
+    // computeFlux: flux = (epen / h) kappa (lambda - T) + sf kappa grad T . n with sf = 1 (forward runs, thermal.cpp:293-296),
+    // lambda = "aux e" at the side points (here: the group's data function)
+    if (lane < nqs) {
+      const double kap = s_kap[wv][lane];
+      bd.flux[(size_t)k * nqs + lane] = epen / h * kap * (s_g[wv][lane] - s_T[wv][lane]) + kap * s_gTn[wv][lane];
+      if (bd.dflux_daux) bd.dflux_daux[(size_t)k * nqs + lane] = epen / h * kap;
+    }
+    if (bd.dflux_du)
+      for (int idx = lane; idx < n * nqs; idx += 64) {
+        const int q = idx / n, j = idx - q * n;
+        bd.dflux_du[((size_t)k * nqs + q) * n + j] =
+            tm.alpha_u * s_kap[wv][q] * (-epen / h * st.basis[(s * n + j) * nqs + q] + s_bgn[wv][j * nqs + q]);
+      }
+    return;
+  }
 
   // D. residual rows (lane = basis dof)
   if (lane < n) {

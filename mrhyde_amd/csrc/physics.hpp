@@ -94,6 +94,7 @@ class thermal : public PhysicsBase {
   void defineFunctions(FunctionManager &fm) override;
   void volumeResidual() override;
   void boundaryResidual() override;
+  void computeFlux() override;
   void setParameter(const std::string &name, double value) override;
   ThermalDev device_params() const;
   double formparam = 1.0;  // settings "form_param" (reference: thermal.cpp:35)
@@ -110,6 +111,7 @@ class porousMixed : public PhysicsBase {
   void defineFunctions(FunctionManager &fm) override;
   void volumeResidual() override;
   void boundaryResidual() override;
+  void computeFlux() override;
 };
 
 // navierstokes: incompressible Navier-Stokes with optional SUPG / PSPG
@@ -119,6 +121,7 @@ class navierstokes : public PhysicsBase {
   navierstokes();
   void defineFunctions(FunctionManager &fm) override;
   void volumeResidual() override;
+  void computeFlux() override;
   void setParameter(const std::string &name, double value) override;
   bool useSUPG = false, usePSPG = false;  // navierstokes.cpp:45-46
   bool fix_uz_offsets = false;            // false reproduces navierstokes.cpp:688

@@ -169,8 +169,10 @@ void thermal::boundaryResidual() {
   bd.form_param = formparam;
   if (w.current_bc == MHA_BC_NEUMANN) {
     bd.data = functionManager->evaluate("Neumann e " + w.sidename);
-  } else if (w.current_bc == MHA_BC_WEAK_DIRICHLET) {
-    bd.data = functionManager->evaluate("Dirichlet e " + w.sidename);
+  } else if (w.current_bc == MHA_BC_WEAK_DIRICHLET || w.current_bc == MHA_BC_INTERFACE) {
+    // "interface": the same terms with the trace value "aux e" at the side points in place of the Dirichlet data
+    // (thermal.cpp:227-243)
+    bd.data = functionManager->evaluate((w.current_bc == MHA_BC_INTERFACE ? "aux e " : "Dirichlet e ") + w.sidename);
     bd.diff = functionManager->evaluate("thermal diffusion");
     MHA_REQUIRE(bd.diff.kind != MHA_FUNC_IP_ARRAY, MHA_ERR_INVALID,
                 "weak Dirichlet needs 'thermal diffusion' at the side points: give it as a constant or closed form");
@@ -178,6 +180,22 @@ void thermal::boundaryResidual() {
     return;  // strong Dirichlet / none: no boundary term (thermal.cpp:188-216 falls through)
   }
   launch_thermal_boundary(w.dev, w.side_tables, bd, w.time_dev, w.res, w.stream);
+}
+
+// reference: thermal<EvalT>::computeFlux (src/physics/thermal.cpp:288-347): wkset->flux(elem, e, pt) on the current
+// boundary group = (10 / h) kappa (lambda - T) + kappa grad T . n with lambda = "aux e <side>" at the side points
+void thermal::computeFlux() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "thermal::computeFlux called without a workset");
+  Workset &w = *wkset;
+  BoundaryDev bd = w.bnd;
+  MHA_REQUIRE(bd.flux != nullptr, MHA_ERR_INVALID, "computeFlux: no flux array on the workset");
+  bd.bc_type = MHA_BC_INTERFACE;
+  bd.form_param = formparam;
+  bd.data = functionManager->evaluate("aux e " + w.sidename);
+  bd.diff = functionManager->evaluate("thermal diffusion");
+  MHA_REQUIRE(bd.diff.kind != MHA_FUNC_IP_ARRAY, MHA_ERR_INVALID,
+              "computeFlux needs 'thermal diffusion' at the side points: give it as a constant or closed form");
+  launch_thermal_boundary(w.dev, w.side_tables, bd, w.time_dev, ElemOut(), w.stream);
 }
 
 // ---- porousMixed -------------------------------------------------------------------------------------------------
@@ -250,6 +268,26 @@ void navierstokes::setParameter(const std::string &name, double value) {
   else if (name == "usePSPG") usePSPG = value != 0.0;
   else if (name == "fix_uz_offsets") fix_uz_offsets = value != 0.0;
   else PhysicsBase::setParameter(name, value);
+}
+
+// reference: porousMixed<EvalT>::computeFlux (src/physics/porousMixed.cpp:440-500): flux(elem, auxp, pt) = u . n
+void porousMixed::computeFlux() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "porousMixed::computeFlux called without a workset");
+  Workset &w = *wkset;
+  MHA_REQUIRE(w.bnd.flux != nullptr, MHA_ERR_INVALID, "computeFlux: no flux array on the workset");
+  launch_porous_flux(w.dev, w.side_tables, w.bnd, w.layout, w.time_dev, w.stream);
+}
+
+// reference: navierstokes<EvalT>::computeFlux (src/physics/navierstokes.cpp:1016-1018) is empty: the flux view keeps the
+// zeros the workset reset left in it
+void navierstokes::computeFlux() {
+  MHA_REQUIRE(wkset != nullptr, MHA_ERR_STATE, "navierstokes::computeFlux called without a workset");
+  Workset &w = *wkset;
+  MHA_REQUIRE(w.bnd.flux != nullptr, MHA_ERR_INVALID, "computeFlux: no flux array on the workset");
+  const size_t npt = static_cast<size_t>(w.bnd.num) * w.side_tables.nqs;
+  MHA_HIP(hipMemsetAsync(w.bnd.flux, 0, sizeof(double) * npt, w.stream));
+  if (w.bnd.dflux_du) MHA_HIP(hipMemsetAsync(w.bnd.dflux_du, 0, sizeof(double) * npt * w.dev.n, w.stream));
+  if (w.bnd.dflux_daux) MHA_HIP(hipMemsetAsync(w.bnd.dflux_daux, 0, sizeof(double) * npt, w.stream));
 }
 
 // reference: navierstokes::volumeResidual (navierstokes.cpp:82-849) as the point function navierstokes_point

@@ -221,3 +221,55 @@ def test_boundary_error_behaviour(oracle):
     torch.cuda.synchronize()
     # constant unit flux over the top side: sum of -res = -(-1 * |top|) ... res receives -(-g w N) = +g w N
     assert abs(res.sum().item() - 1.0) < 1e-13
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell", [(2, 2, 4, (4, 3)), (3, 1, 2, (3, 2, 2)), (3, 2, 4, (2, 3, 2))])
+def test_thermal_compute_flux_and_interface_branch(oracle, dim, order, qdeg, ncell):
+    """thermal::computeFlux (src/physics/thermal.cpp:288-347) on a boundary group of a warped mesh -- the flux view
+    (10/h) kappa (lambda - T) + kappa grad T . n and its derivative arrays -- against the formula evaluated with the
+    oracle's side views; and the "interface" branch of boundaryResidual (thermal.cpp:227-243) against the oracle's
+    weak-Dirichlet restatement fed with the trace values as data."""
+    torch = _torch()
+    import mrhyde_amd
+    m = warped(oracle, dim, order, ncell)
+    rng = np.random.default_rng(5)
+    u = rng.uniform(-1, 1, m["ndof"])
+    name = "right"
+    be, bs = oracle.boundary_sides(dim, ncell, name)
+    sv = oracle.physical_side_basis(dim, order, qdeg, m["nodes"], be, bs)
+    nqs = sv["wts"].shape[1]
+    lam = rng.uniform(-1, 1, (len(be), nqs))
+    kappa = 1.7
+    off = np.asarray(m["offsets"])
+    ue = u[m["lids"][be][:, off]]                                         # [k][n], basis-function order
+    T = np.einsum("kj,kjq->kq", ue, sv["basis"])
+    gn = np.einsum("kjqd,kqd->kjq", sv["basis_grad"], sv["normals"])       # grad N_j . n
+    gTn = np.einsum("kj,kjq->kq", ue, gn)
+    h = sv["wts"].sum(axis=1) ** (1.0 / (dim - 1))
+    flux_ref = (10.0 / h)[:, None] * kappa * (lam - T) + kappa * gTn
+    dfdu_ref = kappa * (-(10.0 / h)[:, None, None] * np.transpose(sv["basis"], (0, 2, 1)) + np.transpose(gn, (0, 2, 1)))
+    rowptr, colind = oracle.build_graph(m["ndof"], m["lids"])
+    blk = make_block(m, dim, order, qdeg, graph=(rowptr, colind))
+    blk.set_function("thermal diffusion", kappa)
+    gid = blk.add_boundary_group(name, mrhyde_amd.BC_INTERFACE, be, bs)
+    lam_d = torch.tensor(lam, device="cuda")
+    blk.set_function("aux e " + name, lam_d)
+    ud = torch.tensor(u, device="cuda")
+    n = m["lids"].shape[1]
+    flux = torch.zeros((len(be), nqs), dtype=torch.float64, device="cuda")
+    dfdu = torch.zeros((len(be), nqs, n), dtype=torch.float64, device="cuda")
+    dfda = torch.zeros((len(be), nqs), dtype=torch.float64, device="cuda")
+    blk.compute_flux(gid, ud, flux, dflux_du=dfdu, dflux_daux=dfda)
+    torch.cuda.synchronize()
+    assert rel_err(flux.cpu().numpy(), flux_ref) < RTOL
+    assert rel_err(dfdu.cpu().numpy(), dfdu_ref) < RTOL
+    assert rel_err(dfda.cpu().numpy(), np.broadcast_to((10.0 / h)[:, None] * kappa, lam.shape)) < RTOL
+    # interface branch of boundaryResidual = weak Dirichlet with the trace as data
+    vals_ref, res_ref = np.zeros(rowptr[-1]), np.zeros(m["ndof"])
+    oracle.assemble_thermal_boundary(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, be, bs, 2, ("array", lam),
+                                     rowptr=rowptr, colind=colind, crs_vals=vals_ref, res=res_ref, diff=kappa)
+    res = torch.zeros(m["ndof"], dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(colind), dtype=torch.float64, device="cuda")
+    blk.assemble_boundary(ud, res, vals)
+    torch.cuda.synchronize()
+    assert rel_err(vals.cpu().numpy(), vals_ref) < RTOL and rel_err(res.cpu().numpy(), res_ref) < RTOL

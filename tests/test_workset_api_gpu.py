@@ -376,3 +376,50 @@ def test_mass_matrix_free_database_and_sparse3d(oracle, tnames, orders, dim, nce
     torch.cuda.synchronize()
     assert rel_err(y.cpu().numpy(), want) < RTOL
     s3.close()
+
+
+@pytest.mark.parametrize("kind,dim,ncell,transient", [("porous", 2, (5, 4), False), ("porous", 3, (3, 2, 3), True), ("ns", 2, (4, 3), False)])
+def test_compute_flux_of_the_multi_variable_modules(oracle, kind, dim, ncell, transient):
+    """porousMixed::computeFlux (src/physics/porousMixed.cpp:440-500): flux(elem, auxp, pt) = u . n at the side points of a
+    boundary group, u from the Piola-mapped HDIV side basis with the caller's orientation signs, and its derivative with
+    respect to the element's unknowns -- against the formula evaluated with the oracle's side views (warped mesh, flipped
+    faces, 2-stage tableau when transient).  navierstokes::computeFlux is empty in the reference (navierstokes.cpp:1016-1018):
+    the view stays zero."""
+    torch = _torch()
+    import mrhyde_amd
+    rng = np.random.default_rng(73)
+    physics, names, types, orders, qdeg, m = build(oracle, kind, dim, ncell, rng)
+    side = "top"
+    belem, bside = oracle.boundary_sides(dim, ncell, side)
+    sb = oracle.physical_side_basis(dim, 1, qdeg, m["nodes"], belem, bside)
+    nb, nqs = sb["wts"].shape
+    u = rng.uniform(-1, 1, m["ndof"])
+    tr, kw = None, {}
+    if transient:
+        A, b, bdf = np.array([[0.5, 0.0], [0.3, 0.7]]), np.array([0.4, 0.6]), np.array([1.5, -2.0, 0.5])
+        tr = dict(u_prev=rng.uniform(-1, 1, (m["ndof"], 2)), u_stage=rng.uniform(-1, 1, (m["ndof"], 2)), stage=1,
+                  butcher_A=A, butcher_b=b, bdf=bdf, dt=0.05)
+    blk = make_block(m, physics, qdeg)
+    if tr is not None:
+        blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+        kw = dict(u_prev=torch.tensor(tr["u_prev"], device="cuda"), u_stage=torch.tensor(tr["u_stage"], device="cuda"))
+    gid = blk.add_boundary_group(side, mrhyde_amd.BC_WEAK_DIRICHLET, belem, bside)
+    n = m["lids"].shape[1]
+    flux = torch.full((nb, nqs), 7.0, dtype=torch.float64, device="cuda")
+    dfdu = torch.full((nb, nqs, n), 7.0, dtype=torch.float64, device="cuda")
+    blk.compute_flux(gid, torch.tensor(u, device="cuda"), flux, dflux_du=dfdu, **kw)
+    torch.cuda.synchronize()
+    if kind == "ns":
+        assert float(flux.abs().max()) == 0.0 and float(dfdu.abs().max()) == 0.0
+        return
+    v = names.index("u")
+    hd = oracle.physical_side_basis_hdiv(dim, qdeg, m["nodes"], belem, bside, var_orient(oracle, m, v, oracle.HDIV))  # [nb][card][nqs][dim]
+    vn = np.einsum("kjqd,kqd->kjq", hd, sb["normals"])
+    off = m["offsets"][m["varptr"][v]:m["varptr"][v + 1]]
+    ue_all, _ = seeded(u, tr)
+    ue = ue_all[m["lids"][belem][:, off]]
+    alpha_u = 1.0 if tr is None else tr["butcher_A"][1, 1] / tr["butcher_b"][1]
+    assert rel_err(flux.cpu().numpy(), np.einsum("kj,kjq->kq", ue, vn)) < RTOL
+    want = np.zeros((nb, nqs, n))
+    want[:, :, m["varptr"][v]:m["varptr"][v + 1]] = alpha_u * np.transpose(vn, (0, 2, 1))
+    assert rel_err(dfdu.cpu().numpy(), want) < RTOL
