@@ -79,10 +79,11 @@ _T0 = time.perf_counter()
 
 
 def measured_traffic(config, mesh, path_name):
-    """HBM bytes per assembly from the committed PMC run of this exact workload (profiles/r2_traffic.json: FETCH_SIZE
-    + WRITE_SIZE collected in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes), or None."""
+    """HBM bytes per assembly from the committed PMC run of this exact workload (profiles/r3_traffic.json: FETCH_SIZE
+    + WRITE_SIZE collected in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes), or None (other sizes,
+    other paths: nothing measured)."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
         e = t.get("config%d_%s" % (config, mesh))
         if e and e.get("path") == path_name:
             return e["hbm_bytes_per_assembly"]
@@ -112,47 +113,57 @@ def measured_copy_gbs(torch, dev):
 # CPU baselines: the oracle ("port" of the reference data flow), bounded samples of the same workload
 # ---------------------------------------------------------------------------------------------------------------------
 
-def cpu_baseline_thermal(dim, order, qdeg, ncell_sample, threads, gpu_vals=None, target_s=12.0, max_reps=8):
+def _median_after_warmups(run, warmups=2, reps=10):
+    """median of >= 10 repetitions after 2 warm-ups."""
+    for _ in range(warmups):
+        run()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = run()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), out, reps
+
+
+def cpu_baseline_thermal(dim, order, qdeg, ncell_sample, threads, gpu_vals=None, budget_s=30.0):
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    m = oracle_lib.mesh_structured(dim, order, ncell_sample)
-    u = synthetic_state(dim, order, ncell_sample, [0] * dim, [1] * dim, 2)
-    pb = oracle_lib.physical_basis(dim, order, qdeg, m["nodes"])  # stored basis: setup, not timed (as in the reference)
-    rowptr, colind = oracle_lib.build_graph(m["ndof"], m["lids"])
     freq = [2 * np.pi] * dim
 
-    def run(nt):
-        return oracle_lib.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=m["boundary"],
-                                           pb=pb, workset_size=100, source=("sinprod", 4.0 * dim * np.pi ** 2, freq),
-                                           num_threads=nt, rowptr=rowptr, colind=colind)
-    ts, reps, ref = [], 1, None
-    while len(ts) < reps:
-        t0 = time.perf_counter()
-        ref = run(threads)
-        ts.append(time.perf_counter() - t0)
-        if len(ts) == 1:  # size the repetition count so that about target_s of CPU work is timed
-            reps = int(min(max_reps, max(2, np.ceil(target_s / max(ts[0], 1e-3)))))
-    t = float(np.median(ts))
+    def prepare(nc):
+        m = oracle_lib.mesh_structured(dim, order, nc)
+        u = synthetic_state(dim, order, nc, [0] * dim, [1] * dim, 2)
+        pb = oracle_lib.physical_basis(dim, order, qdeg, m["nodes"])  # stored basis: setup, not timed (as in the reference)
+        rowptr, colind = oracle_lib.build_graph(m["ndof"], m["lids"])
+
+        def run(nt):
+            return oracle_lib.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=m["boundary"],
+                                               pb=pb, workset_size=100, source=("sinprod", 4.0 * dim * np.pi ** 2, freq),
+                                               num_threads=nt, rowptr=rowptr, colind=colind)
+        return m, run
+    nc = tuple(ncell_sample)
+    m, run = prepare(nc)
+    t0 = time.perf_counter()
+    ref = run(threads)  # probe: sizes the sample so that 2 warm-ups + 10 repetitions fit the budget
+    t1 = time.perf_counter() - t0
+    if 12 * t1 > budget_s and nc[-1] > 2:
+        nz = max(2, int(nc[-1] * budget_s / (12 * t1)))
+        nc = nc[:-1] + (nz,)
+        m, run = prepare(nc)
+    t, last, reps = _median_after_warmups(lambda: run(threads))
     out = {"value": m["nelem"] / t, "unit": "elements/s", "cores": threads, "kind": "port",
-           "sample": "%s Q%d hex elements (%d), workset 100, stored basis, AD width %d, median of %d" % (
-               "x".join(map(str, ncell_sample)), order, m["nelem"], oracle_lib.ad_width((order + 1) ** dim), reps),
+           "sample": "%s Q%d hex elements (%d; z-layers of the 64^3 mesh), workset 100, stored basis, AD width %d, median of %d after 2 warm-ups" % (
+               "x".join(map(str, nc)), order, m["nelem"], oracle_lib.ad_width((order + 1) ** dim), reps),
            "seconds": t}
     if gpu_vals is not None and len(gpu_vals) == len(ref["crs_vals"]):
         out["gpu_max_rel_diff_jacobian"] = float(np.abs(gpu_vals - ref["crs_vals"]).max() / np.abs(ref["crs_vals"]).max())
-    # one core, on a thinner sample of the same mesh (same x-y extent, 4 element layers)
-    nz1 = min(4, ncell_sample[-1])
-    nc1 = tuple(ncell_sample[:-1]) + (nz1,)
-    m1 = oracle_lib.mesh_structured(dim, order, nc1)
-    u1 = synthetic_state(dim, order, nc1, [0] * dim, [1] * dim, 2)
-    pb1 = oracle_lib.physical_basis(dim, order, qdeg, m1["nodes"])
-    rp1, ci1 = oracle_lib.build_graph(m1["ndof"], m1["lids"])
-    t0 = time.perf_counter()
-    oracle_lib.assemble_thermal(dim, order, qdeg, m1["nodes"], m1["lids"], m1["offsets"], u1, fixed=m1["boundary"], pb=pb1,
-                                workset_size=100, source=("sinprod", 4.0 * dim * np.pi ** 2, freq), num_threads=1,
-                                rowptr=rp1, colind=ci1)
-    out["value_1core"] = m1["nelem"] / (time.perf_counter() - t0)
-    out["sample_1core"] = "%s elements, 1 thread" % "x".join(map(str, nc1))
+    # one core, on a thinner sample of the same mesh (same x-y extent, 2 element layers)
+    nc1 = tuple(ncell_sample[:-1]) + (min(2, ncell_sample[-1]),)
+    m1, run1 = prepare(nc1)
+    t1c, _, reps1 = _median_after_warmups(lambda: run1(1), warmups=1, reps=3)
+    out["value_1core"] = m1["nelem"] / t1c
+    out["sample_1core"] = "%s elements, 1 thread, median of %d after 1 warm-up" % ("x".join(map(str, nc1)), reps1)
     return out
 
 
@@ -167,11 +178,9 @@ def cpu_baseline_block(kind, sample_nc, state_fn, funcs, params):
     m = orc.mesh_multi(3, (sample_nc,) * 3, types, orders)
     rowptr, colind = orc.build_graph(m["ndof"], m["lids"])
     u = state_fn(m)
-    t0 = time.perf_counter()
-    orc.assemble_block(m, phys, qdeg, u, funcs=funcs, params=params, rowptr=rowptr, colind=colind)
-    dt = time.perf_counter() - t0
+    dt, _, reps = _median_after_warmups(lambda: orc.assemble_block(m, phys, qdeg, u, funcs=funcs, params=params, rowptr=rowptr, colind=colind))
     return {"value": m["nelem"] / dt, "unit": "elements/s", "cores": 1, "kind": "port", "seconds": dt,
-            "sample": "%d^3 elements of the same block, oracle AD-array restatement, 1 thread" % sample_nc}
+            "sample": "%d^3 elements of the same block, oracle AD-array restatement, 1 thread, median of %d after 2 warm-ups" % (sample_nc, reps)}
 
 
 def cpu_baseline_hdg(sample_nc, seed):
@@ -180,11 +189,11 @@ def cpu_baseline_hdg(sample_nc, seed):
     H = orc.HGRAD
     m = orc.mesh_multi(2, (sample_nc, sample_nc), [H, H, H], [1, 1, 1])
     u, lam = hdg_state(m, seed)
-    t0 = time.perf_counter()
-    orc.swh_hdg_element(m, 2, u, lam.reshape(m["nelem"], 24), np.zeros((m["nelem"], 4), np.uint8), [1.0, 0.0, 0.0], g=1.0, roe=False)
-    dt = time.perf_counter() - t0
+    st = np.zeros((m["nelem"], 4), np.uint8)
+    dt, _, reps = _median_after_warmups(lambda: orc.swh_hdg_element(m, 2, u, lam.reshape(m["nelem"], 24), st, [1.0, 0.0, 0.0], g=1.0, roe=False))
     return {"value": m["nelem"] / dt, "unit": "elements/s", "cores": 1, "kind": "port", "seconds": dt,
-            "sample": "%d^2 HDG elements (side blocks only: the oracle restates the element, not the condensation), 1 thread" % sample_nc}
+            "sample": "%d^2 HDG elements (side blocks only: the oracle restates the element, not the condensation), 1 thread, "
+                      "median of %d after 2 warm-ups" % (sample_nc, reps)}
 
 
 def hdg_state(m, seed):
@@ -371,7 +380,7 @@ def setup_block(kind, args, torch, mrhyde_amd, rank, world, dev):
 
     def cpu():
         log("cpu baseline (1 thread, bounded sample)")
-        sample = 96 if kind == "porous" else 24  # ~10 s of one core each
+        sample = 48 if kind == "porous" else 12  # ~1.5 s of one core per repetition: 2 warm-ups + 10 repetitions
         ofuncs = {k: (v if not isinstance(v, tuple) else v) for k, v in funcs.items()}
         oparams = [] if kind == "porous" else [0, 0, 0]
         return cpu_baseline_block(kind, sample, lambda mm: state(mm, 4 if kind == "porous" else 5), ofuncs, oparams)
@@ -447,7 +456,7 @@ def setup_hdg(args, torch, mrhyde_amd, rank, world, dev):
 
     def cpu():
         log("cpu baseline (1 thread, bounded sample)")
-        return cpu_baseline_hdg(512, 6)  # ~10 s of one core
+        return cpu_baseline_hdg(192, 6)  # ~1.5 s of one core per repetition
 
     return dict(step=step, kernel_ms=kernel_ms, E=E, b_elem=11056, info=info, cpu=cpu, exch=exch, nrows=m["ndof"], nnz=plan.nnz,
                 workload="shallowwaterHybridized HDG on %d^2 quads (Q1 interior, HFACE-1 traces), one backward-Euler stage: side "
@@ -560,7 +569,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": cfg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, args.mesh, pname),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.ncell else measured_traffic(args.config, args.mesh, pname),
                          "kernel_ms": kernel_ms, "bytes_per_elem": b_elem,
                          "measured_copy_gbs": measured_copy_gbs(torch, dev),
                          "kernels": kern + " (HIP events around the assembly's kernels on the context's stream)"},

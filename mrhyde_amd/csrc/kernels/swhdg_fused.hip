@@ -69,7 +69,8 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
   const double *xn = b.nodes + (size_t)e * NN * DIM;
   if (active) {
     // ---- side points: one (point, direction) per lane (as swhdg_element.hip) ----
-    for (int idx = lane; idx < npts * 7; idx += 64) {
+    // (MAXP = 8: 56 tasks, one per lane -- no loop, which also keeps the compiler from overlapping two iterations' state)
+    for (int idx = lane; idx < npts * 7; idx += (MAXP == 8 ? 1 << 20 : 64)) {
       const int p = idx / 7, dir = idx - p * 7, s = p / nqs, q = p - s * nqs;
       const int edge = (s + 1) & 3;  // shards side 0,1,2,3 (bottom, right, top, left) -> HFACE edge 1,2,3,0
       double Ji[DIM * DIM], nrm[DIM], w, x[DIM];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
       Dual dS[3], dSh[3], f[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) { dS[i] = mk(S[i], dir == 1 + i ? 1.0 : 0.0); dSh[i] = mk(Sh[i], dir == 4 + i ? 1.0 : 0.0); }
-      swh_interface_flux(stype, a.roe != 0, dS, dSh, a.farfield, nrm[0], nrm[1], a.g, f);
+      swh_interface_flux_lean(stype, a.roe != 0, dS, dSh, a.farfield, nrm[0], nrm[1], a.g, f);
       if (dir == 0) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) s_f[wv][p][i] = f[i].v * w;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
       }
     }
     // ---- volume points: (point, direction 0..3) per lane; shallowwaterHybridized::volumeResidual ----
-    for (int idx = lane; idx < nq * 4; idx += 64) {
+    for (int idx = lane; idx < nq * 4; idx += (MAXP == 8 ? 1 << 20 : 64)) {  // (at most 9 x 4 tasks)
       const int q = idx >> 2, dir = idx & 3;
       double J[DIM * DIM] = {0, 0, 0, 0}, Ji[DIM * DIM], det, x[DIM] = {0, 0}, xi[DIM] = {0, 0};
       const double vx[4] = {-1.0, 1.0, 1.0, -1.0}, vy[4] = {-1.0, -1.0, 1.0, 1.0};  // reference vertices (shards order)

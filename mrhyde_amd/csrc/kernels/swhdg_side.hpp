@@ -96,6 +96,59 @@ __device__ __forceinline__ void swh_boundary_term(int type, const T *S, const T 
   }
 }
 
+// out = R w(Lambda) L x at the trace state, without holding L and R (21 entries -- 84 registers as Dual numbers -- that
+// the fused element kernel has no room for): the rows of L are applied and dropped one by one.  mode 0: w = |lambda|
+// (Roe-like stabilisation), 1: (lambda + |lambda|) / 2 (A+), 2: (lambda - |lambda|) / 2 (A-).  Same arithmetic as
+// swh_eigendecomp + swh_matvec, entry by entry.
+template <class T>
+__device__ __forceinline__ void swh_characteristic_apply(const T *Sh, double nx, double ny, double g, const T *x, int mode, T *out) {
+  const T H = Sh[0], ux = Sh[1] / H, uy = Sh[2] / H;
+  const T vn = ux * nx + uy * ny, a = s_sqrt(H * g);
+  const T i2a = 0.5 / a, ia = 1.0 / a;
+  T t0 = (s_const(H, 0.5) - vn * i2a) * x[0] + (i2a * nx) * x[1] + (i2a * ny) * x[2];
+  T t1 = ((ux * ny - uy * nx) * ia) * x[0] + (-(ia * ny)) * x[1] + (ia * nx) * x[2];
+  T t2 = (s_const(H, 0.5) + vn * i2a) * x[0] + (-(i2a * nx)) * x[1] + (-(i2a * ny)) * x[2];
+  const T l0 = vn + a, l1 = vn, l2 = vn - a;
+  auto wgt = [&](T l) { return mode == 0 ? s_abs(l) : (mode == 1 ? (l + s_abs(l)) * 0.5 : (l - s_abs(l)) * 0.5); };
+  t0 = t0 * wgt(l0);
+  t1 = t1 * wgt(l1);
+  t2 = t2 * wgt(l2);
+  out[0] = t0 + t2;  // (R's first row is 1 0 1)
+  out[1] = (ux + a * nx) * t0 + (-(a * ny)) * t1 + (ux - a * nx) * t2;
+  out[2] = (uy + a * ny) * t0 + (a * nx) * t1 + (uy - a * ny) * t2;
+}
+
+// swh_interface_flux with the characteristic products applied on the fly (fused element kernel)
+template <class T>
+__device__ __forceinline__ void swh_interface_flux_lean(int side_type, bool roe, const T *S, const T *Sh, const double *Sinf,
+                                                        double nx, double ny, double g, T *out) {
+  if (side_type == MHA_SWH_FARFIELD) {
+    T dS[3] = {S[0] - Sh[0], S[1] - Sh[1], S[2] - Sh[2]}, neg[3];
+    swh_characteristic_apply(Sh, nx, ny, g, dS, 1, out);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dS[i] = s_const(Sh[0], Sinf[i]) - Sh[i];
+    swh_characteristic_apply(Sh, nx, ny, g, dS, 2, neg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = out[i] - neg[i];
+    return;
+  }
+  if (side_type != MHA_SWH_INTERFACE) {
+    swh_boundary_term(side_type, S, Sh, Sinf, nx, ny, g, out);
+    return;
+  }
+  T st[3];
+  if (roe) {
+    const T dS[3] = {S[0] - Sh[0], S[1] - Sh[1], S[2] - Sh[2]};
+    swh_characteristic_apply(Sh, nx, ny, g, dS, 0, st);
+  } else {
+    swh_stab_term(S, Sh, nx, ny, g, false, st);
+  }
+  T F[3][2];
+  swh_flux_vector(Sh, g, F);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[i] = F[i][0] * nx + F[i][1] * ny + st[i];
+}
+
 // what computeFlux leaves in wkset->flux(elem, eqn, pt)
 template <class T>
 __device__ __forceinline__ void swh_interface_flux(int side_type, bool roe, const T *S, const T *Sh, const double *Sinf,

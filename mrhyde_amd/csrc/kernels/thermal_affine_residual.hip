@@ -64,7 +64,10 @@ __device__ __forceinline__ void apply1d(double *v, const double *T) {
 // (odd strides: conflict-free), instead of 64 different cache lines per load instruction.
 // SMALL: the launcher has checked |freq_d x_d| < 1e5 over the mesh (closed-form source): sines without the full-range fallback
 template <int DIM, int P, bool TR, bool EXPR, bool SMALL>
-__global__ __launch_bounds__(kK1tThreads, 2) void thermal_affine_residual_kernel(BlockDev b, ThermalDev ph,
+#ifndef MHA_K1_WAVES
+#define MHA_K1_WAVES 2
+#endif
+__global__ __launch_bounds__(kK1tThreads, MHA_K1_WAVES) void thermal_affine_residual_kernel(BlockDev b, ThermalDev ph,
                                                                               const double *__restrict__ geo,
                                                                               const AffineTables1D *__restrict__ tabp, double *res, int dbg) {
   // The 60 table entries are scalar operands of several hundred FMAs.  Passed by value they sat in 120 SGPRs for the
