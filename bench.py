@@ -277,7 +277,7 @@ def setup_thermal(args, torch, mrhyde_amd, rank, world, dev):
         pname = {1: "element_atomic", 2: "row_owner", 3: "local_then_scatter", 4: "point_engine", 5: "row_gather"}.get(blk.info("last_path"))
         kind = blk.info("row_owner_kind")
         kern = {"row_owner": ("thermal_general_row_owner_kernel (residual + Jacobian, one launch)" if kind == 2
-                              else "thermal_affine_residual_kernel + block_pattern_jacobian_kernel" if blk.info("block_patterns") > 0
+                              else "thermal_affine_residual_wg_kernel + block_pattern_jacobian_kernel" if blk.info("block_patterns") > 0
                               else "thermal_affine_element/residual kernel + row_owner_jacobian_persistent_kernel"),
                 "row_gather": "thermal_general_element_kernel (dense element matrices) + row_gather_kernel"}.get(pname, "element kernel + scatter")
         return pname, kern, {"affine_elements": blk.info("num_affine_elems"), "block_patterns": blk.info("block_patterns"),
@@ -296,7 +296,7 @@ def setup_thermal(args, torch, mrhyde_amd, rank, world, dev):
         return cpu_baseline_thermal(dim, order, qdeg, (nc, nc, args.cpu_sample_layers or nc), threads, gpu_vals=gv)
 
     return dict(step=step, kernel_ms=kernel_ms, E=E, b_elem=algorithmic_bytes_per_elem(nn, dim, n), info=info, cpu=cpu,
-                exch=exch, nrows=nrows, nnz=nnz,
+                exch=exch, nrows=nrows, nnz=nnz, _blk=blk, _u=u, _res=res, _vals=vals,
                 workload="3D thermal Q%d hex, %d^3 structured mesh per GPU (%s), quadrature %d, volume Jacobian+residual "
                          "assembled into CRS" % (order, nc, args.mesh, qdeg))
 

@@ -1668,12 +1668,100 @@ void AssemblyManager::prepareRowOwner() {
       }
     const char *k1 = std::getenv("MHA_K1");
     ro.k1_thread = !(k1 && std::string(k1) == "lanes");
+    ro.k1_plan = K1PlanDev();
+    ro.k1_wg = ro.k1_thread && !(k1 && std::string(k1) == "thread");
   }
   ro.phi.upload(ref_.phi1d);
   ro.dphi.upload(ref_.dphi1d);
   ro.gw.upload(ref_.gauss_wts);
   ro.gp.upload(ref_.gauss_pts);
   MHA_HIP(hipStreamSynchronize(stream_));
+  if (ro.k1_wg) {
+    // Plan of the workgroup-merged K1 (K1PlanDev): the elements in groups of 256, per group the distinct rows its dofs
+    // touch (ascending) and per (element, dof in basis order) the position of its row in that list.
+    constexpr int T = kK1PlanThreads;
+    std::vector<double> geo(static_cast<size_t>(nelem_) * kGeoRec);
+    ro.geo.download(geo.data());
+    bool aligned = true;  // every element axis-aligned (J diagonal: the test the kernels make per element)?
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int e = 0; e < nelem_; ++e) {
+      const double *g = &geo[static_cast<size_t>(e) * kGeoRec];
+      for (int r = 0; r < dim_; ++r) {
+        lo[r] = std::min(lo[r], g[kGeoXc + r]);
+        hi[r] = std::max(hi[r], g[kGeoXc + r]);
+        for (int c = 0; c < dim_; ++c)
+          if (r != c && g[kGeoJ + r * dim_ + c] != 0.0) aligned = false;
+      }
+    }
+    // order of the elements: as numbered (coalesced record loads; good whenever consecutive elements are neighbours),
+    // or along a Morton curve through the centroids when the numbering scatters a group over the mesh (its distinct
+    // rows would not fit the LDS three workgroups deep); MHA_K1_ORDER=natural|morton forces one
+    const char *ord = std::getenv("MHA_K1_ORDER");
+    const int G = (nelem_ + T - 1) / T;
+    std::vector<int32_t> wg_elems(static_cast<size_t>(G) * T), rp, rows, tmp;
+    std::vector<uint16_t> loc;
+    int max_rows = 0;
+    auto build = [&](bool natural) {
+      std::vector<std::pair<uint64_t, int32_t>> keyed(nelem_);
+      for (int e = 0; e < nelem_; ++e) {
+        uint64_t key = 0;
+        if (!natural) {
+          uint32_t q[3] = {0, 0, 0};
+          for (int r = 0; r < dim_; ++r) {
+            const double w = hi[r] > lo[r] ? (geo[static_cast<size_t>(e) * kGeoRec + kGeoXc + r] - lo[r]) / (hi[r] - lo[r]) : 0.0;
+            q[r] = static_cast<uint32_t>(std::min(1048575.0, std::max(0.0, w * 1048575.0)));
+          }
+          for (int bit = 19; bit >= 0; --bit)
+            for (int r = dim_ - 1; r >= 0; --r) key = (key << 1) | ((q[r] >> bit) & 1u);
+        }
+        keyed[e] = {key, e};
+      }
+      std::sort(keyed.begin(), keyed.end());
+      for (size_t i = 0; i < wg_elems.size(); ++i) wg_elems[i] = keyed[std::min<size_t>(i, nelem_ - 1)].second;
+      rp.assign(static_cast<size_t>(G) + 1, 0);
+      rows.clear();
+      rows.reserve(static_cast<size_t>(nelem_) * n_ / 2);
+      loc.assign(static_cast<size_t>(G) * n_ * T, 0);
+      max_rows = 0;
+      for (int g = 0; g < G; ++g) {
+        const int cnt = std::min(T, nelem_ - g * T);
+        tmp.clear();
+        for (int t = 0; t < cnt; ++t) {
+          const int32_t *L = &h_lids_[static_cast<size_t>(wg_elems[static_cast<size_t>(g) * T + t]) * n_];
+          tmp.insert(tmp.end(), L, L + n_);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (int t = 0; t < cnt; ++t) {
+          const int32_t *L = &h_lids_[static_cast<size_t>(wg_elems[static_cast<size_t>(g) * T + t]) * n_];
+          for (int ib = 0; ib < n_; ++ib)
+            loc[(static_cast<size_t>(g) * n_ + ib) * T + t] =
+                static_cast<uint16_t>(std::lower_bound(tmp.begin(), tmp.end(), L[offs[ib]]) - tmp.begin());
+        }
+        rows.insert(rows.end(), tmp.begin(), tmp.end());
+        rp[g + 1] = static_cast<int32_t>(rows.size());
+        max_rows = std::max(max_rows, static_cast<int>(tmp.size()));
+      }
+    };
+    const bool force_morton = ord && std::string(ord) == "morton", force_natural = ord && std::string(ord) == "natural";
+    build(!force_morton);
+    if (!force_morton && !force_natural && static_cast<size_t>(max_rows) * 12 > 52 * 1024) {
+      const int natural_rows = max_rows;
+      build(false);
+      if (max_rows >= natural_rows) build(true);
+    }
+    ro.k1_row_ptr.upload(rp);
+    ro.k1_rows.upload(rows);
+    ro.k1_loc.upload(loc);
+    ro.k1_elems.upload(wg_elems);
+    ro.k1_plan.wg_row_ptr = ro.k1_row_ptr.data();
+    ro.k1_plan.wg_rows = ro.k1_rows.data();
+    ro.k1_plan.loc = ro.k1_loc.data();
+    ro.k1_plan.wg_elems = ro.k1_elems.data();
+    ro.k1_plan.max_rows = (max_rows + 1) / 2 * 2;
+    ro.k1_plan.num_elems = nelem_;
+    ro.k1_plan.axis_aligned = aligned ? 1 : 0;
+  }
   ro.ready = true;
   prepareBlockPattern();
 }
@@ -1989,7 +2077,7 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
   static const int overlap = [] { const char *m = std::getenv("MHA_K1K2_OVERLAP"); return m ? std::atoi(m) : 1; }();
   const double su = ph.time.alpha_u * ph.diff.amp, st = ph.time.alpha_t * ph.rho.amp * ph.cp.amp;
   auto residual = [&](hipStream_t s) {  // K1: one thread per element (default) or the 32-lanes-per-element form (MHA_K1=lanes)
-    if (ro_.k1_thread) launch_thermal_affine_residual(dim_, order_, blockDev(), ph, ro_.geo.data(), ro_.tab1d, res, ro_.max_abs_coord, s);
+    if (ro_.k1_thread) launch_thermal_affine_residual(dim_, order_, blockDev(), ph, ro_.geo.data(), ro_.tab1d, &ro_.k1_plan, res, ro_.max_abs_coord, s);
     else launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, s);
   };
   auto jacobian = [&](hipStream_t s) {  // K2: pattern GEMMs on the matrix cores when the rows group, row blocks otherwise

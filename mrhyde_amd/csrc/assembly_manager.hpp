@@ -172,6 +172,11 @@ class AssemblyManager {
     DeviceBuffer<double> khat, phi, dphi, gw, gp;
     AffineTables1D tab1d;  // thread-per-element K1
     bool k1_thread = false;
+    // workgroup-merged K1 (K1PlanDev): distinct rows of every 256 consecutive elements + 16-bit positions
+    DeviceBuffer<int32_t> k1_row_ptr, k1_rows, k1_elems;
+    bool k1_wg = false;
+    DeviceBuffer<uint16_t> k1_loc;
+    K1PlanDev k1_plan;
     double max_abs_coord[3] = {0, 0, 0};  // of the block's vertices (bounds the arguments of a closed-form source)
     int slot_bytes = 1;
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;

@@ -42,7 +42,10 @@
 
 namespace mha {
 
-constexpr int kBpWaves = 12;       // wavefronts of a persistent workgroup (768 threads, 168 registers each: one workgroup per CU)
+#ifndef MHA_BP_WAVES
+#define MHA_BP_WAVES 12
+#endif
+constexpr int kBpWaves = MHA_BP_WAVES;  // wavefronts of a persistent workgroup (768 threads, 168 registers each: one workgroup per CU)
 constexpr int kBpMaxKSteps = 16;   // GEMM depth held in registers: 64 = 9 hexes x 7 or 16 quads x 4
 constexpr int kBpLaneRows = 24;    // per part and lane: [0..15] A offsets (doubles), [16..19] result rows of the lane's registers, [20] tile row lane & 15: run << 20 | CRS offset inside the run, [21] the same row's entry offset inside the block's LDS image (image roles)
 constexpr int kBpStreamWaves = kBpWaves - 1;  // image roles: wave 0 loads the element records, the others stream the image out

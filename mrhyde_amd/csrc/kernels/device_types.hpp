@@ -121,6 +121,23 @@ struct AffineTables1D {
   double gw[5] = {0}, gp[5] = {0};
 };
 
+// Plan of the workgroup-merged residual kernel (kernels/thermal_affine_residual.hip), made by the host at setup:
+// workgroup g takes the elements wg_elems[256 g .. 256 g + 256) (the last group repeats the last element),
+// wg_rows[wg_row_ptr[g] .. wg_row_ptr[g+1]) are the distinct rows their dofs touch, ascending, and
+// loc[(g * n + ib) * 256 + t] is the position in that list of dof ib (BASIS order) of the group's element t.
+#ifndef MHA_K1_THREADS
+#define MHA_K1_THREADS 256
+#endif
+constexpr int kK1PlanThreads = MHA_K1_THREADS;  // elements (= threads) of a workgroup
+struct K1PlanDev {
+  const int32_t *wg_row_ptr = nullptr;
+  const int32_t *wg_rows = nullptr;
+  const int32_t *wg_elems = nullptr;
+  const uint16_t *loc = nullptr;
+  int max_rows = 0, num_elems = 0;
+  int axis_aligned = 0;  // every element's J is diagonal (checked on the cached geometry records)
+};
+
 // Side reference tables on the device (ref_tables.hpp: SideTables).
 struct SideTablesDev {
   int nsides = 0, nqs = 0;

@@ -85,8 +85,10 @@ void launch_thermal_affine_element(int dim, int order, int nq1, const BlockDev &
                                    const AffineDev &af, double *res, hipStream_t stream);
 // thermal_affine_residual.hip: the same residual, one thread per element (sum-factorised through the point values)
 bool thermal_affine_residual_supported(int dim, int order, int nq1);
+// plan != nullptr: the workgroup-merged form (256 consecutive elements per workgroup meet in LDS: K1PlanDev)
 void launch_thermal_affine_residual(int dim, int order, const BlockDev &b, const ThermalDev &ph, const double *geo,
-                                    const AffineTables1D &tab, double *res, const double *max_abs_coord, hipStream_t stream);
+                                    const AffineTables1D &tab, const K1PlanDev *plan, double *res, const double *max_abs_coord,
+                                    hipStream_t stream);
 // K2: row-owner Jacobian; scale_u = alpha_u*kappa, scale_t = alpha_t*rho*cp
 void launch_row_owner_jacobian(int dim, int n, const RowBlocksDev &rb, const AffineDev &af, const RowOut &out,
                                double scale_u, double scale_t, hipStream_t stream);

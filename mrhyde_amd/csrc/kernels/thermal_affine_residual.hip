@@ -28,7 +28,8 @@ namespace mha {
 namespace {
 
 constexpr int cpow(int b, int e) { return e == 0 ? 1 : b * cpow(b, e - 1); }
-constexpr int kK1tThreads = 256;
+constexpr int kK1tThreads = 256;        // thread-per-element form
+constexpr int kK1wThreads = kK1PlanThreads;  // workgroup-merged form
 
 // index of the tensor entry `pt` with its digit in direction D replaced by v (digits base M, direction 0 fastest)
 template <int M, int D>
@@ -260,6 +261,214 @@ __global__ __launch_bounds__(kK1tThreads, MHA_K1_WAVES) void thermal_affine_resi
   }
 }
 
+// ---- workgroup-merged form (default) ------------------------------------------------------------------------------
+// The same element arithmetic, one thread per element, around a host-made plan (K1PlanDev, AssemblyManager::
+// prepareRowOwner): a workgroup takes 256 elements (consecutive ones, or neighbours along a Morton curve when the
+// numbering scatters them); the DISTINCT rows their dofs touch are listed once, and every (element, dof) knows its
+// position in that list (16 bits, stored [workgroup][dof in basis order][thread]: coalesced).
+//   A  the seeded solution of the listed rows -> an LDS table (coalesced loads of an ascending row list, each row once)
+//   B  a thread's 27 nodal values come out of the table
+//   C  the element arithmetic in registers (sum factorisation through the point values, as above)
+//   D  -r_i goes back into the (zeroed) table with ds_add_f64: contributions of the workgroup's elements to a shared
+//      row meet in LDS
+//   E  the table leaves with ONE atomic per listed row (9.9 per Q2 hex instead of 18-27)
+// Against the form above (27 scattered loads and 18-27 atomics per lane, the LID lists and geometry records staged through
+// 70 KB of LDS, 256 registers + spills, two wavefronts per SIMD): no LID traffic, 31 KB of LDS and a register budget of
+// three wavefronts per SIMD (no spills).
+// SEPK: the host has checked that every element is axis-aligned and the source is the closed form amp prod sin(freq_d
+// x_d): the separable evaluation is the only one compiled in (the general copy of the point loop, with its 81 inlined
+// sines, costs the register budget of the whole kernel)
+template <int DIM, int P, bool TR, bool EXPR, bool SMALL, bool SEPK>
+__global__ __launch_bounds__(kK1wThreads, (TR || EXPR || !SEPK) ? 2 : 3) void thermal_affine_residual_wg_kernel(
+    BlockDev b, ThermalDev ph, const double *__restrict__ geo, const AffineTables1D *__restrict__ tabp, K1PlanDev pl,
+    double *res, int dbg) {
+  const AffineTables1D &tab = *tabp;
+  constexpr int M = P + 1, N = cpow(M, DIM);
+  extern __shared__ double s_tab[];  // [max_rows] seeded u, then the accumulated -r; TR: [max_rows] u_dot behind it;
+                                     // then [max_rows] ints: the listed rows (~row = fixed), kept for E
+  int *s_row = reinterpret_cast<int *>(s_tab + (TR ? 2 : 1) * pl.max_rows);
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x;
+  const int r0 = pl.wg_row_ptr[g], nr = pl.wg_row_ptr[g + 1] - r0;
+  const bool active = g * kK1wThreads + tid < b.e_count;
+  const int e = pl.wg_elems[g * kK1wThreads + tid];
+  const TimeDev &tm = ph.time;
+  // ---- A. performGather + computeSoln*Seeded values (workset.cpp:589-623), once per listed row ----
+  // (four rows per thread and pass, every load of a stage issued before the first use: the loop would otherwise run its
+  //  dependent loads -- row id, then value -- one row at a time)
+  constexpr int KB = 4;
+  for (int base = tid; base < nr; base += KB * kK1wThreads) {
+    int row[KB];
+    double cu[KB];
+    bool fx[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) row[k] = pl.wg_rows[r0 + min(base + k * kK1wThreads, nr - 1)];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      cu[k] = tm.u[row[k]];
+      fx[k] = b.fixed && b.fixed[row[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int i = base + k * kK1wThreads;
+      if (i >= nr) break;
+      s_row[i] = fx[k] ? ~row[k] : row[k];
+      double ue = cu[k];
+      if constexpr (TR) {
+        const double *cp = tm.u_prev + (size_t)row[k] * tm.nsteps;
+        const double *cs = tm.u_stage + (size_t)row[k] * tm.nstages;
+        double beta_u = (1.0 - tm.alpha_u) * cp[0];
+        for (int s = 0; s < tm.stage; ++s) beta_u += tm.stage_ratio[s] * (cs[s] - cp[0]);
+        double beta_t = 0.0;
+        for (int s = 1; s < tm.nsteps + 1; ++s) beta_t += tm.bdf[s] * cp[s - 1];
+        beta_t *= tm.timewt;
+        ue = tm.alpha_u * cu[k] + beta_u;
+        s_tab[pl.max_rows + i] = tm.alpha_t * cu[k] + beta_t;
+      }
+      s_tab[i] = ue;
+    }
+  }
+  // the element's geometry record: G (upper triangle), det, then J and the centroid (requested before the barrier)
+  const double *grec = geo + (size_t)e * kGeoRec;
+  double G[DIM][DIM], xc[DIM], Jd[DIM];
+  {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < DIM; ++a)
+#pragma unroll
+      for (int c = a; c < DIM; ++c) { G[a][c] = grec[k]; G[c][a] = G[a][c]; ++k; }
+  }
+  double det = grec[kGeoDet];
+  bool separable = ph.source.kind != MHA_FUNC_CONSTANT && ph.source.kind != MHA_FUNC_IP_ARRAY && ph.source.kind != MHA_FUNC_EXPRESSION;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r) {
+    xc[r] = grec[kGeoXc + r];
+    Jd[r] = grec[kGeoJ + r * DIM + r];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c)
+      if (r != c && grec[kGeoJ + r * DIM + c] != 0.0) separable = false;
+  }
+  __syncthreads();
+  // ---- B. nodal values of this thread's element, basis (tensor) order ----
+  const uint16_t *loc = pl.loc + (size_t)g * N * kK1wThreads + tid;
+  double U[N], Ud[TR ? N : 1];
+#pragma unroll
+  for (int ib = 0; ib < N; ++ib) {
+    const int k = loc[ib * kK1wThreads];
+    U[ib] = s_tab[k];
+    if constexpr (TR) Ud[ib] = s_tab[pl.max_rows + k];
+  }
+  __syncthreads();
+  for (int i = tid; i < nr; i += kK1wThreads) s_tab[i] = 0.0;  // (the barrier before D orders this against the adds)
+  // ---- C. element arithmetic ----
+  apply1d<DIM, M, 0, true>(U, tab.phi);
+  apply1d<DIM, M, 1, true>(U, tab.phi);
+  if constexpr (DIM == 3) apply1d<DIM, M, DIM - 1, true>(U, tab.phi);
+  if constexpr (TR) {
+    apply1d<DIM, M, 0, true>(Ud, tab.phi);
+    apply1d<DIM, M, 1, true>(Ud, tab.phi);
+    if constexpr (DIM == 3) apply1d<DIM, M, DIM - 1, true>(Ud, tab.phi);
+  }
+  const double kap = ph.diff.amp, rc = ph.rho.amp * ph.cp.amp;  // element-wise constants on this path
+  if (dbg & 2) separable = false;
+  const bool all_sep = SEPK || __builtin_amdgcn_ballot_w64(!separable) == 0;
+  double s1d[DIM][M];
+  if (all_sep) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d)
+#pragma unroll
+      for (int q = 0; q < M; ++q) {
+        const double arg = ph.source.freq[d] * (xc[d] + Jd[d] * tab.gp[q]);
+        s1d[d][q] = SMALL ? sin_reduced(arg) : sin_moderate(arg);
+        __builtin_amdgcn_sched_barrier(0);  // one sine at a time
+      }
+  }
+  double W[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) W[i] = 0.0;
+  auto point_loop = [&](auto sep_tag) {
+    constexpr bool SEP = decltype(sep_tag)::value;
+#pragma unroll
+    for (int pt = 0; pt < N; ++pt) {
+      const int q0 = pt % M, q1 = (pt / M) % M, q2 = pt / (M * M);
+      const int qd[3] = {q0, q1, q2};
+      // One point at a time: the arithmetic is pure, so the optimiser is free to interleave all N points (and then needs
+      // twice the register file; a sched_barrier does not stop it, the IR passes move the arithmetic across it).  Empty
+      // volatile asms keep their order: a point starts behind this one and its updates of W end in the ones below.
+      asm volatile("" : "+v"(U[pt]));
+      double gh[DIM], wq = 1.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        wq *= tab.gw[qd[d]];
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < M; ++v) {
+          const int src = d == 0 ? with_digit<M, 0>(pt, v) : (d == 1 ? with_digit<M, 1>(pt, v) : with_digit<M, 2>(pt, v));
+          s += tab.dcol[qd[d] * M + v] * U[src];
+        }
+        gh[d] = s;
+      }
+      double f;
+      if constexpr (SEP) {
+        f = ph.source.amp;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) f *= s1d[d][qd[d]];
+      } else {
+        double x[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+          double s = xc[r];
+#pragma unroll
+          for (int c = 0; c < DIM; ++c) s += grec[kGeoJ + r * DIM + c] * tab.gp[qd[c]];
+          x[r] = s;
+        }
+        f = eval_func<DIM, EXPR, SMALL>(ph.source, e, pt, N, x);
+      }
+      const double tt = TR ? Ud[TR ? pt : 0] : 0.0;
+      W[pt] += (rc * tt - f) * det * wq;
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {  // F_a = w_q kappa detJ sum_c (J^-1 J^-T)_ac d_c T
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) s += G[a][c] * gh[c];
+        const double Fa = wq * kap * s;
+#pragma unroll
+        for (int v = 0; v < M; ++v) {
+          const int dst = a == 0 ? with_digit<M, 0>(pt, v) : (a == 1 ? with_digit<M, 1>(pt, v) : with_digit<M, 2>(pt, v));
+          W[dst] += tab.dcol[qd[a] * M + v] * Fa;
+          asm volatile("" : "+v"(W[dst]));
+        }
+      }
+    }
+  };
+  if constexpr (SEPK) {
+    point_loop(std::true_type());
+  } else {
+    if (all_sep) point_loop(std::true_type());
+    else point_loop(std::false_type());
+  }
+  apply1d<DIM, M, 0, false>(W, tab.phi);
+  apply1d<DIM, M, 1, false>(W, tab.phi);
+  if constexpr (DIM == 3) apply1d<DIM, M, DIM - 1, false>(W, tab.phi);
+  __syncthreads();
+  // ---- D. the global vector receives -res.val() (assemblyManager.cpp:4075, 4094): met in LDS first ----
+  if (active) {
+    const uint16_t *loc2 = loc;
+    asm volatile("" : "+v"(loc2));  // (the addresses are formed here, not carried through C in registers)
+#pragma unroll
+    for (int ib = 0; ib < N; ++ib) atomicAdd(&s_tab[loc2[ib * kK1wThreads]], -W[ib]);
+  }
+  __syncthreads();
+  // ---- E. one atomic per listed row, fixed rows skipped; the row ids come from LDS (a load from memory here would be
+  //      a latency nothing hides: 12 us of the kernel's 74 when the ids and flags were fetched again) ----
+  if (!(dbg & 1)) {
+    for (int i = tid; i < nr; i += kK1wThreads) {
+      const int row = s_row[i];
+      if (row >= 0) atomicAdd(res + row, s_tab[i]);
+    }
+  }
+}
+
 // device copy of a table, made once per (device, content) and kept for the life of the process
 const AffineTables1D *device_copy(const AffineTables1D &tab) {
   struct Entry { int device; AffineTables1D host; AffineTables1D *dev; };
@@ -278,10 +487,42 @@ const AffineTables1D *device_copy(const AffineTables1D &tab) {
 }
 
 template <int DIM, int P>
-void launch_t(const BlockDev &b, const ThermalDev &ph, const double *geo, const AffineTables1D &tab_host, double *res,
-              bool small_args, hipStream_t stream) {
+void launch_t(const BlockDev &b, const ThermalDev &ph, const double *geo, const AffineTables1D &tab_host, const K1PlanDev *plan,
+              double *res, bool small_args, hipStream_t stream) {
   if (b.e_count <= 0) return;
   const AffineTables1D *tab = device_copy(tab_host);
+  static const int dbg_wg = [] { const char *m = std::getenv("MHA_K1_DBG"); return m ? std::atoi(m) : 0; }();
+  if (plan && plan->loc) {  // workgroup-merged form (the plan covers the block's elements from e_begin = 0)
+    MHA_REQUIRE(b.e_begin == 0 && b.e_count == plan->num_elems, MHA_ERR_INVALID, "K1 plan: element range mismatch");
+    const int grid = (b.e_count + kK1wThreads - 1) / kK1wThreads;
+    const bool tr = ph.time.transient != 0;
+    const size_t lds = sizeof(double) * (size_t)plan->max_rows * (tr ? 2 : 1) + sizeof(int) * (size_t)plan->max_rows;
+    auto go = [&](auto kern) {
+      if (lds > 64 * 1024) MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1wThreads), lds, stream, b, ph, geo, tab, *plan, res, dbg_wg);
+    };
+    const bool sinprod = ph.source.kind != MHA_FUNC_CONSTANT && ph.source.kind != MHA_FUNC_IP_ARRAY && ph.source.kind != MHA_FUNC_EXPRESSION;
+    if (has_expression(ph.source)) {
+      if (tr) go(thermal_affine_residual_wg_kernel<DIM, P, true, true, false, false>);
+      else go(thermal_affine_residual_wg_kernel<DIM, P, false, true, false, false>);
+    } else if (plan->axis_aligned && sinprod && !(dbg_wg & 2)) {
+      if (small_args) {
+        if (tr) go(thermal_affine_residual_wg_kernel<DIM, P, true, false, true, true>);
+        else go(thermal_affine_residual_wg_kernel<DIM, P, false, false, true, true>);
+      } else {
+        if (tr) go(thermal_affine_residual_wg_kernel<DIM, P, true, false, false, true>);
+        else go(thermal_affine_residual_wg_kernel<DIM, P, false, false, false, true>);
+      }
+    } else if (small_args) {
+      if (tr) go(thermal_affine_residual_wg_kernel<DIM, P, true, false, true, false>);
+      else go(thermal_affine_residual_wg_kernel<DIM, P, false, false, true, false>);
+    } else {
+      if (tr) go(thermal_affine_residual_wg_kernel<DIM, P, true, false, false, false>);
+      else go(thermal_affine_residual_wg_kernel<DIM, P, false, false, false, false>);
+    }
+    MHA_HIP(hipGetLastError());
+    return;
+  }
   const int grid = (b.e_count + kK1tThreads - 1) / kK1tThreads;  // a wavefront takes 64 consecutive elements
   const bool tr = ph.time.transient != 0;
   static const int dbg = [] { const char *m = std::getenv("MHA_K1_DBG"); return m ? std::atoi(m) : 0; }();  // profiling aid: 1 no atomics, 2 general source evaluation, 4 no gather
@@ -306,15 +547,16 @@ bool thermal_affine_residual_supported(int dim, int order, int nq1) {
 }
 
 void launch_thermal_affine_residual(int dim, int order, const BlockDev &b, const ThermalDev &ph, const double *geo,
-                                    const AffineTables1D &tab, double *res, const double *max_abs_coord, hipStream_t stream) {
+                                    const AffineTables1D &tab, const K1PlanDev *plan, double *res, const double *max_abs_coord,
+                                    hipStream_t stream) {
   // closed-form source amp prod sin(freq_d x_d): arguments bounded by |freq_d| max|x_d| over the mesh
   bool small_args = ph.source.kind != MHA_FUNC_CONSTANT && ph.source.kind != MHA_FUNC_IP_ARRAY && ph.source.kind != MHA_FUNC_EXPRESSION;
   for (int d = 0; d < dim; ++d) small_args = small_args && std::fabs(ph.source.freq[d]) * max_abs_coord[d] < 0.5e5;
-  if (dim == 2 && order == 1) return launch_t<2, 1>(b, ph, geo, tab, res, small_args, stream);
-  if (dim == 2 && order == 2) return launch_t<2, 2>(b, ph, geo, tab, res, small_args, stream);
-  if (dim == 2 && order == 4) return launch_t<2, 4>(b, ph, geo, tab, res, small_args, stream);
-  if (dim == 3 && order == 1) return launch_t<3, 1>(b, ph, geo, tab, res, small_args, stream);
-  if (dim == 3 && order == 2) return launch_t<3, 2>(b, ph, geo, tab, res, small_args, stream);
+  if (dim == 2 && order == 1) return launch_t<2, 1>(b, ph, geo, tab, plan, res, small_args, stream);
+  if (dim == 2 && order == 2) return launch_t<2, 2>(b, ph, geo, tab, plan, res, small_args, stream);
+  if (dim == 2 && order == 4) return launch_t<2, 4>(b, ph, geo, tab, plan, res, small_args, stream);
+  if (dim == 3 && order == 1) return launch_t<3, 1>(b, ph, geo, tab, plan, res, small_args, stream);
+  if (dim == 3 && order == 2) return launch_t<3, 2>(b, ph, geo, tab, plan, res, small_args, stream);
   MHA_REQUIRE(false, MHA_ERR_INVALID, "thread-per-element residual kernel: unsupported (dim, order)");
 }
 

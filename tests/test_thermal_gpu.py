@@ -387,18 +387,32 @@ RO_CASES = [  # dim, order, qdeg, ncell
 ]
 
 
+def _select_k1(monkeypatch, k1):
+    """K1 forms (thermal_affine_residual.hip / thermal_row_owner.hip): wg = workgroup-merged (the default), morton = the
+    same with the elements grouped along a Morton curve, thread = one thread per element with global atomics, lanes =
+    32 lanes per element."""
+    if k1 in ("wg", "morton"):
+        monkeypatch.delenv("MHA_K1", raising=False)
+        monkeypatch.setenv("MHA_K1_ORDER", "morton" if k1 == "morton" else "natural")
+    else:
+        monkeypatch.setenv("MHA_K1", k1)
+
+
 @pytest.mark.parametrize("dim,order,qdeg,ncell", RO_CASES)
 @pytest.mark.parametrize("mode", ["accumulate", "overwrite"])
-@pytest.mark.parametrize("k2", ["blocks", "pattern"])
-def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, mode, k2):
-    """Fused row-owner kernel on affine (sheared) meshes vs the oracle: CRS values, residual, fixed rows.
+@pytest.mark.parametrize("k2,k1,shear", [("pattern", "wg", True), ("pattern", "wg", False), ("pattern", "morton", True),
+                                          ("pattern", "morton", False), ("pattern", "thread", True),
+                                          ("blocks", "lanes", True), ("blocks", "wg", False)])
+def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, mode, k2, k1, shear):
+    """Fused row-owner kernel on affine meshes (sheared: general source evaluation; axis-aligned: the separable one) vs
+    the oracle: CRS values, residual, fixed rows.
     k2 = pattern (the default): the Jacobian rows as block-pattern GEMMs on the matrix cores (block_pattern.hip);
     k2 = blocks: the LDS-accumulator row-block kernel (the fallback for meshes whose blocks do not group)."""
     torch = _torch()
     import mrhyde_amd
     monkeypatch.setenv("MHA_K2", k2)
-    monkeypatch.setenv("MHA_K1", "thread" if k2 == "pattern" else "lanes")  # K1: one thread / 32 lanes per element
-    m = affine_mesh(oracle, dim, order, ncell)
+    _select_k1(monkeypatch, k1)
+    m = affine_mesh(oracle, dim, order, ncell, shear=shear)
     rng = np.random.default_rng(21)
     u = rng.uniform(-1, 1, m["ndof"])
     fixed = m["boundary"]
@@ -439,12 +453,12 @@ def test_row_owner_matches_oracle(oracle, monkeypatch, dim, order, qdeg, ncell, 
     assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
 
 
-@pytest.mark.parametrize("k2", ["blocks", "pattern"])
-def test_row_owner_transient_and_source_array(oracle, monkeypatch, k2):
+@pytest.mark.parametrize("k2,k1", [("blocks", "lanes"), ("pattern", "thread"), ("pattern", "wg"), ("pattern", "morton")])
+def test_row_owner_transient_and_source_array(oracle, monkeypatch, k2, k1):
     torch = _torch()
     import mrhyde_amd
     monkeypatch.setenv("MHA_K2", k2)
-    monkeypatch.setenv("MHA_K1", "thread" if k2 == "pattern" else "lanes")  # K1: one thread / 32 lanes per element
+    _select_k1(monkeypatch, k1)
     dim, order, qdeg, ncell = 3, 2, 4, (3, 4, 3)
     m = affine_mesh(oracle, dim, order, ncell)
     rng = np.random.default_rng(23)
@@ -474,6 +488,61 @@ def test_row_owner_transient_and_source_array(oracle, monkeypatch, k2):
     torch.cuda.synchronize()
     assert crs_err(vals.cpu().numpy(), ref) < RTOL
     assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+
+
+@pytest.mark.parametrize("order_env", ["natural", "morton", None])
+@pytest.mark.parametrize("transient", [False, True])
+def test_merged_residual_kernel_on_a_shuffled_numbering(oracle, monkeypatch, order_env, transient):
+    """The workgroup-merged K1 takes 256 elements per workgroup through a host-made plan (distinct rows + 16-bit
+    positions).  Here: 3 workgroups (the last one partial), the elements renumbered at random (a group's rows then
+    spread over the whole mesh; with MHA_K1_ORDER unset the plan may regroup them along a Morton curve), axis-aligned
+    elements with the closed-form source (the separable evaluation), steady and transient."""
+    torch = _torch()
+    import mrhyde_amd
+    monkeypatch.delenv("MHA_K1", raising=False)
+    if order_env:
+        monkeypatch.setenv("MHA_K1_ORDER", order_env)
+    else:
+        monkeypatch.delenv("MHA_K1_ORDER", raising=False)
+    dim, order, qdeg, ncell = 3, 2, 4, (9, 8, 9)
+    m = affine_mesh(oracle, dim, order, ncell, shear=False)
+    rng = np.random.default_rng(77)
+    perm = rng.permutation(m["nelem"])
+    m["nodes"] = np.ascontiguousarray(m["nodes"][perm])
+    m["lids"] = np.ascontiguousarray(m["lids"][perm])
+    nd = m["ndof"]
+    u = rng.uniform(-1, 1, nd)
+    fixed = m["boundary"]
+    freq = [1.3, 0.7, 2.1]
+    kw = {}
+    if transient:
+        nsteps, nstages, stage = 2, 2, 1
+        A = np.array([[0.2928932188, 0.0], [0.7071067812, 0.2928932188]])
+        bb = np.array([0.7071067812, 0.2928932188])
+        bdf = np.array([1.5, -2.0, 0.5])
+        tr = dict(u_prev=rng.uniform(-1, 1, (nd, nsteps)), u_stage=rng.uniform(-1, 1, (nd, nstages)), stage=stage,
+                  butcher_A=A, butcher_b=bb, bdf=bdf, dt=0.02)
+        kw = dict(transient=tr, rho=1.3, cp=0.7)
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed,
+                                  source=("sinprod", 3.0, freq), diff=1.7, **kw)
+    blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+    blk.set_function("thermal source", ("sinprod", 3.0, freq))
+    blk.set_function("thermal diffusion", 1.7)
+    t = lambda a: torch.tensor(a, device="cuda")
+    res = torch.full((nd,), 7.0, dtype=torch.float64, device="cuda")
+    vals = torch.zeros(len(ref["colind"]), dtype=torch.float64, device="cuda")
+    if transient:
+        blk.set_function("density", 1.3)
+        blk.set_function("specific heat", 0.7)
+        blk.set_time_integration(True, nsteps, nstages, stage, 0.02, A, bb, bdf)
+        blk.assemble_jacres(t(u), res, vals, u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]),
+                            path=mrhyde_amd.PATH_ROW_OWNER, overwrite=True)
+    else:
+        blk.assemble_jacres(t(u), res, vals, path=mrhyde_amd.PATH_ROW_OWNER, overwrite=True)
+    torch.cuda.synchronize()
+    assert blk.info("num_affine_elems") == m["nelem"]
+    assert rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+    assert crs_err(vals.cpu().numpy(), ref) < RTOL
 
 
 def test_auto_path_selection(oracle):
