@@ -78,11 +78,14 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
       const double tc = (edge & 1) ? st.ip[(s * nqs + q) * DIM] : st.ip[(s * nqs + q) * DIM + 1];
       const double mu0 = 0.5 * (1.0 - tc), mu1 = 0.5 * (1.0 + tc);
       double S[3] = {0, 0, 0}, Sh[3];
+      int eo = edge * 2;
+      asm volatile("" : "+v"(eo));  // (a real per-lane address: left to itself the compiler reads all 24 trace values
+                                    //  into registers and selects -- 48 registers held through the flux evaluation)
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
 #pragma unroll
         for (int dof = 0; dof < 4; ++dof) S[i] += s_u[wv][i * 4 + dof] * st.basis[(s * 4 + dof) * nqs + q];
-        Sh[i] = s_l[wv][i * 8 + edge * 2] * mu0 + s_l[wv][i * 8 + edge * 2 + 1] * mu1;
+        Sh[i] = s_l[wv][i * 8 + eo] * mu0 + s_l[wv][i * 8 + eo + 1] * mu1;
       }
       const int stype = a.side_types ? a.side_types[(size_t)e * 4 + s] : 0;
       Dual dS[3], dSh[3], f[3];
@@ -113,12 +116,21 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
         xi[0] += nv * vx[k];
         xi[1] += nv * vy[k];
 #pragma unroll
-        for (int r = 0; r < DIM; ++r) {
-          x[r] += xn[k * DIM + r] * nv;
+        for (int r = 0; r < DIM; ++r) x[r] += xn[k * DIM + r] * nv;
+      }
+      // the source functions first, while nothing else is live (their closed forms are the largest code of the phase)
+      double src[3] = {0.0, 0.0, 0.0};
+      if (dir == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) src[i] = eval_func<DIM, false>(pp.f[i], e, q, nq, x);
+      }
+      asm volatile("" : "+v"(src[0]), "+v"(src[1]), "+v"(src[2]), "+v"(xi[0]), "+v"(xi[1]));
+#pragma unroll
+      for (int k = 0; k < NN; ++k)
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
 #pragma unroll
           for (int cc = 0; cc < DIM; ++cc) J[r * DIM + cc] += xn[k * DIM + r] * b.nodegrad[(k * nq + q) * DIM + cc];
-        }
-      }
       invert<DIM>(J, Ji, det);
       const double w = b.ref_wts[q] * det;
       // HGRAD order 1 in dof order (x fastest): N_a = (1 + sx xi)(1 + sy eta) / 4
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
         s_vw[wv][q] = w;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          s_vr[wv][q][i] = (Sd[i] - eval_func<DIM, false>(pp.f[i], e, q, nq, x)) * w;  // (v, dS/dt) - (v, source)
+          s_vr[wv][q][i] = (Sd[i] - src[i]) * w;  // (v, dS/dt) - (v, source)
           s_vr[wv][q][3 + i] = -F[i][0].v * w;                                           // -(dv/dx, F_x)
           s_vr[wv][q][6 + i] = -F[i][1].v * w;                                           // -(dv/dy, F_y)
         }
