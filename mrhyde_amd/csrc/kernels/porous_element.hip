@@ -75,11 +75,15 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
       for (int d = 0; d < DIM; ++d) xn[k][d] = sm[((active ? tid : 0) * NN + k) * DIM + d];
     __syncthreads();  // vertices are in registers: the buffer is reused for the results
   }
-  double A[NU][NU], Bv[NU], rp = 0.0, ru[NU];
+  // Orientation signs: v_i and div_i carry s_i, so res_{u,i} ~ s_i, A_ij ~ s_i s_j, and u_i enters as s_i u_i.  The
+  // point loop works on the unsigned basis with us_i = s_i u_i and the signs are applied once at the end.  The
+  // divergence terms need no quadrature at all: div_i w = s_i (+-1/2) / detJ * (w_ref detJ) = s_i (+-1/2) w_ref, so
+  //   Bv_i = -s_i (+-1/2) sum_q w_ref,  sum_q div u w = (sum_i us_i (+-1/2)) sum_q w_ref.
+  double A[NU][NU], rp = 0.0, ru[NU], us[NU], wsum = 0.0;
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
-    Bv[i] = 0.0;
     ru[i] = 0.0;
+    us[i] = u[1 + i] * sg[1 + i];
 #pragma unroll
     for (int j = 0; j < NU; ++j) A[i][j] = 0.0;
   }
@@ -100,54 +104,66 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
       x[r] = s;
     }
     invert<DIM>(J, Ji, det);
-    // reference point from the geometry basis of the vertex with all +1 signs: N_k = prod (1 + s x)/2 -> use the
-    // u table instead: phihat_{2c+1}(q) = (1 + x_c)/2
+    // reference point from the u table: phihat_{2c+1}(q) = (1 + x_c)/2
     const double *Tu = vl.tables + vl.table_off[1] + (size_t)q * (DIM + 1) * vl.cardpad[1];
 #pragma unroll
     for (int c = 0; c < DIM; ++c) xi[c] = 2.0 * Tu[c * vl.cardpad[1] + 2 * c + 1] - 1.0;
-    const double w = b.ref_wts[q] * det, rdet = 1.0 / det;
+    const double wr = b.ref_wts[q], w = wr * det, rdet = 1.0 / det;
+    wsum += wr;
     const double src = eval_func<DIM, EXPR>(pp.f[0], e, q, NQ, x), mob = eval_func<DIM, EXPR>(pp.f[4], e, q, NQ, x);
     const double rmob = 1.0 / mob;  // one division per point instead of fifteen
     double kinv[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) kinv[d] = eval_func<DIM, EXPR>(pp.f[1 + d], e, q, NQ, x);
-    // v_i = sg_i * ph_i * J[:,c_i] / det, div_i = sg_i * (+-1/2) / det
-    double ph[NU], dv[NU], uq[DIM], divu = 0.0;
+    rp += src * w;
+    // unsigned basis: v_i = ph_i J[:,c_i], ph_i = (1 -/+ xi_c)/2 / det
+    double ph[NU], uq[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) uq[d] = 0.0;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int c = i >> 1;
-      ph[i] = sg[1 + i] * ((i & 1) ? 0.5 * (1.0 + xi[c]) : 0.5 * (1.0 - xi[c])) * rdet;
-      dv[i] = sg[1 + i] * ((i & 1) ? 0.5 : -0.5) * rdet;
-      divu += u[1 + i] * dv[i];
+      ph[i] = ((i & 1) ? 0.5 * (1.0 + xi[c]) : 0.5 * (1.0 - xi[c])) * rdet;
 #pragma unroll
-      for (int d = 0; d < DIM; ++d) uq[d] += u[1 + i] * ph[i] * J[d * DIM + c];
+      for (int d = 0; d < DIM; ++d) uq[d] += us[i] * ph[i] * J[d * DIM + c];
     }
-    rp += (src - divu) * w;
-    // M[c][c'] = sum_d J[d][c] kinv_d J[d][c'] / mobility
-    double M[DIM][DIM];
+    // M[c][c'] = sum_d J[d][c] kinv_d J[d][c'] / mobility * w (symmetric), ku[c] = sum_d kinv_d uq_d J[d][c] / mobility * w
+    const double wm = w * rmob;
+    double M[DIM][DIM], ku[DIM];
 #pragma unroll
-    for (int c = 0; c < DIM; ++c)
+    for (int c = 0; c < DIM; ++c) {
+      double t = 0.0;
 #pragma unroll
-      for (int c2 = 0; c2 < DIM; ++c2) {
+      for (int d = 0; d < DIM; ++d) t += kinv[d] * uq[d] * J[d * DIM + c];
+      ku[c] = t * wm;
+#pragma unroll
+      for (int c2 = c; c2 < DIM; ++c2) {
         double s = 0.0;
 #pragma unroll
         for (int d = 0; d < DIM; ++d) s += J[d * DIM + c] * kinv[d] * J[d * DIM + c2];
-        M[c][c2] = s * rmob;
+        M[c][c2] = s * wm;
       }
+    }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int c = i >> 1;
-      double kuv = 0.0;
+      ru[i] += ku[c] * ph[i];
 #pragma unroll
-      for (int d = 0; d < DIM; ++d) kuv += kinv[d] * uq[d] * J[d * DIM + c];
-      ru[i] += (kuv * ph[i] * rmob - u[0] * dv[i]) * w;
-      Bv[i] -= dv[i] * w;
-#pragma unroll
-      for (int j = i; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1] * w;  // symmetric: upper triangle only
+      for (int j = i; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1];  // symmetric: upper triangle only (c <= j >> 1)
     }
   }
+  // signs and the divergence terms
+  double Bv[NU], divu = 0.0;
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const double hs = (i & 1) ? 0.5 : -0.5;
+    divu += us[i] * hs;
+    Bv[i] = -sg[1 + i] * hs * wsum;
+    ru[i] = sg[1 + i] * (ru[i] - u[0] * hs * wsum);
+#pragma unroll
+    for (int j = i; j < NU; ++j) A[i][j] *= sg[1 + i] * sg[1 + j];
+  }
+  rp -= divu * wsum;
   const double au = tm.alpha_u;
   if constexpr (DOF) {
     // dof order, stored (the row-gather scratch is never accumulated into): residual [p, u_0..], matrix rows [p | u_i]
@@ -202,13 +218,16 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
   }
 }
 
-// The plain-coefficient instantiations are held to 256 registers (two wavefronts per SIMD; left alone the compiler takes
-// ~310 and runs one); the deck-string ones call the interpreter and keep the default budget.
+// The plain-coefficient instantiations are held to two wavefronts per SIMD (243 registers, no spills since the signs and
+// the divergence terms left the point loop; three would need 168 and spill 240 B per lane -- tried with the constant
+// coefficients compiled in, and with the point's stages fenced: no better); the deck-string ones call the interpreter
+// and keep the default budget.
 template <int DIM, bool DOF>
 __global__ __launch_bounds__(kPorousThreads) __attribute__((amdgpu_waves_per_eu(2))) void porous_element_kernel(
     BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm, ElemOut out) {
   porous_element_body<DIM, false, DOF>(b, vl, pp, tm, out);
 }
+
 template <int DIM, bool DOF>
 __global__ __launch_bounds__(kPorousThreads) void porous_element_expr_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
                                                                             TimeDev tm, ElemOut out) {
