@@ -285,7 +285,8 @@ __global__ __launch_bounds__(kK1wThreads, (TR || EXPR || !SEPK) ? 2 : 3) void th
   const AffineTables1D &tab = *tabp;
   constexpr int M = P + 1, N = cpow(M, DIM);
   extern __shared__ double s_tab[];  // [max_rows] seeded u, then the accumulated -r; TR: [max_rows] u_dot behind it;
-                                     // then [max_rows] ints: the listed rows (~row = fixed), kept for E
+                                     // then [max_rows] ints: the listed rows (~row = fixed), kept for E; then
+                                     // [N][threads] 16-bit positions, kept for D
   int *s_row = reinterpret_cast<int *>(s_tab + (TR ? 2 : 1) * pl.max_rows);
   const int tid = threadIdx.x;
   const int g = blockIdx.x;
@@ -293,6 +294,13 @@ __global__ __launch_bounds__(kK1wThreads, (TR || EXPR || !SEPK) ? 2 : 3) void th
   const bool active = g * kK1wThreads + tid < b.e_count;
   const int e = pl.wg_elems[g * kK1wThreads + tid];
   const TimeDev &tm = ph.time;
+  // the positions of this thread's dofs: requested first, used after the barrier (their latency runs under phase A)
+  int kpos[N];
+  {
+    const uint16_t *loc = pl.loc + (size_t)g * N * kK1wThreads + tid;
+#pragma unroll
+    for (int ib = 0; ib < N; ++ib) kpos[ib] = loc[ib * kK1wThreads];
+  }
   // ---- A. performGather + computeSoln*Seeded values (workset.cpp:589-623), once per listed row ----
   // (four rows per thread and pass, every load of a stage issued before the first use: the loop would otherwise run its
   //  dependent loads -- row id, then value -- one row at a time)
@@ -349,14 +357,15 @@ __global__ __launch_bounds__(kK1wThreads, (TR || EXPR || !SEPK) ? 2 : 3) void th
       if (r != c && grec[kGeoJ + r * DIM + c] != 0.0) separable = false;
   }
   __syncthreads();
-  // ---- B. nodal values of this thread's element, basis (tensor) order ----
-  const uint16_t *loc = pl.loc + (size_t)g * N * kK1wThreads + tid;
+  // ---- B. nodal values of this thread's element, basis (tensor) order; the positions are parked in LDS for D ----
+  uint16_t *s_loc = reinterpret_cast<uint16_t *>(s_row + pl.max_rows) + tid;  // [N][threads]
   double U[N], Ud[TR ? N : 1];
 #pragma unroll
   for (int ib = 0; ib < N; ++ib) {
-    const int k = loc[ib * kK1wThreads];
+    const int k = kpos[ib];
     U[ib] = s_tab[k];
     if constexpr (TR) Ud[ib] = s_tab[pl.max_rows + k];
+    s_loc[ib * kK1wThreads] = (uint16_t)k;
   }
   __syncthreads();
   for (int i = tid; i < nr; i += kK1wThreads) s_tab[i] = 0.0;  // (the barrier before D orders this against the adds)
@@ -453,10 +462,8 @@ __global__ __launch_bounds__(kK1wThreads, (TR || EXPR || !SEPK) ? 2 : 3) void th
   __syncthreads();
   // ---- D. the global vector receives -res.val() (assemblyManager.cpp:4075, 4094): met in LDS first ----
   if (active) {
-    const uint16_t *loc2 = loc;
-    asm volatile("" : "+v"(loc2));  // (the addresses are formed here, not carried through C in registers)
 #pragma unroll
-    for (int ib = 0; ib < N; ++ib) atomicAdd(&s_tab[loc2[ib * kK1wThreads]], -W[ib]);
+    for (int ib = 0; ib < N; ++ib) atomicAdd(&s_tab[s_loc[ib * kK1wThreads]], -W[ib]);
   }
   __syncthreads();
   // ---- E. one atomic per listed row, fixed rows skipped; the row ids come from LDS (a load from memory here would be
@@ -496,7 +503,7 @@ void launch_t(const BlockDev &b, const ThermalDev &ph, const double *geo, const 
     MHA_REQUIRE(b.e_begin == 0 && b.e_count == plan->num_elems, MHA_ERR_INVALID, "K1 plan: element range mismatch");
     const int grid = (b.e_count + kK1wThreads - 1) / kK1wThreads;
     const bool tr = ph.time.transient != 0;
-    const size_t lds = sizeof(double) * (size_t)plan->max_rows * (tr ? 2 : 1) + sizeof(int) * (size_t)plan->max_rows;
+    const size_t lds = sizeof(double) * (size_t)plan->max_rows * (tr ? 2 : 1) + sizeof(int) * (size_t)plan->max_rows + sizeof(uint16_t) * cpow(P + 1, DIM) * kK1wThreads;
     auto go = [&](auto kern) {
       if (lds > 64 * 1024) MHA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, dim3(grid), dim3(kK1wThreads), lds, stream, b, ph, geo, tab, *plan, res, dbg_wg);
