@@ -234,6 +234,10 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
     const int vrowC = (relrow >= 0 && i < c.nblocks && !(DBG & 2)) ? (c.sbase[ic * c.nruns + (max(relrow, 0) >> 20)] + (relrow & 0xfffff)) * 8 : -1;
     lds_barrier();  // block i's records are in place; every wavefront has issued the stores of block i - 2
     asm volatile("" ::: "memory");  // (the LDS has changed: without this a wavefront that does not write it hoists all its W reads out of the loop, 112 registers)
+    // markers for csrc/check_store_count.awk (run by the Makefile on the kernel's ISA): between the two comments of a
+    // loader instantiation there must be exactly STORES (+ 4 with the straddle form) buffer_store instructions -- the
+    // counted wait below retires the record loads by leaving that many younger operations in flight
+    if constexpr (loader) asm volatile("; MHA_LOADER_ITER stores=%0" ::"n"(STORES));
     const double *rec = c.recbuf + (i & 1) * c.recstride;
     v4d acc[NQ];
 #pragma unroll
@@ -299,6 +303,7 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, const int32_t *__rest
       // block i + 1's records (requested one iteration ago) into the other buffer -- last read during block i - 1, and
       // everybody has passed this iteration's barrier since; this iteration's stores stay in flight.  Then request
       // block i + 2's into the same registers.
+      asm volatile("; MHA_LOADER_WAIT stores=%0" ::"n"(STORES));
       asm_wait_vmcnt<STORES>();
       deposit(Rc, c.recbuf + ((i + 1) & 1) * c.recstride);
       fetch(i + 2, Rc);
