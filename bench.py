@@ -374,7 +374,7 @@ def setup_block(kind, args, torch, mrhyde_amd, rank, world, dev):
 
     def info():
         pname = {4: "point_engine", 5: "row_gather"}.get(blk.info("last_path"), str(blk.info("last_path")))
-        kern = ("porous_element_kernel (dense element arrays) + row_gather_kernel" if kind == "porous"
+        kern = (("porous_element_direct_kernel (element threads store into the CRS) + porous_direct_finish_kernel" if blk.info("porous_direct") else "porous_element_kernel (dense element arrays) + row_gather_kernel") if kind == "porous"
                 else "point_engine_kernel<3, navierstokes> (dense element matrices) + row_gather_kernel")
         return pname, kern, {}
 

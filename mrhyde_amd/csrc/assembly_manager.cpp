@@ -196,7 +196,7 @@ void AssemblyManager::setOrientation(const int8_t *signs) {
   db_index_.clear();
 }
 
-void AssemblyManager::prepareRowGather(bool need_jacobian) {
+void AssemblyManager::prepareRowGather(bool need_jacobian, bool dense) {
   if (!has_incidence_) {
     std::vector<int32_t> ptr, elem, lpos;
     build_row_incidence(nrows_, nelem_, n_, h_lids_.data(), ptr, elem, lpos);
@@ -214,8 +214,59 @@ void AssemblyManager::prepareRowGather(bool need_jacobian) {
     has_incidence_ = true;
   }
   prepareElemSlots();
+  if (!dense) return;  // (the direct form of porousMixed needs the incidences and the slot map only)
   if (need_jacobian) d_gather_J_.resize(static_cast<size_t>(nelem_) * n_ * n_);
   d_gather_res_.resize(static_cast<size_t>(nelem_) * n_);
+}
+
+// The direct form of the porousMixed assembly (kernels/porous_element.hip) rests on one property of the mesh: any two
+// elements share at most ONE dof (a face), so that a matrix entry (i, j), i != j, has one contributing element and a
+// row at most two.  Checked here on the LID lists, once per mesh / graph; anything else keeps the row gather.
+bool AssemblyManager::porousDirectUsable() {
+  if (porous_direct_ >= 0) return porous_direct_ == 1;
+  porous_direct_ = 0;
+  const char *m = std::getenv("MHA_POROUS_DIRECT"), *k = std::getenv("MHA_POROUS_KERNEL"), *g = std::getenv("MHA_GATHER_ORDER");
+  if (m && m[0] == '0') { porous_direct_why_ = "MHA_POROUS_DIRECT=0"; return false; }
+  if ((k && k[0] == 'e') || (g && g[0] == 'p')) { porous_direct_why_ = "point engine / position order forced"; return false; }
+  if (!physics_ || physics_->label != "porousMixed" || n_ != 1 + 2 * dim_) { porous_direct_why_ = "not the lowest-order mixed element"; return false; }
+  std::vector<int32_t> ptr, elem, lpos;
+  build_row_incidence(nrows_, nelem_, n_, h_lids_.data(), ptr, elem, lpos);
+  for (int r = 0; r < nrows_; ++r) {
+    const int ni = ptr[r + 1] - ptr[r];
+    if (ni > 2) { porous_direct_why_ = "a row with more than two incident elements"; return false; }
+    if (ni == 2) {
+      const int32_t *a = &h_lids_[static_cast<size_t>(elem[ptr[r]]) * n_], *b = &h_lids_[static_cast<size_t>(elem[ptr[r] + 1]) * n_];
+      int shared = 0;
+      for (int i = 0; i < n_; ++i)
+        for (int j = 0; j < n_; ++j) shared += a[i] == b[j];
+      if (shared != 1) { porous_direct_why_ = "two elements share more than one dof"; return false; }
+    }
+  }
+  for (int e = 0; e < nelem_; ++e)  // (an element listing a dof twice would add twice into one entry)
+    for (int i = 0; i < n_; ++i)
+      for (int j = i + 1; j < n_; ++j)
+        if (h_lids_[static_cast<size_t>(e) * n_ + i] == h_lids_[static_cast<size_t>(e) * n_ + j]) { porous_direct_why_ = "repeated dof in an element"; return false; }
+  // which incidence of its row an element is (dof order), and where the diagonal of a face row sits in the CRS
+  std::vector<int32_t> offs(n_), p2d(n_, 0);
+  d_offsets_.download(offs.data());
+  for (int f = 0; f < n_; ++f) p2d[offs[f]] = f;
+  std::vector<uint8_t> side(static_cast<size_t>(nelem_) * n_, 0);
+  std::vector<int32_t> diag(nrows_, -1);
+  for (int r = 0; r < nrows_; ++r) {
+    bool face = false;
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+      const int d = p2d[lpos[k]];
+      side[static_cast<size_t>(elem[k]) * n_ + d] = static_cast<uint8_t>(k - ptr[r]);
+      face = face || d > 0;
+    }
+    if (face)
+      for (int k = h_rowptr_[r]; k < h_rowptr_[r + 1]; ++k)
+        if (h_colind_[k] == r) diag[r] = k;
+  }
+  d_direct_side_.upload(side);
+  d_direct_diag_.upload(diag);
+  porous_direct_ = 1;
+  return true;
 }
 
 void AssemblyManager::launchPointEngine(int compute_jacobian, const ElemOut &out, int e_begin, int e_count) {
@@ -258,6 +309,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   gro_ = GeneralRowOwnerData();
   has_elem_slot_ = false;
   has_incidence_ = false;
+  porous_direct_ = -1;
 }
 
 void AssemblyManager::selectPhysics(int physics_id) {
@@ -500,7 +552,10 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
   MHA_REQUIRE(!deterministic || row_owner_kind == 1, MHA_ERR_INVALID,
               "MHA_ASSEMBLE_DETERMINISTIC is available on the affine row-owner path (thermal, affine elements, constant "
               "coefficients; MHA_PATH_AUTO or MHA_PATH_ROW_OWNER)");
-  if (path == MHA_PATH_ROW_GATHER) prepareRowGather(compute_jacobian != 0);
+  // porousMixed behind MHA_PATH_ROW_GATHER: the direct form (element threads store into the CRS, a finishing pass sums
+  // residual and diagonal parts) whenever the mesh allows it and no scatter option asks for the dense matrices
+  const bool porous_direct = path == MHA_PATH_ROW_GATHER && engineOnly() && !adjoint && !lump_mass && porousDirectUsable();
+  if (path == MHA_PATH_ROW_GATHER) prepareRowGather(compute_jacobian != 0, !porous_direct);
   timedBegin();
   if (overwrite && path != MHA_PATH_ROW_GATHER && !(path == MHA_PATH_ROW_OWNER && ro_all_rows)) {
     // the accumulate-only kernels get the fused zeroing as an explicit memset on the same stream
@@ -559,6 +614,22 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
         // block with a wider caller graph or 16-bit slots keeps the position order instead of failing)
         dof_order = !by_pos && !adjoint && !lump_mass && physics_->label == "porousMixed" && max_row_ <= 32 && n_ <= 16 &&
                     elem_slot_bytes_ == 1;
+        if (porous_direct && elem_slot_bytes_ == 1) {
+          d_direct_part_.resize(static_cast<size_t>(nrows_) * 4);
+          o.local_J = nullptr;
+          o.local_res = nullptr;
+          o.direct_part = d_direct_part_.data();
+          o.direct_slot = static_cast<const uint8_t *>(d_elem_slot_.data());
+          o.direct_side = d_direct_side_.data();
+          o.direct_vals = compute_jacobian ? crs_vals : nullptr;
+          o.direct_overwrite = overwrite ? 1 : 0;
+          launchPointEngine(compute_jacobian, o, 0, nelem_);
+          launch_porous_direct_finish(blockDev(), d_inc_ptr_.data(), d_direct_diag_.data(), o.direct_part, res, o.direct_vals,
+                                      overwrite ? 1 : 0, stream_);
+          last_porous_direct_ = 1;
+          break;
+        }
+        last_porous_direct_ = 0;
         o.local_dof_order = dof_order ? 1 : 0;
         launchPointEngine(compute_jacobian, o, 0, nelem_);
       }
@@ -2119,6 +2190,7 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "dofs_per_elem") return n_;
   if (key == "num_ip") return nq_;
   if (key == "last_path") return last_path_;
+  if (key == "porous_direct") return last_porous_direct_;  // the last row-gather assembly of a porousMixed block stored straight into the CRS
   if (key == "workset_size") return wkset_.maxElem;
   if (key == "row_blocks") return ro_.ready ? ro_.rb.num_blocks : 0;
   if (key == "row_owner_kind") return last_row_owner_kind_;  // of the last assembly: 1 affine kernels, 2 general-element kernel

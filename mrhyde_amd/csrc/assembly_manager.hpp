@@ -129,9 +129,16 @@ class AssemblyManager {
   // row-gather path: row -> (element, position) incidences on the device, full-block dense scratch
   DeviceBuffer<int32_t> d_inc_ptr_, d_inc_elem_, d_inc_pos_, d_inc_dof_;
   DeviceBuffer<double> d_gather_J_, d_gather_res_;
+  // porousMixed direct form (ElemOut::direct_*): -1 not decided, 0 no (why in porous_direct_why_), 1 yes
+  int porous_direct_ = -1, last_porous_direct_ = 0;
+  std::string porous_direct_why_;
+  DeviceBuffer<double> d_direct_part_;   // [nrows][2][2]
+  DeviceBuffer<uint8_t> d_direct_side_;  // [E][n] (dof order): which incidence of its row the element is
+  DeviceBuffer<int32_t> d_direct_diag_;  // [nrows] CRS position of the diagonal of a face row, -1 otherwise
+  bool porousDirectUsable();
   bool has_incidence_ = false;
   int max_row_ = 0;
-  void prepareRowGather(bool need_jacobian);
+  void prepareRowGather(bool need_jacobian, bool dense = true);
   void launchPointEngine(int compute_jacobian, const ElemOut &out, int e_begin, int e_count);
   int nelem_ = 0, nrows_ = 0, workset_size_ = 0;
   bool has_mesh_ = false, has_graph_ = false;

@@ -80,6 +80,16 @@ struct ElemOut {
   double *local_res = nullptr;  // [E][n]      (updateRes convention, -=)
   double *res = nullptr;        // [nrows]     atomic scatter of -res.val()
   double *crs_vals = nullptr;   // [nnz]       atomic scatter of +res.dx()
+  // porousMixed direct form (kernels/porous_element.hip): the element thread stores its matrix entries straight into
+  // the CRS through the element-major slot map -- on a conforming lowest-order mixed mesh two elements share exactly one
+  // dof, so every entry but the diagonal of a face row has ONE contributor -- and leaves its residual entry and its
+  // diagonal part of every row in that row's record direct_part[nrows][2][2] (slot direct_side[e][dof] = 0 or 1: which
+  // of the row's incident elements this one is) for the finishing pass over the rows
+  double *direct_part = nullptr;
+  const uint8_t *direct_side = nullptr; // [E][n] (dof order)
+  double *direct_vals = nullptr;        // CRS values (null: residual only)
+  const uint8_t *direct_slot = nullptr; // [E][n][n] position of column LIDs[e][j] inside row LIDs[e][i] (LID-position order)
+  int direct_overwrite = 0;
 };
 
 // Row-block partition on the device (row_blocks.hpp).

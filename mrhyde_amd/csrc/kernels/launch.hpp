@@ -114,6 +114,11 @@ void launch_porous_boundary(const BlockDev &b, const SideTablesDev &st, const Bo
 // porous_element.hip: porousMixed volume terms, one thread per element, dense element arrays out
 void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
                            const ElemOut &out, hipStream_t stream);
+// finishing pass of the direct form: one thread per row sums the (residual, diagonal) parts its incident elements left
+// in the row's record part[nrows][2][2]; diagpos[row] = CRS position of the diagonal of a face row, -1 otherwise; fixed
+// rows are zeroed when overwriting
+void launch_porous_direct_finish(const BlockDev &b, const int32_t *inc_ptr, const int32_t *diagpos, const double *part,
+                                 double *res, double *vals, int overwrite, hipStream_t stream);
 
 // row_gather.hip: CRS rows summed from dense element matrices, no global atomics
 void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *local_J, const double *local_res,

@@ -9,7 +9,11 @@
 // with v_i = s_i J phihat_i / detJ, div_i = s_i divhat_i / detJ (HDIVtransformVALUE / DIV,
 // discretizationInterface.cpp:1019,1053; s_i the orientation sign), phihat_{2c+h} = (1 -/+ x_c)/2 e_c.
 // Output: dense local_J / local_res in LID-position order (updateJac / updateRes convention), from which
-// kernels/row_gather.hip builds the CRS rows.  Same gather / seeding conventions as the point engine.
+// kernels/row_gather.hip builds the CRS rows -- or (DIRECT, round 3, the default of the assembly) straight into the CRS:
+// two elements of a conforming lowest-order mixed mesh share exactly one dof, so every matrix entry except the diagonal
+// of a face row has ONE contributing element and is stored by that element's thread through the element-major slot
+// map; its residual entry and diagonal part of each row go into that row's 4-double record (two incident elements),
+// which a finishing pass (one thread per row, coalesced) turns into the residual entry and the diagonal entry.  No dense element matrices (784 B per element written and read back), no second pass over the matrix.  Same gather / seeding conventions as the point engine.
 // A thread's 24 vertex coordinates and 56 results are contiguous per ELEMENT, i.e. 192 / 392 bytes apart between
 // lanes.  Two forms: (DOF = false, the public updateJac / updateRes arrays) the workgroup's 128 elements are staged through
 // LDS and move to and from memory as flat, fully coalesced arrays in LID-position order -- 448 B of LDS per thread, i.e.
@@ -29,7 +33,7 @@ namespace {
 
 constexpr int kPorousThreads = 128;
 
-template <int DIM, bool EXPR, bool DOF>
+template <int DIM, bool EXPR, bool DOF, bool DIRECT = false>
 __device__ __forceinline__ void porous_element_body(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp,
                                                     const TimeDev &tm, const ElemOut &out) {
   constexpr int NN = 1 << DIM, NU = 2 * DIM, N = 1 + NU;
@@ -165,6 +169,40 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
   }
   rp -= divu * wsum;
   const double au = tm.alpha_u;
+  if constexpr (DIRECT) {
+    // straight into the CRS: every entry this element owns alone (all but the diagonals of its face rows); residual
+    // entries and diagonal parts go to the side array the finishing pass sums per row (ElemOut::direct_*)
+    if (active) {
+      const uint8_t *side = out.direct_side + (size_t)e * N;
+      const bool jac = out.direct_vals && out.compute_jacobian;
+      const uint8_t *sl = out.direct_slot + (size_t)e * N * N;
+      double *vals = out.direct_vals;
+      const bool ow = out.direct_overwrite != 0;
+#pragma unroll
+      for (int fi = 0; fi < N; ++fi) {
+        const int row = L[pos[fi]];
+        // the row's record: {residual part, diagonal part} of incident element 0, then of element 1
+        double2 rec;
+        rec.x = fi == 0 ? -rp : -ru[fi - 1];
+        rec.y = (fi > 0 && jac) ? au * A[fi - 1][fi - 1] : 0.0;
+        *reinterpret_cast<double2 *>(out.direct_part + (size_t)row * 4 + side[fi] * 2) = rec;
+        if (!jac || (b.fixed && b.fixed[row])) continue;
+        double *rowv = vals + b.rowptr[row];
+        const uint8_t *srow = sl + pos[fi] * N;
+#pragma unroll
+        for (int fj = 0; fj < N; ++fj) {
+          if (fi == fj && fi > 0) continue;  // the diagonal of a face row has two contributors: finishing pass
+          double v;
+          if (fi == 0) v = fj == 0 ? 0.0 : au * Bv[fj - 1];
+          else if (fj == 0) v = au * Bv[fi - 1];
+          else v = au * (fj > fi ? A[fi - 1][fj - 1] : A[fj - 1][fi - 1]);
+          double *dst = rowv + srow[pos[fj]];
+          *dst = ow ? v : *dst + v;
+        }
+      }
+    }
+    return;
+  }
   if constexpr (DOF) {
     // dof order, stored (the row-gather scratch is never accumulated into): residual [p, u_0..], matrix rows [p | u_i]
     if (active) {
@@ -233,6 +271,40 @@ __global__ __launch_bounds__(kPorousThreads) void porous_element_expr_kernel(Blo
                                                                             TimeDev tm, ElemOut out) {
   porous_element_body<DIM, true, DOF>(b, vl, pp, tm, out);
 }
+template <int DIM>
+__global__ __launch_bounds__(kPorousThreads) __attribute__((amdgpu_waves_per_eu(2))) void porous_element_direct_kernel(
+    BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm, ElemOut out) {
+  porous_element_body<DIM, false, true, true>(b, vl, pp, tm, out);
+}
+template <int DIM>
+__global__ __launch_bounds__(kPorousThreads) void porous_element_direct_expr_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
+                                                                                   TimeDev tm, ElemOut out) {
+  porous_element_body<DIM, true, true, true>(b, vl, pp, tm, out);
+}
+
+// finishing pass of the direct form, one thread per row: coalesced reads of the row records, one residual entry and
+// (face rows) one diagonal entry out
+__global__ __launch_bounds__(256) void porous_direct_finish_kernel(BlockDev b, const int32_t *__restrict__ inc_ptr,
+                                                                   const int32_t *__restrict__ diagpos,
+                                                                   const double *__restrict__ part, double *res, double *vals,
+                                                                   int overwrite) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= b.nrows) return;
+  const int ni = inc_ptr[row + 1] - inc_ptr[row];
+  const double4 rec = reinterpret_cast<const double4 *>(part)[row];
+  const int dp = diagpos[row];  // < 0: a cell row (the element stored its zero diagonal itself) or no diagonal in the graph
+  if (b.fixed && b.fixed[row]) {  // isFixedDOF rows are skipped by the scatter; overwriting leaves zeros
+    if (overwrite) {
+      if (vals) for (int k = b.rowptr[row]; k < b.rowptr[row + 1]; ++k) vals[k] = 0.0;
+      if (res) res[row] = 0.0;
+    }
+    return;
+  }
+  const double r = (ni > 0 ? rec.x : 0.0) + (ni > 1 ? rec.z : 0.0);
+  const double dg = (ni > 0 ? rec.y : 0.0) + (ni > 1 ? rec.w : 0.0);
+  if (res) res[row] = overwrite ? r : res[row] + r;
+  if (vals && dp >= 0) vals[dp] = overwrite ? dg : vals[dp] + dg;
+}
 
 }  // namespace
 
@@ -243,6 +315,15 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
               "porous element kernel writes dense element arrays only");
   const int grid = (b.e_count + kPorousThreads - 1) / kPorousThreads;
   const int n = 1 + 2 * b.dim;
+  if (out.direct_part) {  // direct form: no dense arrays
+    MHA_REQUIRE(out.direct_slot != nullptr && out.direct_side != nullptr && out.local_base == 0, MHA_ERR_INVALID, "porous direct form: slot map missing");
+    const size_t ldsd = sizeof(double) * kPorousThreads * (size_t)(1 << b.dim) * b.dim;
+    auto god = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kPorousThreads), ldsd, stream, b, vl, pp, tm, out); };
+    if (has_expression(pp)) { if (b.dim == 2) god(porous_element_direct_expr_kernel<2>); else god(porous_element_direct_expr_kernel<3>); }
+    else { if (b.dim == 2) god(porous_element_direct_kernel<2>); else god(porous_element_direct_kernel<3>); }
+    MHA_HIP(hipGetLastError());
+    return;
+  }
   const bool dof = out.local_dof_order != 0;
   MHA_REQUIRE(!dof || out.local_store, MHA_ERR_INVALID, "dof-ordered element arrays are stored, never accumulated into");
   const size_t lds = dof ? sizeof(double) * kPorousThreads * (size_t)(1 << b.dim) * b.dim : sizeof(double) * kPorousThreads * std::max<size_t>((size_t)(1 << b.dim) * b.dim, (size_t)n * n + n);
@@ -255,6 +336,14 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
   };
   if (b.dim == 2) { if (dof) pick(std::integral_constant<int, 2>(), std::true_type()); else pick(std::integral_constant<int, 2>(), std::false_type()); }
   else { if (dof) pick(std::integral_constant<int, 3>(), std::true_type()); else pick(std::integral_constant<int, 3>(), std::false_type()); }
+  MHA_HIP(hipGetLastError());
+}
+
+void launch_porous_direct_finish(const BlockDev &b, const int32_t *inc_ptr, const int32_t *diagpos, const double *part,
+                                 double *res, double *vals, int overwrite, hipStream_t stream) {
+  if (b.nrows <= 0) return;
+  hipLaunchKernelGGL(porous_direct_finish_kernel, dim3((b.nrows + 255) / 256), dim3(256), 0, stream, b, inc_ptr, diagpos, part,
+                     res, vals, overwrite);
   MHA_HIP(hipGetLastError());
 }
 

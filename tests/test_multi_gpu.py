@@ -145,6 +145,54 @@ def test_porous_mixed_matches_oracle(oracle, dim, ncell):
     assert crs_err(out["crs_vals2"], ref) < RTOL and rel_err(out["res2"], ref["res"]) < RTOL
 
 
+@pytest.mark.parametrize("dim,ncell", [(2, (6, 5)), (3, (4, 3, 5))])
+@pytest.mark.parametrize("transient", [False, True])
+def test_porous_direct_form_equals_row_gather_and_oracle(oracle, monkeypatch, dim, ncell, transient):
+    """porousMixed behind MHA_PATH_ROW_GATHER / AUTO: by default the element threads store their matrix entries straight
+    into the CRS (two elements share one dof: only the diagonal of a face row has two contributors) and a finishing
+    pass sums the residual and diagonal parts per row; MHA_POROUS_DIRECT=0 keeps dense element arrays + the row gather.
+    Both against the oracle and each other: fixed rows, overwrite on garbage, accumulate, residual only."""
+    torch = _torch()
+    import mrhyde_amd
+    rng = np.random.default_rng(61)
+    m = warp(oracle.mesh_multi(dim, ncell, [oracle.HVOL, oracle.HDIV], [0, 1]))
+    u = rng.uniform(-1, 1, m["ndof"])
+    fixed = (rng.uniform(size=m["ndof"]) < 0.1).astype(np.uint8)
+    funcs = {"source": ("sinprod", 2.0, [1.1, 0.7, 1.9][:dim]), "Kinv_xx": 1.3, "Kinv_yy": 0.7, "Kinv_zz": 2.1,
+             "total_mobility": 1.9}
+    tr = transient_state(rng, m["ndof"], u) if transient else None
+    ref = oracle.assemble_block(m, oracle.PHYS_POROUS_MIXED, 2, u, funcs=funcs, transient=tr, fixed=fixed)
+    results = {}
+    for direct in (True, False):
+        if direct:
+            monkeypatch.delenv("MHA_POROUS_DIRECT", raising=False)
+        else:
+            monkeypatch.setenv("MHA_POROUS_DIRECT", "0")
+        blk = make_block(m, "porousMixed", 2, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+        for k, v in funcs.items():
+            blk.set_function(k, v)
+        kw = {}
+        if tr is not None:
+            blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+            kw = dict(u_prev=torch.tensor(tr["u_prev"], device="cuda"), u_stage=torch.tensor(tr["u_stage"], device="cuda"))
+        ud = torch.tensor(u, device="cuda")
+        res = torch.full((m["ndof"],), 7.0, dtype=torch.float64, device="cuda")
+        vals = torch.full((len(ref["colind"]),), -3.0, dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(ud, res, vals, overwrite=True, **kw)  # AUTO
+        torch.cuda.synchronize()
+        assert blk.info("last_path") == mrhyde_amd.PATH_ROW_GATHER and blk.info("porous_direct") == (1 if direct else 0)
+        r1, v1 = res.cpu().numpy().copy(), vals.cpu().numpy().copy()
+        assert rel_err(r1, ref["res"]) < RTOL and crs_err(v1, ref) < RTOL
+        for r in np.flatnonzero(fixed)[:30]:
+            assert r1[r] == 0.0 and np.all(v1[ref["rowptr"][r]:ref["rowptr"][r + 1]] == 0.0)
+        blk.assemble_jacres(ud, res, vals, **kw)  # accumulate on top
+        assert rel_err(res.cpu().numpy(), 2 * r1) < 1e-14 and rel_err(vals.cpu().numpy(), 2 * v1) < 1e-14
+        blk.assemble_jacres(ud, res, vals, compute_jacobian=False, overwrite=True, **kw)  # residual only
+        assert rel_err(res.cpu().numpy(), r1) < 1e-14 and rel_err(vals.cpu().numpy(), 2 * v1) < 1e-14
+        results[direct] = (r1, v1)
+    assert rel_err(results[True][0], results[False][0]) < 1e-13 and rel_err(results[True][1], results[False][1]) < 1e-13
+
+
 @pytest.mark.parametrize("dim,ncell,orders", [(2, (4, 3), (1, 1)), (2, (3, 2), (2, 1)), (3, (2, 2, 2), (2, 1)),
                                              (3, (2, 3, 2), (1, 1))])
 @pytest.mark.parametrize("mode", ["plain", "supg+pspg transient", "fix_uz"])
