@@ -133,7 +133,10 @@ void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *l
   // rows in flight per wavefront; MHA_GATHER_LPR=16 keeps four
   static const int lpr_env = [] { const char *m = std::getenv("MHA_GATHER_LPR"); return m ? std::atoi(m) : 0; }();
   const bool tiny_ok = small_rows && g.max_row <= 16 && b.n <= 8 && g.slot_bytes == 1;
-  const int lpr = !small_rows ? 64 : (tiny_ok && lpr_env != 16) ? 8 : 16;  // (4 lanes per row: 1.65 against 1.53 ms at config 3)
+  // medium rows (the 42-entry trace rows of the HDG scatter: two incident elements of 24 dofs): four rows per wavefront
+  // (config 5's scatter: 64 lanes per row 336 us, 32: 230, 16: 165; MHA_GATHER_LPR=64|32|8 select the others)
+  const bool medium = !small_rows && g.max_row <= 64 && b.n <= 32 && g.slot_bytes == 1 && g.inc_dof == nullptr && lpr_env != 64;
+  const int lpr = medium ? (lpr_env == 32 ? 32 : lpr_env == 8 ? 8 : 16) : !small_rows ? 64 : (tiny_ok && lpr_env != 16) ? 8 : 16;  // (4 lanes per row: 1.65 against 1.53 ms at config 3)
   const int rpw = 64 / lpr;
   const size_t lds = sizeof(double) * 4 * rpw * (size_t)g.max_row;
   MHA_REQUIRE(lds <= 64 * 1024, MHA_ERR_INVALID, "CRS rows of " << g.max_row << " entries do not fit the row-gather kernel");
@@ -145,6 +148,8 @@ void launch_row_gather(const BlockDev &b, const RowGatherDev &g, const double *l
   MHA_REQUIRE(!dof || (small_rows && g.slot_bytes == 1 && !g.adjoint && !g.lump_mass), MHA_ERR_INVALID,
               "dof-ordered element arrays are gathered by the short-row kernels only");
   if (lpr == 8) { if (dof) go(row_gather_kernel<uint8_t, 8, true>); else go(row_gather_kernel<uint8_t, 8, false>); }
+  else if (lpr == 32) go(row_gather_kernel<uint8_t, 32, false>);
+  else if (medium) go(row_gather_kernel<uint8_t, 16, false>);
   else if (g.slot_bytes == 1) {
     if (!small_rows) go(row_gather_kernel<uint8_t, 64, false>);
     else if (dof) go(row_gather_kernel<uint8_t, 16, true>);
