@@ -57,6 +57,45 @@ __device__ __forceinline__ bool gauss_jordan_columns(int ni, double (&col)[MAXI]
   return !bad;
 }
 
+// The same elimination for a block size known at compile time (the fused HDG element kernel: 12 interior unknowns): the
+// pivot loop is unrolled, so "row k" is a register name and only the pivot row found at run time is reached through a
+// select chain -- a third of the instructions of the run-time form.
+template <int NI>
+__device__ __forceinline__ bool gauss_jordan_columns_static(double (&col)[NI]) {
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    double best = -1.0;
+    int piv = k;
+#pragma unroll
+    for (int i = k; i < NI; ++i) {
+      const double a = fabs(col[i]);
+      if (a > best) { best = a; piv = i; }
+    }
+    piv = __builtin_amdgcn_readlane(piv, k);
+    best = readlane_f64(best, k);
+    if (!(best > 0.0)) bad = true;  // (keeps going on garbage: the caller reports the block as singular)
+    // swap rows k and piv of this lane's column: col[k] is a register, col[piv] a select chain over rows > k
+    double cp = col[k];
+#pragma unroll
+    for (int i = k + 1; i < NI; ++i) if (i == piv) cp = col[i];
+    const double ck = col[k];
+#pragma unroll
+    for (int i = k + 1; i < NI; ++i) if (i == piv) col[i] = ck;
+    const double akk = readlane_f64(cp, k);
+    const double rk = cp / akk;  // this lane's entry of the normalised pivot row
+    col[k] = cp;                 // (column k of the multipliers below is read before the update)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i == k) continue;
+      const double aik = readlane_f64(col[i], k);
+      col[i] -= aik * rk;
+    }
+    col[k] = rk;
+  }
+  return !bad;
+}
+
 // low[a]: entry (ni + a, lane) of [A_lu | A_ll | r_l], col[] as gauss_jordan_columns leaves it: S = A_ll - A_lu X_ul
 // (lanes ni .. n - 1, column lane - ni), g = r_l - A_lu x_r (lane n) and x_r (lane n) to element-major arrays (any may
 // be null).

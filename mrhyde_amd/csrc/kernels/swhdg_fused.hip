@@ -27,6 +27,7 @@ namespace mha {
 namespace {
 
 constexpr int kFuWaves = 4, kFuMaxSidePts = 16, kFuMaxVolPts = 9, kFuRows = 36, kFuInt = 12, kFuTrace = 24;
+constexpr int kFuSchurLds = 672;  // doubles per wavefront: A_lu [24][12] + X [12][32], then P [24][25] over them
 
 template <int MAXP>  // side points of an element (4 sides x points per side) held in registers during the column assembly
 __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev b, SideTablesDev st, SwhElementDev a, TimeDev tm,
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
   __shared__ double s_vr[kFuWaves][kFuMaxVolPts][9];     // (Sdot_i - source_i) w, then -F_i^x w, -F_i^y w
   __shared__ double s_vD[kFuWaves][kFuMaxVolPts][18];    // d(F_i^d)/dS_k * w: [i][d][k]
   __shared__ double s_vw[kFuWaves][kFuMaxVolPts];        // w = reference weight * det J
+  __shared__ double s_sch[kFuWaves][kFuSchurLds];        // staging of the Schur product on the matrix cores
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int el = blockIdx.x * kFuWaves + wv;
   const bool active = el < b.e_count;
@@ -238,25 +240,27 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
         }
       }
     }
-  } else if (rhs) {
-#pragma unroll
-    for (int rp = 0; rp < 12; ++rp) {
-      double v[3] = {0.0, 0.0, 0.0};
-      for (int p = 0; p < npts; ++p) {
-        const double t = s_T[wv][p][rp];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) v[i] -= s_f[wv][p][i] * t;
-      }
-      if (rp < 4)
+  }
+  // right-hand side (column kFuRows, held by one lane): its 36 entries are formed one per LANE -- row c = (equation ck,
+  // side function cp) -- and handed to that lane's registers with v_readlane; as a branch of the column code above it was
+  // a second pass of the whole wavefront for the benefit of a single lane
+  {
+    double mine = 0.0;
+    if (c < kFuRows) {
+      for (int p = 0; p < npts; ++p) mine -= s_f[wv][p][ck] * s_T[wv][p][cp];
+      if (cp < 4 && c < 12)
         for (int q = 0; q < nq; ++q)
+          mine -= s_vr[wv][q][ck] * s_vT[wv][q][cp] + s_vr[wv][q][3 + ck] * s_vT[wv][q][4 + cp] + s_vr[wv][q][6 + ck] * s_vT[wv][q][8 + cp];
+    }
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
-            v[i] -= s_vr[wv][q][i] * s_vT[wv][q][rp] + s_vr[wv][q][3 + i] * s_vT[wv][q][4 + rp] + s_vr[wv][q][6 + i] * s_vT[wv][q][8 + rp];
+    for (int r = 0; r < kFuInt; ++r) {
+      const double v = readlane_f64(mine, r);
+      if (rhs) col[r] = v;
+    }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        if (rp < 4) col[i * 4 + rp] = v[i];
-        else low[i * 8 + rp - 4] = v[i];
-      }
+    for (int r = 0; r < kFuTrace; ++r) {
+      const double v = readlane_f64(mine, kFuInt + r);
+      if (rhs) low[r] = v;
     }
   }
   // ---- loop bookkeeping of nonlinearSolver (subgrid.hip: combine), on the interior residual ----
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
   }
   // ---- static condensation in registers ----
   const int64_t eo = e - b.e_begin;
-  if (!gauss_jordan_columns<kFuInt>(kFuInt, col)) { if (lane == 0 && o.singular) atomicAdd(o.singular, 1); return; }
+  if (!gauss_jordan_columns_static<kFuInt>(col)) { if (lane == 0 && o.singular) atomicAdd(o.singular, 1); return; }
   if (o.update_u) {  // sol += du for the elements still in their loop (subgrid.hip: update), fused
     const bool go = !o.active || o.active[eo];
     double dui = 0.0;
@@ -290,7 +294,65 @@ __global__ __launch_bounds__(64 * kFuWaves, 3) void swhdg_fused_kernel(BlockDev 
     }
     if (go && lane < 12) o.update_u[myrow] += dui;
   }
-  schur_from_registers<kFuInt, kFuTrace>(kFuInt, kFuTrace, lane, eo, col, low, o.schur, o.gvec, o.du);
+  // ---- Schur complement S = A_ll - A_lu X_ul, g = r_l - A_lu x_r on the matrix cores ----
+  // (schur_from_registers forms the same numbers with 576 v_readlane pairs and 288 FMAs per lane: a fifth of the kernel's
+  // instructions.)  A_lu (rows of `low` in lanes < 12) and X = [X_ul | x_r] (`col` of lanes 12..36) go through the
+  // wavefront's staging buffer into MFMA operand layout: P = A_lu X as 2 x 2 tiles of 16 x 16, K = 12 = 3 steps; P comes
+  // back through the same buffer in column-per-lane order and is subtracted from the lane's column of [A_ll | r_l].
+  {
+    double *sb = s_sch[wv];
+    auto wave_sync = [] {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (lane < kFuInt) {
+#pragma unroll
+      for (int a = 0; a < kFuTrace; ++a) sb[a * kFuInt + lane] = low[a];
+    } else if (lane <= kFuRows) {
+#pragma unroll
+      for (int i = 0; i < kFuInt; ++i) sb[kFuTrace * kFuInt + i * 32 + (lane - kFuInt)] = col[i];
+    }
+    wave_sync();
+    const int l15 = lane & 15, g4 = lane >> 4;
+    double av[2][3], bv[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        av[t][ks] = sb[(t * 16 + l15) * kFuInt + 4 * ks + g4];  // rows >= 24 read past A_lu: they only reach P rows >= 24, never read
+        bv[t][ks] = sb[kFuTrace * kFuInt + (4 * ks + g4) * 32 + t * 16 + l15];  // columns > 24 likewise
+      }
+    wave_sync();  // operands are in registers: P may overwrite them
+    typedef double v4d __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        v4d d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][ks], bv[ct][ks], d, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = rt * 16 + g4 + 4 * u, cc = ct * 16 + l15;
+          if (row < kFuTrace && cc <= kFuTrace) sb[row * 25 + cc] = d[u];
+        }
+      }
+    wave_sync();
+    if (o.du && lane == kFuRows) {
+#pragma unroll
+      for (int i = 0; i < kFuInt; ++i) o.du[eo * kFuInt + i] = col[i];
+    }
+    if (lane >= kFuInt && lane <= kFuRows) {
+      const int bcol = lane - kFuInt;
+#pragma unroll
+      for (int a = 0; a < kFuTrace; ++a) {
+        const double sacc = low[a] - sb[a * 25 + bcol];
+        if (lane < kFuRows) { if (o.schur) o.schur[(eo * kFuTrace + a) * kFuTrace + bcol] = sacc; }
+        else if (o.gvec) o.gvec[eo * kFuTrace + a] = sacc;
+      }
+    }
+  }
 }
 
 }  // namespace
