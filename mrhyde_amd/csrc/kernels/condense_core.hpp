@@ -76,12 +76,15 @@ __device__ __forceinline__ bool gauss_jordan_columns_static(double (&col)[NI]) {
     best = readlane_f64(best, k);
     if (!(best > 0.0)) bad = true;  // (keeps going on garbage: the caller reports the block as singular)
     // swap rows k and piv of this lane's column: col[k] is a register, col[piv] a select chain over rows > k
+    // (piv is wave-uniform: no swap, no chain, when the diagonal entry is the pivot)
     double cp = col[k];
+    if (piv != k) {
 #pragma unroll
-    for (int i = k + 1; i < NI; ++i) if (i == piv) cp = col[i];
-    const double ck = col[k];
+      for (int i = k + 1; i < NI; ++i) if (i == piv) cp = col[i];
+      const double ck = col[k];
 #pragma unroll
-    for (int i = k + 1; i < NI; ++i) if (i == piv) col[i] = ck;
+      for (int i = k + 1; i < NI; ++i) if (i == piv) col[i] = ck;
+    }
     const double akk = readlane_f64(cp, k);
     const double rk = cp / akk;  // this lane's entry of the normalised pivot row
     col[k] = cp;                 // (column k of the multipliers below is read before the update)
