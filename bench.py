@@ -281,6 +281,7 @@ def setup_thermal(args, torch, mrhyde_amd, rank, world, dev):
                               else "thermal_affine_element/residual kernel + row_owner_jacobian_persistent_kernel"),
                 "row_gather": "thermal_general_element_kernel (dense element matrices) + row_gather_kernel"}.get(pname, "element kernel + scatter")
         return pname, kern, {"affine_elements": blk.info("num_affine_elems"), "block_patterns": blk.info("block_patterns"),
+                             "affine_geometry_shapes": blk.info("affine_shapes"),
                              "row_blocks": blk.info("general_row_blocks") if kind == 2 else blk.info("row_blocks"),
                              "row_owner_kind": kind}
 

@@ -1832,6 +1832,28 @@ void AssemblyManager::prepareRowOwner() {
     ro.k1_plan.max_rows = (max_rows + 1) / 2 * 2;
     ro.k1_plan.num_elems = nelem_;
     ro.k1_plan.axis_aligned = aligned ? 1 : 0;
+    // geometry database (reference: identifyVolumetricDatabase, assemblyManager.cpp:4314-4467; here exact matching of
+    // the 16 shape doubles, bit for bit, so nothing is substituted): distinct shapes in order of first appearance
+    {
+      static_assert(kGeoXc == 16, "the shape part of a geometry record is its first 16 doubles");
+      std::unordered_map<std::string, int32_t> seen;
+      std::vector<double> shapes;
+      std::vector<int32_t> sidx(nelem_);
+      for (int e = 0; e < nelem_; ++e) {
+        const char *rec = reinterpret_cast<const char *>(&geo[static_cast<size_t>(e) * kGeoRec]);
+        auto it = seen.emplace(std::string(rec, 16 * sizeof(double)), static_cast<int32_t>(seen.size()));
+        if (it.second) shapes.insert(shapes.end(), &geo[static_cast<size_t>(e) * kGeoRec], &geo[static_cast<size_t>(e) * kGeoRec] + 16);
+        sidx[e] = it.first->second;
+      }
+      const char *db = std::getenv("MHA_K1_DATABASE");
+      if (!(db && db[0] == '0')) {
+        ro.k1_shape.upload(shapes);
+        ro.k1_shape_idx.upload(sidx);
+        ro.k1_plan.shape = ro.k1_shape.data();
+        ro.k1_plan.shape_idx = ro.k1_shape_idx.data();
+      }
+      ro.k1_plan.num_shapes = static_cast<int>(seen.size());
+    }
   }
   ro.ready = true;
   prepareBlockPattern();
@@ -2190,6 +2212,7 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "dofs_per_elem") return n_;
   if (key == "num_ip") return nq_;
   if (key == "last_path") return last_path_;
+  if (key == "affine_shapes") return ro_.ready ? ro_.k1_plan.num_shapes : 0;  // distinct geometry records behind the residual kernel's database index
   if (key == "porous_direct") return last_porous_direct_;  // the last row-gather assembly of a porousMixed block stored straight into the CRS
   if (key == "workset_size") return wkset_.maxElem;
   if (key == "row_blocks") return ro_.ready ? ro_.rb.num_blocks : 0;

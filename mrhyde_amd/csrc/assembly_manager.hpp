@@ -180,7 +180,8 @@ class AssemblyManager {
     AffineTables1D tab1d;  // thread-per-element K1
     bool k1_thread = false;
     // workgroup-merged K1 (K1PlanDev): distinct rows of every 256 consecutive elements + 16-bit positions
-    DeviceBuffer<int32_t> k1_row_ptr, k1_rows, k1_elems;
+    DeviceBuffer<int32_t> k1_row_ptr, k1_rows, k1_elems, k1_shape_idx;
+    DeviceBuffer<double> k1_shape;
     bool k1_wg = false;
     DeviceBuffer<uint16_t> k1_loc;
     K1PlanDev k1_plan;

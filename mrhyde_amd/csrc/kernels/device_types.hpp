@@ -146,6 +146,12 @@ struct K1PlanDev {
   const uint16_t *loc = nullptr;
   int max_rows = 0, num_elems = 0;
   int axis_aligned = 0;  // every element's J is diagonal (checked on the cached geometry records)
+  // geometry database of the affine path (the reference's identifyVolumetricDatabase idea, exact matching): the shape
+  // part of the geometry record -- detJ J^-1 J^-T, detJ, J: 16 doubles -- once per DISTINCT shape, an index per element
+  // (a uniform mesh has one shape: the kernel reads 4 + 32 bytes per element instead of 160); the centroid stays per element
+  const double *shape = nullptr;       // [num_shapes][16]
+  const int32_t *shape_idx = nullptr;  // [E]
+  int num_shapes = 0;
 };
 
 // Side reference tables on the device (ref_tables.hpp: SideTables).

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(kK1wThreads, (TR || EXPR || !SEPK) ? 2 : 3) void th
     }
   }
   // the element's geometry record: G (upper triangle), det, then J and the centroid (requested before the barrier)
-  const double *grec = geo + (size_t)e * kGeoRec;
+  const double *gcen = geo + (size_t)e * kGeoRec;  // the element's own record: centroid
+  const double *grec = pl.shape ? pl.shape + (size_t)pl.shape_idx[e] * 16 : gcen;  // shape part: through the database
   double G[DIM][DIM], xc[DIM], Jd[DIM];
   {
     int k = 0;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kK1wThreads, (TR || EXPR || !SEPK) ? 2 : 3) void th
   bool separable = ph.source.kind != MHA_FUNC_CONSTANT && ph.source.kind != MHA_FUNC_IP_ARRAY && ph.source.kind != MHA_FUNC_EXPRESSION;
 #pragma unroll
   for (int r = 0; r < DIM; ++r) {
-    xc[r] = grec[kGeoXc + r];
+    xc[r] = gcen[kGeoXc + r];
     Jd[r] = grec[kGeoJ + r * DIM + r];
 #pragma unroll
     for (int c = 0; c < DIM; ++c)
