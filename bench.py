@@ -280,8 +280,16 @@ def setup_thermal(args, torch, mrhyde_amd, rank, world, dev):
                               else "thermal_affine_residual_wg_kernel + block_pattern_jacobian_kernel" if blk.info("block_patterns") > 0
                               else "thermal_affine_element/residual kernel + row_owner_jacobian_persistent_kernel"),
                 "row_gather": "thermal_general_element_kernel (dense element matrices) + row_gather_kernel"}.get(pname, "element kernel + scatter")
+        dbm = blk.info("jacobian_database_mode") == 1
+        if dbm:
+            kern = ("thermal_affine_residual_wg_kernel + block_pattern_jacobian_kernel on one representative row block per "
+                    "assembly pattern + replicate_runs_kernel (geometry-database mode: every element has the same geometry record)")
         return pname, kern, {"affine_elements": blk.info("num_affine_elems"), "block_patterns": blk.info("block_patterns"),
                              "affine_geometry_shapes": blk.info("affine_shapes"),
+                             "jacobian_mode": ("geometry database: 1 distinct element geometry, Jacobian rows computed for one row block per "
+                                               "assembly pattern and replicated (bit-identical to the full kernel; MHA_BP_DATABASE=0 "
+                                               "or --jacobian full runs the matrix-core kernel on every block)") if dbm
+                                              else "full: pattern products on the matrix cores for every row block",
                              "row_blocks": blk.info("general_row_blocks") if kind == 2 else blk.info("row_blocks"),
                              "row_owner_kind": kind}
 
@@ -474,6 +482,9 @@ def main():
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--path", default="auto", choices=["auto", "element_atomic", "row_owner", "local_then_scatter", "row_gather"])
     ap.add_argument("--mesh", default="affine", choices=["affine", "perturbed"])
+    ap.add_argument("--jacobian", default="database", choices=["database", "full"],
+                    help="config 2: 'full' keeps the matrix-core Jacobian kernel on every row block even when the mesh has one "
+                         "element geometry (the default replicates one block per assembly pattern then: geometry-database mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-layers", type=int, default=0, help="z-layers of the CPU sample of config 2 (0 = all)")
     args = ap.parse_args()
@@ -515,6 +526,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if args.jacobian == "full":
+        os.environ["MHA_BP_DATABASE"] = "0"
     if args.config == 2:
         w = setup_thermal(args, torch, mrhyde_amd, rank, world, dev)
     elif args.config == 3:
@@ -560,6 +573,23 @@ def main():
                "partition": ("strips of element rows, 1 per GPU" if args.config == 5 else "z-slabs, 1 per GPU") if world > 1 else "single block",
                "shared_row_bytes_per_step": wire}
         cfg.update(extra)
+        if args.config == 2 and world == 1 and str(extra.get("jacobian_mode", "")).startswith("geometry database"):
+            # the same workload with the full kernel, outside the timed region: both numbers in one line
+            os.environ["MHA_BP_DATABASE"] = "0"
+            w2 = setup_thermal(args, torch, mrhyde_amd, rank, world, dev)
+            for _ in range(args.warmup):
+                w2["step"]()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                w2["step"]()
+            torch.cuda.synchronize()
+            full_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+            full_kernel_ms = w2["kernel_ms"](max(3, min(args.steps, 10)))
+            cfg["full_kernel"] = {"ms_per_step": full_ms, "kernel_ms": full_kernel_ms,
+                                  "frac": b_elem * E / (full_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "kernels": w2["info"]()[1]}
+            del os.environ["MHA_BP_DATABASE"]
         out = {
             "metric": "assembled elements/sec (vol Jacobian+residual)",
             "value": world * E * args.steps / elapsed,

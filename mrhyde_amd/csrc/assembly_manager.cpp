@@ -1839,10 +1839,15 @@ void AssemblyManager::prepareRowOwner() {
       std::unordered_map<std::string, int32_t> seen;
       std::vector<double> shapes;
       std::vector<int32_t> sidx(nelem_);
+      const int nsym_g = dim_ * (dim_ + 1) / 2;
       for (int e = 0; e < nelem_; ++e) {
-        const char *rec = reinterpret_cast<const char *>(&geo[static_cast<size_t>(e) * kGeoRec]);
-        auto it = seen.emplace(std::string(rec, 16 * sizeof(double)), static_cast<int32_t>(seen.size()));
-        if (it.second) shapes.insert(shapes.end(), &geo[static_cast<size_t>(e) * kGeoRec], &geo[static_cast<size_t>(e) * kGeoRec] + 16);
+        double rec[16];
+        for (int k = 0; k < 16; ++k) {  // (entries a 2-D record does not use are not part of the shape)
+          const bool used = k < nsym_g || k == kGeoDet || (k >= kGeoJ && k < kGeoJ + dim_ * dim_);
+          rec[k] = used ? geo[static_cast<size_t>(e) * kGeoRec + k] : 0.0;
+        }
+        auto it = seen.emplace(std::string(reinterpret_cast<const char *>(rec), sizeof(rec)), static_cast<int32_t>(seen.size()));
+        if (it.second) shapes.insert(shapes.end(), rec, rec + 16);
         sidx[e] = it.first->second;
       }
       const char *db = std::getenv("MHA_K1_DATABASE");
@@ -1853,6 +1858,7 @@ void AssemblyManager::prepareRowOwner() {
         ro.k1_plan.shape_idx = ro.k1_shape_idx.data();
       }
       ro.k1_plan.num_shapes = static_cast<int>(seen.size());
+      ro.num_shapes = ro.k1_plan.num_shapes;
     }
   }
   ro.ready = true;
@@ -1961,6 +1967,52 @@ void AssemblyManager::prepareBlockPattern() {
   d.timing = bp.timing.empty() ? nullptr : bp.timing.data();
   MHA_HIP(hipStreamSynchronize(stream_));
   bp.usable = true;
+  // Geometry-database mode (reference: identifyVolumetricDatabase, assemblyManager.cpp:4314-4467,
+  // here with exact matching): with ONE geometry shape in the block the rows of a row block depend on its pattern
+  // only -- the kernel runs on one representative block per role (the role's first) and the representative's runs are
+  // replicated.  MHA_BP_DATABASE=0 keeps the full kernel.
+  bp.db_mode = false;
+  const char *dbm = std::getenv("MHA_BP_DATABASE");
+  if (ro_.num_shapes == 1 && !d.has_image && !(dbm && dbm[0] == '0')) {
+    std::vector<int32_t> rseg(static_cast<size_t>(h.num_roles) * 4, 0), rptr(static_cast<size_t>(h.num_roles) + 1, 0);
+    struct Run { int32_t src, dst, len; };
+    std::vector<Run> runs;
+    for (int k = 0; k < h.num_roles; ++k) {
+      rseg[4 * k] = k;
+      rseg[4 * k + 1] = 0;
+      rseg[4 * k + 2] = 1;
+      rptr[k + 1] = k + 1;
+      const int32_t *ro = &h.role[static_cast<size_t>(k) * kBpRoleInts];
+      const int64_t row_base = (static_cast<int64_t>(ro[4]) << 32) | static_cast<uint32_t>(ro[3]);  // R_ROWB_HI / _LO
+      const int nruns = ro[5], nblocks = ro[6];                                                        // R_NRUNS, R_NBLOCKS
+      const int32_t *rl = &h.runlen[static_cast<size_t>(h.role_runlen_off[k])];
+      for (int j = 1; j < nblocks; ++j)
+        for (int r = 0; r < nruns; ++r)
+          runs.push_back({h.rowbase[static_cast<size_t>(row_base + r)], h.rowbase[static_cast<size_t>(row_base + static_cast<int64_t>(j) * nruns + r)], rl[r]});
+    }
+    std::sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) { return a.dst < b.dst; });
+    // 1 KB chunks on 128-byte lines (the CRS values are 128-byte aligned: checked at launch): 16 entries per line
+    std::vector<int32_t> chunks;
+    for (const Run &r : runs) {
+      const int64_t dbeg = r.dst, dend = static_cast<int64_t>(r.dst) + r.len;
+      for (int64_t c = dbeg / 16 * 16; c < dend; c += 128) {
+        chunks.push_back(static_cast<int32_t>(c / 2));                    // destination / 16 bytes
+        chunks.push_back(static_cast<int32_t>(r.src + (c - dbeg)));       // source entry of lane 0's first double
+        chunks.push_back(static_cast<int32_t>(dbeg));
+        chunks.push_back(static_cast<int32_t>(dend));
+      }
+    }
+    bp.rep_seg.upload(rseg);
+    bp.rep_wg_seg_ptr.upload(rptr);
+    bp.copy_chunks.upload(chunks);
+    bp.copy_runs = static_cast<int>(chunks.size() / 4);
+    bp.dev_rep = d;
+    bp.dev_rep.seg = bp.rep_seg.data();
+    bp.dev_rep.wg_seg_ptr = bp.rep_wg_seg_ptr.data();
+    bp.dev_rep.num_wgs = h.num_roles;
+    bp.dev_rep.timing = nullptr;
+    bp.db_mode = true;
+  }
 }
 
 bool AssemblyManager::rowOwnerUsable(std::string *why) const {
@@ -2174,7 +2226,13 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
     else launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, s);
   };
   auto jacobian = [&](hipStream_t s) {  // K2: pattern GEMMs on the matrix cores when the rows group, row blocks otherwise
-    if (bpat_.usable) {
+    if (bpat_.usable && bpat_.db_mode && out.overwrite && !bpat_.dev.timing) {
+      // geometry-database mode: the representatives' rows, then their copies (same stream: ordered)
+      launch_block_pattern_jacobian(bpat_.dev_rep, out, su, st, s);
+      launch_replicate_runs(bpat_.copy_chunks.data(), bpat_.copy_runs, out.vals, s);
+      last_db_mode_ = 1;
+    } else if (bpat_.usable) {
+      last_db_mode_ = 0;
       launch_block_pattern_jacobian(bpat_.dev, out, su, st, s);
       if (bpat_.dev.timing) {  // profiling aid: wall-clock stamps of every wavefront of the last launch -> $MHA_BP_TIMING
         MHA_HIP(hipStreamSynchronize(s));
@@ -2212,6 +2270,7 @@ int64_t AssemblyManager::info(const std::string &key) const {
   if (key == "dofs_per_elem") return n_;
   if (key == "num_ip") return nq_;
   if (key == "last_path") return last_path_;
+  if (key == "jacobian_database_mode") return last_db_mode_;  // the last affine row-owner Jacobian replicated one block per pattern
   if (key == "affine_shapes") return ro_.ready ? ro_.k1_plan.num_shapes : 0;  // distinct geometry records behind the residual kernel's database index
   if (key == "porous_direct") return last_porous_direct_;  // the last row-gather assembly of a porousMixed block stored straight into the CRS
   if (key == "workset_size") return wkset_.maxElem;

@@ -131,6 +131,7 @@ class AssemblyManager {
   DeviceBuffer<double> d_gather_J_, d_gather_res_;
   // porousMixed direct form (ElemOut::direct_*): -1 not decided, 0 no (why in porous_direct_why_), 1 yes
   int porous_direct_ = -1, last_porous_direct_ = 0;
+  int last_db_mode_ = 0;
   std::string porous_direct_why_;
   DeviceBuffer<double> d_direct_part_;   // [nrows][2][2]
   DeviceBuffer<uint8_t> d_direct_side_;  // [E][n] (dof order): which incidence of its row the element is
@@ -188,6 +189,7 @@ class AssemblyManager {
     double max_abs_coord[3] = {0, 0, 0};  // of the block's vertices (bounds the arguments of a closed-form source)
     int slot_bytes = 1;
     int num_affine_elems = 0, num_affine_blocks = 0, num_general_blocks = 0;
+    int num_shapes = 0;  // distinct geometry records (shape part, bit for bit) of the block's affine elements
     bool all_rows_covered = false;
   } ro_;
   // general-element row-owner kernel (kernels/thermal_general_row_owner.hip): its own row blocks (2x2x2 / 4x4 chunks,
@@ -219,6 +221,11 @@ class AssemblyManager {
     DeviceBuffer<int32_t> role, seg, wg_seg_ptr, part_ptr, part_hdr, part_lane, rowbase, erec_elem, chunk_tab, wg_seg_ptr_img;
     DeviceBuffer<double> w, erec2;
     DeviceBuffer<long long> timing;
+    // geometry-database mode (one shape in the block): the kernel on one representative block per role + replication
+    bool db_mode = false;
+    BlockPatternDev dev_rep;  // dev with the segment tables of the representatives
+    DeviceBuffer<int32_t> rep_seg, rep_wg_seg_ptr, copy_chunks;  // [chunks][4]: see launch_replicate_runs
+    int copy_runs = 0;                                           // chunks
   } bpat_;
   void prepareBlockPattern();
 

@@ -663,6 +663,14 @@ BlockPatternPlan build_block_patterns(const RowBlocks &rb, int n, int nsym, cons
     ro[R_NCHUNK] = r.nchunk;
     ro[R_CHUNK_LO] = static_cast<int32_t>(r.chunk_off & 0xffffffffll);
     ro[R_CHUNK_HI] = static_cast<int32_t>(r.chunk_off >> 32);
+    pl.role_runlen_off.push_back(static_cast<int64_t>(pl.runlen.size()));
+    if (!blocks.empty()) {  // entries of every run, from the role's first block (the pattern fixes them)
+      const int32_t b0 = blocks[0];
+      for (int o = rb.row_ptr[b0]; o < rb.row_ptr[b0 + 1]; ++o) {
+        if (o == rb.row_ptr[b0] || rb.rows[o - 1] + 1 != rb.rows[o]) pl.runlen.push_back(0);
+        pl.runlen.back() += rowptr[rb.rows[o] + 1] - rowptr[rb.rows[o]];
+      }
+    }
     for (int32_t b : blocks) {
       for (int t = rb.elem_ptr[b]; t < rb.elem_ptr[b + 1]; ++t) pl.erec_elem.push_back(rb.elems[t]);
       pl.erec_elem.push_back(-1);

@@ -84,6 +84,8 @@ struct BlockPatternPlan {
   std::vector<double> w;               // LDS images of the roles: per role [stiffness rows | mass rows], each w_doubles long
   std::vector<int32_t> erec_elem;      // role-major, block-major [T + 1] element ids; -1 = the block's zero record
   std::vector<int32_t> rowbase;        // role-major, block-major [runs]: CRS offset of the first row of every run of consecutive owned rows
+  std::vector<int32_t> runlen;         // role-major [runs]: CRS entries of each run (the same for every block of a role)
+  std::vector<int64_t> role_runlen_off;// [num_roles] -> first entry of the role in runlen
   std::vector<int32_t> chunk_tab;      // image roles: [chunks][kBpChunkInts], role-major
   int num_image_roles = 0;
   int64_t mfma_per_assembly = 0;       // diagnostics

@@ -879,6 +879,72 @@ void launch_build_erec2(int64_t total_records, int nsym, const int32_t *erec_ele
   MHA_HIP(hipGetLastError());
 }
 
+// ---- geometry-database mode: the rows of one block per pattern, replicated ------------------------------------------
+// When every element of the block has the SAME geometry record (AssemblyManager: one shape in the geometry database)
+// the CRS rows a row block produces depend on its assembly pattern only.  The Jacobian kernel then runs on ONE
+// representative block per role and this kernel copies the representative's runs of consecutive rows to the same runs
+// of every other block of the role.  The destination is walked in 1 KB chunks that start on 128-byte lines, 16 bytes
+// per lane, so every store instruction but a run's first and last covers whole lines (the row pieces of the kernel
+// above cannot: see DESIGN 3.1); the source comes out of the L2 (a pattern's rows are ~64 KB).  Bit-identical to the
+// full kernel: the same inputs go through the same instructions, once instead of once per block.
+// chunk = {destination / 16 bytes (a multiple of 8: the chunk starts on a 128-byte line), source entry of lane 0's first
+// double (may be up to 15 below the run's first entry), first and one-past-last destination ENTRY of the run}: the list
+// comes from the host, sorted by destination.  Four chunks per wavefront and pass, every load of the pass issued before
+// its first store (one chunk at a time the kernel is a chain of dependent latencies: 326 us for the 1.07 GB of config 2).
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void replicate_runs_kernel(const int4 *__restrict__ chunks, int nchunks, double *vals) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
+  for (int base = wave * U; base < nchunks; base += nwaves * U) {
+    int4 t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[u] = chunks[min(base + u, nchunks - 1)];  // wave-uniform: scalar loads
+    double x0[U], x1[U];
+    bool v0[U], v1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long e = (long long)t[u].x * 2 + 2 * lane;  // destination entry of this lane's first double
+      v0[u] = base + u < nchunks && e >= t[u].z && e < t[u].w;
+      v1[u] = base + u < nchunks && e + 1 >= t[u].z && e + 1 < t[u].w;
+      const long long se = (long long)t[u].y + 2 * lane;
+      x0[u] = v0[u] ? vals[se] : 0.0;
+      x1[u] = v1[u] ? vals[se + 1] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double *dst = vals + (long long)t[u].x * 2 + 2 * lane;
+      if (v0[u] && v1[u]) {
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        v2d_t v = {x0[u], x1[u]};
+        if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2d_t *>(dst));
+        else *reinterpret_cast<v2d_t *>(dst) = v;
+      } else if (v0[u]) dst[0] = x0[u];
+      else if (v1[u]) dst[1] = x1[u];
+    }
+  }
+}
+
+void launch_replicate_runs(const int32_t *chunks, int nchunks, double *vals, hipStream_t stream) {
+  if (nchunks <= 0) return;
+  MHA_REQUIRE((reinterpret_cast<uintptr_t>(vals) & 127u) == 0, MHA_ERR_INVALID, "geometry-database mode: CRS values must start on a 128-byte line");
+  // nontemporal stores (the written lines are not read again before they leave the L2: 276 -> 249 us) and a grid that
+  // gives every wavefront few passes (2048 workgroups 246 us, 8192: 225, 32768 with two chunks per pass: 220):
+  // profiles/r3_k2_database_modes.sh.  MHA_REP_MODE: 0 four chunks per pass, plain stores; 1 four + nontemporal; 2 eight;
+  // 3 eight + nontemporal; 4 (default) two + nontemporal; 5 one + nontemporal
+  static const int mode = [] { const char *m = std::getenv("MHA_REP_MODE"); return m ? std::atoi(m) : 4; }();
+  static const int wgs = [] { const char *m = std::getenv("MHA_REP_WGS"); return m ? std::atoi(m) : 32768; }();
+  const int4 *ch = reinterpret_cast<const int4 *>(chunks);
+  const int per_wg = 4 * (mode == 2 || mode == 3 ? 8 : mode == 4 ? 2 : mode == 5 ? 1 : 4);
+  const int grid = std::min((nchunks + per_wg - 1) / per_wg, wgs);
+  if (mode == 0) hipLaunchKernelGGL((replicate_runs_kernel<4, false>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  else if (mode == 1) hipLaunchKernelGGL((replicate_runs_kernel<4, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  else if (mode == 2) hipLaunchKernelGGL((replicate_runs_kernel<8, false>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  else if (mode == 3) hipLaunchKernelGGL((replicate_runs_kernel<8, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  else if (mode == 5) hipLaunchKernelGGL((replicate_runs_kernel<1, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  else hipLaunchKernelGGL((replicate_runs_kernel<2, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  MHA_HIP(hipGetLastError());
+}
+
 void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, double su, double st, hipStream_t stream) {
   if (d.num_wgs <= 0 || !out.vals) return;
   const size_t lds = sizeof(double) * (size_t)d.max_w_doubles + sizeof(int) * kBpSegInts + 2 * sizeof(double) * (size_t)d.max_rec_doubles;

@@ -78,6 +78,9 @@ void launch_affine_geometry(const BlockDev &b, double *geo, hipStream_t stream);
 void launch_build_erec2(int64_t total_records, int nsym, const int32_t *erec_elem, const double *geo, double *erec2,
                         hipStream_t stream);
 void launch_block_pattern_jacobian(const BlockPatternDev &d, const RowOut &out, double su, double st, hipStream_t stream);
+// geometry-database mode of the Jacobian: copies runs of CRS entries inside vals, 1 KB chunk by chunk (chunks: [n][4]
+// ints = destination / 16 bytes, source entry of lane 0, first and one-past-last destination entry of the run)
+void launch_replicate_runs(const int32_t *chunks, int nchunks, double *vals, hipStream_t stream);
 void launch_build_erec(int dim, const RowBlocksDev &rb, const double *geo, double *erec, int total,
                        hipStream_t stream);
 // K1: element-wise residual (-> res with atomics)

@@ -918,3 +918,62 @@ def test_deterministic_mode_is_bit_reproducible(oracle, transient):
     with pytest.raises(mrhyde_amd.MhaError):
         blk2.assemble_jacres(t(np.zeros(mp["ndof"])), torch.zeros(mp["ndof"], dtype=torch.float64, device="cuda"),
                              torch.zeros(blk2.get_graph()[1].shape[0], dtype=torch.float64, device="cuda"), deterministic=True)
+
+
+@pytest.mark.parametrize("dim,order,qdeg,ncell", [(3, 2, 4, (8, 8, 4)), (3, 1, 2, (16, 8, 8)), (2, 2, 4, (16, 16))])
+@pytest.mark.parametrize("transient", [False, True])
+def test_geometry_database_mode_is_bit_identical(oracle, monkeypatch, dim, order, qdeg, ncell, transient):
+    """One geometry shape in the block (a uniform mesh whose spacing is exactly representable): the Jacobian kernel runs
+    on one representative row block per pattern and the representative's runs of CRS rows are replicated
+    (`jacobian_database_mode`); MHA_BP_DATABASE=0 runs the full kernel.  Same inputs through the same instructions:
+    the two must agree BIT FOR BIT, and with the oracle to the usual tolerance; fixed rows, overwrite on garbage."""
+    torch = _torch()
+    import mrhyde_amd
+    monkeypatch.delenv("MHA_K1", raising=False)
+    monkeypatch.delenv("MHA_K2", raising=False)
+    m = affine_mesh(oracle, dim, order, ncell, shear=False)
+    rng = np.random.default_rng(5)
+    nd = m["ndof"]
+    u = rng.uniform(-1, 1, nd)
+    fixed = m["boundary"]
+    freq = [1.3, 0.7, 2.1][:dim]
+    kw, okw = {}, {}
+    if transient:
+        nsteps, nstages, stage = 2, 2, 1
+        A = np.array([[0.2928932188, 0.0], [0.7071067812, 0.2928932188]])
+        bb = np.array([0.7071067812, 0.2928932188])
+        bdf = np.array([1.5, -2.0, 0.5])
+        tr = dict(u_prev=rng.uniform(-1, 1, (nd, nsteps)), u_stage=rng.uniform(-1, 1, (nd, nstages)), stage=stage,
+                  butcher_A=A, butcher_b=bb, bdf=bdf, dt=0.02)
+        okw = dict(transient=tr, rho=1.3, cp=0.7)
+    ref = oracle.assemble_thermal(dim, order, qdeg, m["nodes"], m["lids"], m["offsets"], u, fixed=fixed,
+                                  source=("sinprod", 3.0, freq), diff=1.7, **okw)
+    got = {}
+    for db in (True, False):
+        if db:
+            monkeypatch.delenv("MHA_BP_DATABASE", raising=False)
+        else:
+            monkeypatch.setenv("MHA_BP_DATABASE", "0")
+        blk = make_block(m, dim, order, qdeg, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+        blk.set_function("thermal source", ("sinprod", 3.0, freq))
+        blk.set_function("thermal diffusion", 1.7)
+        t = lambda a: torch.tensor(a, device="cuda")
+        if transient:
+            blk.set_function("density", 1.3)
+            blk.set_function("specific heat", 0.7)
+            blk.set_time_integration(True, nsteps, nstages, stage, 0.02, A, bb, bdf)
+            kw = dict(u_prev=t(tr["u_prev"]), u_stage=t(tr["u_stage"]))
+        res = torch.full((nd,), 7.0, dtype=torch.float64, device="cuda")
+        vals = torch.full((len(ref["colind"]),), -3.0, dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(t(u), res, vals, path=mrhyde_amd.PATH_ROW_OWNER, overwrite=True, **kw)
+        torch.cuda.synchronize()
+        assert blk.info("block_patterns") > 0 and blk.info("affine_shapes") == 1
+        assert blk.info("jacobian_database_mode") == (1 if db else 0)
+        got[db] = vals.cpu().numpy().copy()
+        assert crs_err(got[db], ref) < RTOL and rel_err(res.cpu().numpy(), ref["res"]) < RTOL
+        if db:  # accumulating assemblies take the full kernel (a copy cannot add)
+            blk.assemble_jacres(t(u), res, vals, path=mrhyde_amd.PATH_ROW_OWNER, **kw)
+            torch.cuda.synchronize()
+            assert blk.info("jacobian_database_mode") == 0
+            assert crs_err(vals.cpu().numpy(), ref, 2.0) < RTOL
+    assert np.array_equal(got[True], got[False])
