@@ -891,7 +891,7 @@ void launch_build_erec2(int64_t total_records, int nsym, const int32_t *erec_ele
 // double (may be up to 15 below the run's first entry), first and one-past-last destination ENTRY of the run}: the list
 // comes from the host, sorted by destination.  Four chunks per wavefront and pass, every load of the pass issued before
 // its first store (one chunk at a time the kernel is a chain of dependent latencies: 326 us for the 1.07 GB of config 2).
-template <int U, bool NT>
+template <int U, bool NT, bool NOLOAD = false>
 __global__ __launch_bounds__(256) void replicate_runs_kernel(const int4 *__restrict__ chunks, int nchunks, double *vals) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (gridDim.x * 256) >> 6;
@@ -907,8 +907,8 @@ __global__ __launch_bounds__(256) void replicate_runs_kernel(const int4 *__restr
       v0[u] = base + u < nchunks && e >= t[u].z && e < t[u].w;
       v1[u] = base + u < nchunks && e + 1 >= t[u].z && e + 1 < t[u].w;
       const long long se = (long long)t[u].y + 2 * lane;
-      x0[u] = v0[u] ? vals[se] : 0.0;
-      x1[u] = v1[u] ? vals[se + 1] : 0.0;
+      x0[u] = (v0[u] && !NOLOAD) ? vals[se] : 1.0;  // (NOLOAD: profiling only -- what the stores alone cost)
+      x1[u] = (v1[u] && !NOLOAD) ? vals[se + 1] : 1.0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -941,6 +941,8 @@ void launch_replicate_runs(const int32_t *chunks, int nchunks, double *vals, hip
   else if (mode == 2) hipLaunchKernelGGL((replicate_runs_kernel<8, false>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
   else if (mode == 3) hipLaunchKernelGGL((replicate_runs_kernel<8, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
   else if (mode == 5) hipLaunchKernelGGL((replicate_runs_kernel<1, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  else if (mode == 9) hipLaunchKernelGGL((replicate_runs_kernel<2, true, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
+  else if (mode == 10) hipLaunchKernelGGL((replicate_runs_kernel<2, false, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
   else hipLaunchKernelGGL((replicate_runs_kernel<2, true>), dim3(grid), dim3(256), 0, stream, ch, nchunks, vals);
   MHA_HIP(hipGetLastError());
 }

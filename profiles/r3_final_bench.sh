@@ -8,4 +8,5 @@ for c in 2 3 4 5; do
   python -c "import json,sys; d=json.loads(open(sys.argv[1]).readlines()[-1]); print(sys.argv[1], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)" $O/final_bench_config$c.json
 done
 python bench.py --config 2 --mesh perturbed --steps 20 --warmup 5 --no-cpu-baseline > $O/final_bench_config2_perturbed.json 2> $O/final_bench_config2_perturbed.err
+python bench.py --config 2 --jacobian full --steps 20 --warmup 5 --no-cpu-baseline > $O/final_bench_config2_full.json 2> $O/final_bench_config2_full.err
 tail -c 400 $O/final_bench_config2_perturbed.json
