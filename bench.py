@@ -482,6 +482,8 @@ def main():
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--path", default="auto", choices=["auto", "element_atomic", "row_owner", "local_then_scatter", "row_gather"])
     ap.add_argument("--mesh", default="affine", choices=["affine", "perturbed"])
+    ap.add_argument("--no-full-compare", action="store_true",
+                    help="config 2 in geometry-database mode: do not run the full kernel after the timed region (profiling runs)")
     ap.add_argument("--jacobian", default="database", choices=["database", "full"],
                     help="config 2: 'full' keeps the matrix-core Jacobian kernel on every row block even when the mesh has one "
                          "element geometry (the default replicates one block per assembly pattern then: geometry-database mode)")
@@ -573,7 +575,7 @@ def main():
                "partition": ("strips of element rows, 1 per GPU" if args.config == 5 else "z-slabs, 1 per GPU") if world > 1 else "single block",
                "shared_row_bytes_per_step": wire}
         cfg.update(extra)
-        if args.config == 2 and world == 1 and str(extra.get("jacobian_mode", "")).startswith("geometry database"):
+        if args.config == 2 and world == 1 and not args.no_full_compare and str(extra.get("jacobian_mode", "")).startswith("geometry database"):
             # the same workload with the full kernel, outside the timed region: both numbers in one line
             os.environ["MHA_BP_DATABASE"] = "0"
             w2 = setup_thermal(args, torch, mrhyde_amd, rank, world, dev)

@@ -622,7 +622,8 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
           o.direct_slot = static_cast<const uint8_t *>(d_elem_slot_.data());
           o.direct_side = d_direct_side_.data();
           o.direct_vals = compute_jacobian ? crs_vals : nullptr;
-          o.direct_overwrite = overwrite ? 1 : 0;
+          static const bool porous_nt = [] { const char *m = std::getenv("MHA_POROUS_NT"); return m && m[0] == '1'; }();  // experiment: nontemporal entry stores
+          o.direct_overwrite = overwrite ? (porous_nt ? 2 : 1) : 0;
           launchPointEngine(compute_jacobian, o, 0, nelem_);
           launch_porous_direct_finish(blockDev(), d_inc_ptr_.data(), d_direct_diag_.data(), o.direct_part, res, o.direct_vals,
                                       overwrite ? 1 : 0, stream_);

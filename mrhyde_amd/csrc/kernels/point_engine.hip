@@ -368,6 +368,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
     if (out.compute_jacobian) {
       typedef double v4d __attribute__((ext_vector_type(4)));
       double *lj_e = out.local_J ? out.local_J + (size_t)(e - out.local_base) * n * n : nullptr;
+      const bool nt_store = (dbg_stop & 16) != 0;
       constexpr int NWV = TPE / 64;             // waves working on this element
       const int wv = gt >> 6, lane = gt & 63, l15 = lane & 15, l4 = lane >> 4;
       // When every wave has at most one column tile (the 89-dof navierstokes element: seven tiles on eight waves), the
@@ -499,7 +500,9 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
                   const double val = d[t] * s_sgn[i] * sgj;
                   if (lj_e) {
                     double *lj = lj_e + (pos_i * n + pos_j);
-                    *lj = out.local_store ? val : *lj + val;
+                    // (the row-gather scratch is written once and read once, by another kernel: nontemporal)
+                    if (out.local_store) { if (nt_store) __builtin_nontemporal_store(val, lj); else *lj = val; }
+                    else *lj = *lj + val;
                   }
                   if (out.crs_vals && !(b.fixed && b.fixed[row_i])) {
                     const size_t so = ((size_t)e * n + pos_i) * n + pos_j;

@@ -197,7 +197,8 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
           else if (fj == 0) v = au * Bv[fi - 1];
           else v = au * (fj > fi ? A[fi - 1][fj - 1] : A[fj - 1][fi - 1]);
           double *dst = rowv + srow[pos[fj]];
-          *dst = ow ? v : *dst + v;
+          if (ow) { if (out.direct_overwrite == 2) __builtin_nontemporal_store(v, dst); else *dst = v; }
+          else *dst = *dst + v;
         }
       }
     }

@@ -21,13 +21,13 @@ pmc() {  # name, counter, bench args...
   echo "pmc $name $ctr" >> $LOG
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -- python $R/bench.py "$@" > $O/pmc_${name}_$ctr.log 2>&1 || { echo "pmc $name $ctr FAILED" >> $LOG; return 1; }
 }
-stats config2 --steps 20 --warmup 3 --no-cpu-baseline &&
+stats config2 --steps 20 --warmup 3 --no-cpu-baseline --no-full-compare &&
 stats config2_perturbed --mesh perturbed --steps 20 --warmup 3 --no-cpu-baseline &&
 stats config3 --config 3 --steps 20 --warmup 3 --no-cpu-baseline &&
 stats config4 --config 4 --steps 5 --warmup 1 --no-cpu-baseline &&
 stats config5 --config 5 --steps 20 --warmup 3 --no-cpu-baseline &&
 for c in FETCH_SIZE WRITE_SIZE; do
-  pmc config2 $c --steps 3 --warmup 1 --no-cpu-baseline &&
+  pmc config2 $c --steps 3 --warmup 1 --no-cpu-baseline --no-full-compare &&
   pmc config2_perturbed $c --mesh perturbed --steps 3 --warmup 1 --no-cpu-baseline &&
   pmc config3 $c --config 3 --steps 3 --warmup 1 --no-cpu-baseline &&
   pmc config4 $c --config 4 --steps 3 --warmup 1 --no-cpu-baseline &&
