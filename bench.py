@@ -383,9 +383,20 @@ def setup_block(kind, args, torch, mrhyde_amd, rank, world, dev):
 
     def info():
         pname = {4: "point_engine", 5: "row_gather"}.get(blk.info("last_path"), str(blk.info("last_path")))
-        kern = (("porous_element_direct_kernel (element threads store into the CRS) + porous_direct_finish_kernel" if blk.info("porous_direct") else "porous_element_kernel (dense element arrays) + row_gather_kernel") if kind == "porous"
+        pd = blk.info("porous_direct") if kind == "porous" else 0
+        kern = (("porous_element_direct_res_kernel (residual parts, all elements) + porous_element_direct_kernel (entries of the "
+                 "representative rows) + porous_direct_finish_kernel + replicate_runs_kernel" if pd == 2
+                 else "porous_element_direct_kernel (element threads store into the CRS) + porous_direct_finish_kernel" if pd == 1
+                 else "porous_element_kernel (dense element arrays) + row_gather_kernel") if kind == "porous"
                 else "point_engine_kernel<3, navierstokes> (dense element matrices) + row_gather_kernel")
-        return pname, kern, {}
+        extra = {}
+        if kind == "porous":
+            extra["jacobian_mode"] = ("database: uniform block with constant permeability / mobility -- every element matrix is the same; the "
+                                      "entries of a few representative rows per row class are computed and replicated (bit-identical to the "
+                                      "direct form, MHA_POROUS_DATABASE=0)" if pd == 2
+                                      else "direct: every element thread stores its matrix entries into the CRS" if pd == 1
+                                      else "dense element arrays + row gather")
+        return pname, kern, extra
 
     def cpu():
         log("cpu baseline (1 thread, bounded sample)")

@@ -219,6 +219,133 @@ void AssemblyManager::prepareRowGather(bool need_jacobian, bool dense) {
   d_gather_res_.resize(static_cast<size_t>(nelem_) * n_);
 }
 
+// Database mode of the direct form.  Preconditions, checked once per mesh / graph (the coefficient kinds per assembly):
+// every element has the same vertex offsets from its first vertex and the same orientation signs, bit for bit (then the
+// direct kernel, which works on relative coordinates, produces the same matrix for every element).  Rows are classified
+// by what determines their values: fixed flag, and per incident element its local dof and the slots of the element's
+// columns in the row.  Per class the first run of >= 2 K consecutive rows gives K = ceil(128 / len) + 2 representative
+// rows (enough for any 1 KB chunk to be sourced contiguously from their periodic image); every other row of a class that
+// has representatives is REPLICATED; the rest (fixed rows, short or rare classes, the representatives) are COMPUTED as
+// before, by the elements incident to them.
+bool AssemblyManager::porousDatabaseUsable() {
+  PorousDatabase &db = porous_db_;
+  if (db.state >= 0) return db.state == 1;
+  db.state = 0;
+  const char *m = std::getenv("MHA_POROUS_DATABASE");
+  if (m && m[0] == '0') { db.why = "MHA_POROUS_DATABASE=0"; return false; }
+  if (!porousDirectUsable() || elem_slot_bytes_ != 1) { db.why = "direct form not usable"; return false; }
+  const int nn = nnodes_, d = dim_;
+  std::vector<double> nodes(static_cast<size_t>(nelem_) * nn * d);
+  d_nodes_.download(nodes.data());
+  for (int e = 1; e < nelem_; ++e)
+    for (int k = 1; k < nn; ++k)
+      for (int c = 0; c < d; ++c) {
+        const double a = nodes[(static_cast<size_t>(e) * nn + k) * d + c] - nodes[static_cast<size_t>(e) * nn * d + c];
+        const double b0 = nodes[static_cast<size_t>(k) * d + c] - nodes[c];
+        if (std::memcmp(&a, &b0, sizeof(double)) != 0) { db.why = "elements of different shapes"; return false; }
+      }
+  if (has_orient_)
+    for (int e = 1; e < nelem_; ++e)
+      if (std::memcmp(&h_orient_[static_cast<size_t>(e) * n_], &h_orient_[0], n_) != 0) { db.why = "orientation signs differ between elements"; return false; }
+  // ---- row classes ----
+  prepareElemSlots();
+  std::vector<uint8_t> slot(static_cast<size_t>(nelem_) * n_ * n_);
+  MHA_HIP(hipStreamSynchronize(stream_));
+  d_elem_slot_.download(slot.data());
+  std::vector<int32_t> ptr, elem, lpos, offs(n_), p2d(n_, 0);
+  build_row_incidence(nrows_, nelem_, n_, h_lids_.data(), ptr, elem, lpos);
+  d_offsets_.download(offs.data());
+  for (int f = 0; f < n_; ++f) p2d[offs[f]] = f;
+  std::unordered_map<std::string, int32_t> classes;
+  std::vector<int32_t> cls(nrows_, -1);
+  std::string key;
+  for (int r = 0; r < nrows_; ++r) {
+    if (has_fixed_ && h_fixed_[r]) continue;  // fixed rows: computed (zeroed) by the finishing pass
+    key.clear();
+    key.push_back(static_cast<char>(h_rowptr_[r + 1] - h_rowptr_[r]));
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+      key.push_back(static_cast<char>(p2d[lpos[k]]));
+      const uint8_t *srow = &slot[(static_cast<size_t>(elem[k]) * n_ + lpos[k]) * n_];
+      for (int f = 0; f < n_; ++f) key.push_back(static_cast<char>(srow[offs[f]]));
+    }
+    cls[r] = classes.emplace(key, static_cast<int32_t>(classes.size())).first->second;
+  }
+  const int nc = static_cast<int>(classes.size());
+  std::vector<int32_t> rep_entry(nc, -1), len_of(nc, 0), K_of(nc, 0);
+  std::vector<uint8_t> replicated(nrows_, 0);
+  // pass 1: representatives = the first K rows of the first long run of a class
+  for (int r = 0; r < nrows_;) {
+    int r1 = r + 1;
+    while (r1 < nrows_ && cls[r1] == cls[r]) ++r1;
+    const int c = cls[r];
+    if (c >= 0 && rep_entry[c] < 0) {
+      const int len = h_rowptr_[r + 1] - h_rowptr_[r];
+      const int K = len > 0 ? (128 + len - 1) / len + 2 : 0;
+      if (len > 0 && r1 - r >= 2 * K) { rep_entry[c] = h_rowptr_[r]; len_of[c] = len; K_of[c] = K; for (int q = r + K; q < r1; ++q) replicated[q] = 1; }
+    }
+    r = r1;
+  }
+  // pass 2: every other row of a class that has representatives
+  for (int r = 0; r < nrows_; ++r) {
+    const int c = cls[r];
+    if (c < 0 || rep_entry[c] < 0 || replicated[r]) continue;
+    const bool is_rep = h_rowptr_[r] >= rep_entry[c] && h_rowptr_[r] < rep_entry[c] + K_of[c] * len_of[c];
+    if (!is_rep) replicated[r] = 1;
+  }
+  // chunks of the replicated ranges (maximal runs of replicated rows of one class), 1 KB on 128-byte lines
+  std::vector<int32_t> chunks;
+  int64_t computed = 0;
+  for (int r = 0; r < nrows_;) {
+    if (!replicated[r]) { ++computed; ++r; continue; }
+    int r1 = r + 1;
+    while (r1 < nrows_ && replicated[r1] && cls[r1] == cls[r]) ++r1;
+    const int c = cls[r], len = len_of[c];
+    const int64_t dbeg = h_rowptr_[r], dend = h_rowptr_[r1];
+    for (int64_t c0 = dbeg / 16 * 16; c0 < dend; c0 += 128) {
+      const int64_t ph = ((c0 - dbeg) % len + len) % len;
+      chunks.push_back(static_cast<int32_t>(c0 / 2));
+      chunks.push_back(static_cast<int32_t>(rep_entry[c] + ph));
+      chunks.push_back(static_cast<int32_t>(dbeg));
+      chunks.push_back(static_cast<int32_t>(dend));
+    }
+    r = r1;
+  }
+  if (chunks.empty()) { db.why = "no class has a run long enough to replicate"; return false; }
+  // elements incident to computed rows store their entries; diagonal positions of the computed face rows only
+  std::vector<uint8_t> jacflag(nelem_, 0);
+  std::vector<int32_t> diag(nrows_, -1);
+  for (int r = 0; r < nrows_; ++r) {
+    if (replicated[r]) continue;
+    bool face = false;
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) { jacflag[elem[k]] = 1; face = face || p2d[lpos[k]] > 0; }
+    if (face)
+      for (int k = h_rowptr_[r]; k < h_rowptr_[r + 1]; ++k)
+        if (h_colind_[k] == r) diag[r] = k;
+  }
+  db.jacflag.upload(jacflag);
+  {
+    std::vector<int32_t> elist;
+    for (int e = 0; e < nelem_; ++e)
+      if (jacflag[e]) elist.push_back(e);
+    db.num_listed = static_cast<int>(elist.size());
+    if (elist.empty()) elist.push_back(0);
+    db.elist.upload(elist);
+  }
+  db.diag.upload(diag);
+  db.chunks.upload(chunks);
+  db.num_chunks = static_cast<int>(chunks.size() / 4);
+  db.num_classes = nc;
+  db.computed_rows = computed;
+  db.state = 1;
+  if (std::getenv("MHA_VERBOSE")) {
+    int64_t flagged = 0;
+    for (uint8_t f : jacflag) flagged += f;
+    fprintf(stderr, "[mrhyde_amd] porousMixed database mode: %d row classes, %lld of %d rows computed, %lld of %d elements store entries, %d chunks\n",
+            nc, (long long)computed, nrows_, (long long)flagged, nelem_, db.num_chunks);
+  }
+  return true;
+}
+
 // The direct form of the porousMixed assembly (kernels/porous_element.hip) rests on one property of the mesh: any two
 // elements share at most ONE dof (a face), so that a matrix entry (i, j), i != j, has one contributing element and a
 // row at most two.  Checked here on the LID lists, once per mesh / graph; anything else keeps the row gather.
@@ -310,6 +437,7 @@ void AssemblyManager::setGraph(const int32_t *rowptr, const int32_t *colind) {
   has_elem_slot_ = false;
   has_incidence_ = false;
   porous_direct_ = -1;
+  porous_db_ = PorousDatabase();
 }
 
 void AssemblyManager::selectPhysics(int physics_id) {
@@ -624,10 +752,31 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
           o.direct_vals = compute_jacobian ? crs_vals : nullptr;
           static const bool porous_nt = [] { const char *m = std::getenv("MHA_POROUS_NT"); return m && m[0] == '1'; }();  // experiment: nontemporal entry stores
           o.direct_overwrite = overwrite ? (porous_nt ? 2 : 1) : 0;
+          // database mode: overwriting assemblies of a uniform block with constant permeability / mobility
+          bool pdb = overwrite && compute_jacobian && (reinterpret_cast<uintptr_t>(crs_vals) & 127u) == 0;
+          for (const char *name : {"Kinv_xx", "Kinv_yy", "Kinv_zz", "total_mobility"})
+            pdb = pdb && functions_.has(name) && functions_.evaluate(name).kind == MHA_FUNC_CONSTANT;
+          pdb = pdb && porousDatabaseUsable();
+          static const bool two_kernels = [] { const char *m = std::getenv("MHA_POROUS_DB_LEAN"); return !(m && m[0] == '0'); }();
+          if (pdb && two_kernels && functions_.evaluate("source").kind != MHA_FUNC_EXPRESSION) {
+            // database mode: the lean build (residual parts only) over all elements, then the full build over the few
+            // elements incident to computed rows (same records, rewritten with the diagonal parts; their entries)
+            ElemOut lean = o;
+            lean.direct_res_only = 1;
+            launchPointEngine(compute_jacobian, lean, 0, nelem_);
+            o.direct_elist = porous_db_.elist.data();
+            launchPointEngine(compute_jacobian, o, 0, porous_db_.num_listed);
+            launch_porous_direct_finish(blockDev(), d_inc_ptr_.data(), porous_db_.diag.data(), o.direct_part, res, o.direct_vals, 1, stream_);
+            launch_replicate_runs(porous_db_.chunks.data(), porous_db_.num_chunks, crs_vals, stream_);
+            last_porous_direct_ = 2;
+            break;
+          }
+          if (pdb) o.direct_jacflag = porous_db_.jacflag.data();
           launchPointEngine(compute_jacobian, o, 0, nelem_);
-          launch_porous_direct_finish(blockDev(), d_inc_ptr_.data(), d_direct_diag_.data(), o.direct_part, res, o.direct_vals,
-                                      overwrite ? 1 : 0, stream_);
-          last_porous_direct_ = 1;
+          launch_porous_direct_finish(blockDev(), d_inc_ptr_.data(), pdb ? porous_db_.diag.data() : d_direct_diag_.data(), o.direct_part,
+                                      res, o.direct_vals, overwrite ? 1 : 0, stream_);
+          if (pdb) launch_replicate_runs(porous_db_.chunks.data(), porous_db_.num_chunks, crs_vals, stream_);
+          last_porous_direct_ = pdb ? 2 : 1;
           break;
         }
         last_porous_direct_ = 0;

@@ -137,6 +137,20 @@ class AssemblyManager {
   DeviceBuffer<uint8_t> d_direct_side_;  // [E][n] (dof order): which incidence of its row the element is
   DeviceBuffer<int32_t> d_direct_diag_;  // [nrows] CRS position of the diagonal of a face row, -1 otherwise
   bool porousDirectUsable();
+  // database mode of the direct form (uniform mesh, constant coefficients: every element matrix is the same): rows of
+  // the same CLASS -- same incident local dofs, same column slots -- are equal, so the element threads store the entries
+  // of a few representative rows per class only and replicate_runs_kernel fills the rest
+  struct PorousDatabase {
+    int state = -1;  // -1 not tried, 0 not usable (why), 1 built
+    std::string why;
+    DeviceBuffer<uint8_t> jacflag;     // [E]
+    DeviceBuffer<int32_t> elist;       // the elements with jacflag set
+    int num_listed = 0;
+    DeviceBuffer<int32_t> diag, chunks;  // finishing pass: diagonal positions of the COMPUTED face rows; copy chunks
+    int num_chunks = 0, num_classes = 0;
+    int64_t computed_rows = 0;
+  } porous_db_;
+  bool porousDatabaseUsable();
   bool has_incidence_ = false;
   int max_row_ = 0;
   void prepareRowGather(bool need_jacobian, bool dense = true);

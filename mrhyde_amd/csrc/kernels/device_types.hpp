@@ -87,6 +87,10 @@ struct ElemOut {
   // of the row's incident elements this one is) for the finishing pass over the rows
   double *direct_part = nullptr;
   const uint8_t *direct_side = nullptr; // [E][n] (dof order)
+  const int32_t *direct_elist = nullptr;    // direct form on a LIST of elements (e_count entries) instead of a range
+  int direct_res_only = 0;                  // 1: the lean build: residual parts only (rows' records), no matrix arithmetic
+  const uint8_t *direct_jacflag = nullptr;  // [E] or null: 0 = the element's matrix entries are not stored (its rows are
+                                            // replicated from representative rows: database mode), residual parts always are
   double *direct_vals = nullptr;        // CRS values (null: residual only)
   const uint8_t *direct_slot = nullptr; // [E][n][n] position of column LIDs[e][j] inside row LIDs[e][i] (LID-position order)
   int direct_overwrite = 0;

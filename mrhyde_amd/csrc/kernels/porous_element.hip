@@ -32,8 +32,11 @@ namespace mha {
 namespace {
 
 constexpr int kPorousThreads = 128;
+#ifndef MHA_POROUS_RES_WAVES
+#define MHA_POROUS_RES_WAVES 2
+#endif
 
-template <int DIM, bool EXPR, bool DOF, bool DIRECT = false>
+template <int DIM, bool EXPR, bool DOF, bool DIRECT = false, bool RESONLY = false>
 __device__ __forceinline__ void porous_element_body(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp,
                                                     const TimeDev &tm, const ElemOut &out) {
   constexpr int NN = 1 << DIM, NU = 2 * DIM, N = 1 + NU;
@@ -46,7 +49,8 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
     __syncthreads();
   }
   const bool active = tid < cnt;
-  const int e = b.e_begin + e0 + (active ? tid : 0), NQ = vl.nq;
+  const int eidx = b.e_begin + e0 + (active ? tid : 0), NQ = vl.nq;
+  const int e = (DIRECT && out.direct_elist) ? out.direct_elist[eidx] : eidx;
   const int32_t *L = b.lids + (size_t)e * N;
   // gather + seeding values; positions: p at offsets[0], u_i at offsets[1 + i]
   int pos[N];
@@ -68,10 +72,22 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
   }
   double xn[DOF ? 1 : NN][DIM];
   double *sx = sm + (size_t)tid * NN * DIM;  // DOF: the thread's own vertices (read back by the same thread: no barrier)
+  double x0[DIM];  // DIRECT: vertex 0; the other vertices are kept RELATIVE to it, so that elements of the same shape go
+                   // through bit-identical geometry arithmetic wherever they sit (what the database mode relies on)
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) x0[d] = 0.0;
   if constexpr (DOF) {
     const double *src = b.nodes + (size_t)e * NN * DIM;  // 16-byte aligned: NN * DIM is even
 #pragma unroll
     for (int k = 0; k < NN * DIM; k += 2) *reinterpret_cast<double2 *>(sx + k) = *reinterpret_cast<const double2 *>(src + k);
+    if constexpr (DIRECT) {
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) x0[d] = sx[d];
+#pragma unroll
+      for (int k = 0; k < NN; ++k)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) sx[k * DIM + d] -= x0[d];
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < NN; ++k)
@@ -91,6 +107,14 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
 #pragma unroll
     for (int j = 0; j < NU; ++j) A[i][j] = 0.0;
   }
+  // The matrix part (M, A: two thirds of the point's arithmetic, 42 registers) is compiled out of the loop for wavefronts
+  // none of whose elements need it: residual-only assemblies, and in database mode every wavefront without an element
+  // incident to a computed row (all but ~2 % of them at config 3).
+  const bool need_matrix_lane = !RESONLY && out.compute_jacobian &&
+      (DIRECT ? (active && out.direct_vals != nullptr && (!out.direct_jacflag || out.direct_jacflag[e])) : out.local_J != nullptr);
+  const bool need_matrix = __builtin_amdgcn_ballot_w64(need_matrix_lane) != 0;
+  auto point_loop = [&](auto jm_tag) {
+  constexpr bool JM = decltype(jm_tag)::value;
   for (int q = 0; q < NQ; ++q) {
     double J[DIM * DIM], Ji[DIM * DIM], det, x[DIM], xi[DIM];
 #pragma unroll
@@ -105,7 +129,7 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < NN; ++k) s += (DOF ? sx[k * DIM + r] : xn[k][r]) * b.nodeval[k * NQ + q];
-      x[r] = s;
+      x[r] = DIRECT ? x0[r] + s : s;  // (the geometry basis sums to one)
     }
     invert<DIM>(J, Ji, det);
     // reference point from the u table: phihat_{2c+1}(q) = (1 + x_c)/2
@@ -140,22 +164,29 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
 #pragma unroll
       for (int d = 0; d < DIM; ++d) t += kinv[d] * uq[d] * J[d * DIM + c];
       ku[c] = t * wm;
+      if constexpr (JM) {
 #pragma unroll
-      for (int c2 = c; c2 < DIM; ++c2) {
-        double s = 0.0;
+        for (int c2 = c; c2 < DIM; ++c2) {
+          double s = 0.0;
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) s += J[d * DIM + c] * kinv[d] * J[d * DIM + c2];
-        M[c][c2] = s * wm;
+          for (int d = 0; d < DIM; ++d) s += J[d * DIM + c] * kinv[d] * J[d * DIM + c2];
+          M[c][c2] = s * wm;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int c = i >> 1;
       ru[i] += ku[c] * ph[i];
+      if constexpr (JM) {
 #pragma unroll
-      for (int j = i; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1];  // symmetric: upper triangle only (c <= j >> 1)
+        for (int j = i; j < NU; ++j) A[i][j] += ph[i] * ph[j] * M[c][j >> 1];  // symmetric: upper triangle only (c <= j >> 1)
+      }
     }
   }
+  };
+  if constexpr (RESONLY) point_loop(std::false_type());
+  else { if (need_matrix) point_loop(std::true_type()); else point_loop(std::false_type()); }
   // signs and the divergence terms
   double Bv[NU], divu = 0.0;
 #pragma unroll
@@ -172,9 +203,12 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
   if constexpr (DIRECT) {
     // straight into the CRS: every entry this element owns alone (all but the diagonals of its face rows); residual
     // entries and diagonal parts go to the side array the finishing pass sums per row (ElemOut::direct_*)
+    // (database mode: most wavefronts have no element whose entries are stored -- one scalar branch skips the 43 stores)
+    const bool any_jac = !RESONLY && __builtin_amdgcn_ballot_w64(active && out.direct_vals && out.compute_jacobian &&
+                                                                 (!out.direct_jacflag || out.direct_jacflag[e])) != 0;
     if (active) {
       const uint8_t *side = out.direct_side + (size_t)e * N;
-      const bool jac = out.direct_vals && out.compute_jacobian;
+      const bool jac = !RESONLY && out.direct_vals && out.compute_jacobian && (!out.direct_jacflag || out.direct_jacflag[e]);
       const uint8_t *sl = out.direct_slot + (size_t)e * N * N;
       double *vals = out.direct_vals;
       const bool ow = out.direct_overwrite != 0;
@@ -186,7 +220,7 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
         rec.x = fi == 0 ? -rp : -ru[fi - 1];
         rec.y = (fi > 0 && jac) ? au * A[fi - 1][fi - 1] : 0.0;
         *reinterpret_cast<double2 *>(out.direct_part + (size_t)row * 4 + side[fi] * 2) = rec;
-        if (!jac || (b.fixed && b.fixed[row])) continue;
+        if (!any_jac || !jac || (b.fixed && b.fixed[row])) continue;
         double *rowv = vals + b.rowptr[row];
         const uint8_t *srow = sl + pos[fi] * N;
 #pragma unroll
@@ -277,6 +311,13 @@ __global__ __launch_bounds__(kPorousThreads) __attribute__((amdgpu_waves_per_eu(
     BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm, ElemOut out) {
   porous_element_body<DIM, false, true, true>(b, vl, pp, tm, out);
 }
+// the lean build of the direct form: residual parts only (database mode runs it over all elements, the full build over
+// the few elements incident to computed rows)
+template <int DIM>
+__global__ __launch_bounds__(kPorousThreads) __attribute__((amdgpu_waves_per_eu(MHA_POROUS_RES_WAVES))) void porous_element_direct_res_kernel(
+    BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm, ElemOut out) {
+  porous_element_body<DIM, false, true, true, true>(b, vl, pp, tm, out);
+}
 template <int DIM>
 __global__ __launch_bounds__(kPorousThreads) void porous_element_direct_expr_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp,
                                                                                    TimeDev tm, ElemOut out) {
@@ -320,7 +361,8 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
     MHA_REQUIRE(out.direct_slot != nullptr && out.direct_side != nullptr && out.local_base == 0, MHA_ERR_INVALID, "porous direct form: slot map missing");
     const size_t ldsd = sizeof(double) * kPorousThreads * (size_t)(1 << b.dim) * b.dim;
     auto god = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(kPorousThreads), ldsd, stream, b, vl, pp, tm, out); };
-    if (has_expression(pp)) { if (b.dim == 2) god(porous_element_direct_expr_kernel<2>); else god(porous_element_direct_expr_kernel<3>); }
+    if (out.direct_res_only && !has_expression(pp)) { if (b.dim == 2) god(porous_element_direct_res_kernel<2>); else god(porous_element_direct_res_kernel<3>); }
+    else if (has_expression(pp)) { if (b.dim == 2) god(porous_element_direct_expr_kernel<2>); else god(porous_element_direct_expr_kernel<3>); }
     else { if (b.dim == 2) god(porous_element_direct_kernel<2>); else god(porous_element_direct_kernel<3>); }
     MHA_HIP(hipGetLastError());
     return;

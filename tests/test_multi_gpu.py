@@ -193,6 +193,58 @@ def test_porous_direct_form_equals_row_gather_and_oracle(oracle, monkeypatch, di
     assert rel_err(results[True][0], results[False][0]) < 1e-13 and rel_err(results[True][1], results[False][1]) < 1e-13
 
 
+@pytest.mark.parametrize("dim,ncell", [(3, (64, 2, 4)), (2, (128, 4))])
+@pytest.mark.parametrize("transient", [False, True])
+def test_porous_database_mode_is_bit_identical(oracle, monkeypatch, dim, ncell, transient):
+    """porousMixed on a UNIFORM block with constant permeability / mobility: every element matrix is the same, rows of
+    the same class (incident local dofs + column slots) are equal; the direct kernel stores the entries of a few
+    representative rows per class and replicate_runs_kernel fills the rest (`porous_direct` = 2).  Bit for bit the
+    matrix of the plain direct form (MHA_POROUS_DATABASE=0: `porous_direct` = 1), and the oracle's to tolerance; the
+    residual likewise; fixed rows, overwrite on garbage.  (Long x-lines: a class needs a run of >= 2 (ceil(128 / len) + 2)
+    consecutive rows to have representatives.)"""
+    torch = _torch()
+    import mrhyde_amd
+    rng = np.random.default_rng(67)
+    m = oracle.mesh_multi(dim, ncell, [oracle.HVOL, oracle.HDIV], [0, 1])  # unit-spaced, not warped: exactly uniform
+    u = rng.uniform(-1, 1, m["ndof"])
+    fixed = (rng.uniform(size=m["ndof"]) < 0.02).astype(np.uint8)
+    funcs = {"source": ("sinprod", 2.0, [0.11, 0.7, 1.9][:dim]), "Kinv_xx": 1.3, "Kinv_yy": 0.7, "Kinv_zz": 2.1,
+             "total_mobility": 1.9}
+    tr = transient_state(rng, m["ndof"], u) if transient else None
+    ref = oracle.assemble_block(m, oracle.PHYS_POROUS_MIXED, 2, u, funcs=funcs, transient=tr, fixed=fixed)
+    got = {}
+    for db in (True, False):
+        if db:
+            monkeypatch.delenv("MHA_POROUS_DATABASE", raising=False)
+        else:
+            monkeypatch.setenv("MHA_POROUS_DATABASE", "0")
+        blk = make_block(m, "porousMixed", 2, fixed=fixed, graph=(ref["rowptr"], ref["colind"]))
+        for k, v in funcs.items():
+            blk.set_function(k, v)
+        kw = {}
+        if tr is not None:
+            blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+            kw = dict(u_prev=torch.tensor(tr["u_prev"], device="cuda"), u_stage=torch.tensor(tr["u_stage"], device="cuda"))
+        ud = torch.tensor(u, device="cuda")
+        res = torch.full((m["ndof"],), 7.0, dtype=torch.float64, device="cuda")
+        vals = torch.full((len(ref["colind"]),), -3.0, dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(ud, res, vals, overwrite=True, **kw)
+        torch.cuda.synchronize()
+        assert blk.info("porous_direct") == (2 if db else 1)
+        got[db] = (res.cpu().numpy().copy(), vals.cpu().numpy().copy())
+        assert rel_err(got[db][0], ref["res"]) < RTOL and crs_err(got[db][1], ref) < RTOL
+        for r in np.flatnonzero(fixed)[:30]:
+            assert got[db][0][r] == 0.0 and np.all(got[db][1][ref["rowptr"][r]:ref["rowptr"][r + 1]] == 0.0)
+        if db:  # an accumulating assembly cannot replicate: plain direct form
+            blk.assemble_jacres(ud, res, vals, **kw)
+            torch.cuda.synchronize()
+            assert blk.info("porous_direct") == 1
+            assert rel_err(vals.cpu().numpy(), 2 * got[db][1]) < 1e-14
+    # the matrix: bit for bit; the residual comes from the lean (residual-only) build of the same loop in database mode,
+    # whose arithmetic the compiler schedules differently: equal to round-off
+    assert np.array_equal(got[True][1], got[False][1]) and rel_err(got[True][0], got[False][0]) < 1e-14
+
+
 @pytest.mark.parametrize("dim,ncell,orders", [(2, (4, 3), (1, 1)), (2, (3, 2), (2, 1)), (3, (2, 2, 2), (2, 1)),
                                              (3, (2, 3, 2), (1, 1))])
 @pytest.mark.parametrize("mode", ["plain", "supg+pspg transient", "fix_uz"])
