@@ -772,6 +772,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
             break;
           }
           if (pdb) o.direct_jacflag = porous_db_.jacflag.data();
+          if (!compute_jacobian) o.direct_res_only = 1;  // residual-only assemblies: the lean build
           launchPointEngine(compute_jacobian, o, 0, nelem_);
           launch_porous_direct_finish(blockDev(), d_inc_ptr_.data(), pdb ? porous_db_.diag.data() : d_direct_diag_.data(), o.direct_part,
                                       res, o.direct_vals, overwrite ? 1 : 0, stream_);
