@@ -2377,7 +2377,7 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
     else launch_thermal_affine_element(dim_, order_, ref_.nq1, blockDev(), ph, af, res, s);
   };
   auto jacobian = [&](hipStream_t s) {  // K2: pattern GEMMs on the matrix cores when the rows group, row blocks otherwise
-    if (bpat_.usable && bpat_.db_mode && out.overwrite && !bpat_.dev.timing) {
+    if (bpat_.usable && bpat_.db_mode && out.overwrite && !bpat_.dev.timing && (reinterpret_cast<uintptr_t>(out.vals) & 127u) == 0) {  // (the copy's chunks sit on 128-byte lines of the caller's array)
       // geometry-database mode: the representatives' rows, then their copies (same stream: ordered)
       launch_block_pattern_jacobian(bpat_.dev_rep, out, su, st, s);
       launch_replicate_runs(bpat_.copy_chunks.data(), bpat_.copy_runs, out.vals, s);
