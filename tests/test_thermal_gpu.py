@@ -976,4 +976,9 @@ def test_geometry_database_mode_is_bit_identical(oracle, monkeypatch, dim, order
             torch.cuda.synchronize()
             assert blk.info("jacobian_database_mode") == 0
             assert crs_err(vals.cpu().numpy(), ref, 2.0) < RTOL
+            # a value array that does not start on a 128-byte line: the full kernel again, same bits
+            big = torch.full((len(ref["colind"]) + 1,), -3.0, dtype=torch.float64, device="cuda")
+            blk.assemble_jacres(t(u), res, big[1:], path=mrhyde_amd.PATH_ROW_OWNER, overwrite=True, **kw)
+            torch.cuda.synchronize()
+            assert blk.info("jacobian_database_mode") == 0 and np.array_equal(big[1:].cpu().numpy(), got[True])
     assert np.array_equal(got[True], got[False])
