@@ -2365,8 +2365,11 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
     if (compute_jacobian) launch_block_pattern_jacobian(bpat_.dev, out, ph.time.alpha_u * ph.diff.amp, ph.time.alpha_t * ph.rho.amp * ph.cp.amp, stream_);
     return;
   }
-  // K1 accumulates the residual with atomics: the fused zeroing becomes a (small) memset
-  if (overwrite) MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
+  // K1 accumulates the residual with atomics: the fused zeroing becomes a (small) memset -- on the stream K1 runs on (with
+  // the side stream below it no longer sits in front of the Jacobian kernels)
+  static const int overlap_early = [] { const char *m = std::getenv("MHA_K1K2_OVERLAP"); return m ? std::atoi(m) : 1; }();
+  const bool memset_on_side = overwrite && overlap_early && compute_jacobian;
+  if (overwrite && !memset_on_side) MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, stream_));
   // K1 (residual, VALU-bound) and K2 (Jacobian, latency-bound) write different arrays: K2 goes first on the
   // context's stream and K1 on a side stream, so that K1's workgroups fill the wave slots K2 leaves free
   // (0.743 -> 0.686 ms per assembly on config 2, profiles/r1_ab_k1k2_overlap.log); MHA_K1K2_OVERLAP=0 serialises them
@@ -2403,6 +2406,7 @@ void AssemblyManager::launchRowOwner(bool compute_jacobian, bool overwrite, doub
     }
     MHA_HIP(hipEventRecord(ev_fork_, stream_));
     MHA_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+    if (memset_on_side) MHA_HIP(hipMemsetAsync(res, 0, sizeof(double) * nrows_, side_stream_));
     if (overlap == 2) residual(side_stream_);
     jacobian(stream_);
     if (overlap != 2) residual(side_stream_);
