@@ -593,7 +593,15 @@ int mha_export_add(const mha_export_plan *p, mha_comm *c, double *vals_dev, doub
  *       "row_block_max_acc","row_owner_lds_bytes","block_patterns","block_pattern_roles",
  *       "block_pattern_blocks","block_pattern_mfma"
  * (the block_pattern keys are 0 when the matrix-core form of the row-owner Jacobian is not in use: MHA_K2=blocks,
- * or a mesh whose row blocks share too few assembly patterns)                            */
+ * or a mesh whose row blocks share too few assembly patterns)
+ * round 3: "row_owner_kind" (1 affine kernels, 2 general-element kernel, of the last assembly), "general_row_blocks",
+ *   "affine_shapes"          distinct geometry records (shape part, bit for bit) of the block's affine elements -- the
+ *                            geometry database behind the affine path (reference: identifyVolumetricDatabase,
+ *                            assemblyManager.cpp:4314-4467, with exact matching)
+ *   "jacobian_database_mode" 1: the last affine row-owner Jacobian was computed for one row block per assembly pattern
+ *                            and replicated (one shape, overwriting assembly); bit-identical to the full kernel
+ *   "porous_direct"          last porousMixed assembly behind MHA_PATH_ROW_GATHER: 0 dense element arrays + row gather,
+ *                            1 element threads stored into the CRS, 2 database mode (representative rows + replication) */
 int mha_get_info(mha_context *ctx, const char *key, int64_t *value);
 /* average device time (ms) of the last assembly's kernels, measured with HIP events on the
  * context's stream; valid after mha_set_timing(ctx,1).                                  */
