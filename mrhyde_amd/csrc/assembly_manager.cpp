@@ -247,6 +247,18 @@ bool AssemblyManager::porousDatabaseUsable() {
   if (has_orient_)
     for (int e = 1; e < nelem_; ++e)
       if (std::memcmp(&h_orient_[static_cast<size_t>(e) * n_], &h_orient_[0], n_) != 0) { db.why = "orientation signs differ between elements"; return false; }
+  {  // is the common shape an axis-aligned box?  (shards vertex order: bit pattern of vertex k = (k in {1,2,5,6}, k in {2,3,6,7}, k >= 4))
+    db.axis_aligned = true;
+    for (int k = 0; k < nn; ++k) {
+      const bool bit[3] = {k == 1 || k == 2 || k == 5 || k == 6, k == 2 || k == 3 || k == 6 || k == 7, k >= 4};
+      const int ref[3] = {1, 3, 4};  // the vertices one step from vertex 0 in x, y, z
+      for (int c = 0; c < d; ++c) {
+        const double rel = nodes[static_cast<size_t>(k) * d + c] - nodes[c];
+        const double want = bit[c] ? nodes[static_cast<size_t>(ref[c]) * d + c] - nodes[c] : 0.0;
+        if (rel != want) db.axis_aligned = false;
+      }
+    }
+  }
   // ---- row classes ----
   prepareElemSlots();
   std::vector<uint8_t> slot(static_cast<size_t>(nelem_) * n_ * n_);
@@ -761,6 +773,7 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
           if (pdb && two_kernels && functions_.evaluate("source").kind != MHA_FUNC_EXPRESSION) {
             // database mode: the lean build (residual parts only) over all elements, then the full build over the few
             // elements incident to computed rows (same records, rewritten with the diagonal parts; their entries)
+            o.direct_axis_aligned = porous_db_.axis_aligned ? 1 : 0;
             ElemOut lean = o;
             lean.direct_res_only = 1;
             launchPointEngine(compute_jacobian, lean, 0, nelem_);

@@ -148,6 +148,7 @@ class AssemblyManager {
     int num_listed = 0;
     DeviceBuffer<int32_t> diag, chunks;  // finishing pass: diagonal positions of the COMPUTED face rows; copy chunks
     int num_chunks = 0, num_classes = 0;
+    bool axis_aligned = false;  // the common element shape is an axis-aligned box
     int64_t computed_rows = 0;
   } porous_db_;
   bool porousDatabaseUsable();

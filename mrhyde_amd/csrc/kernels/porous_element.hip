@@ -113,6 +113,25 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
   const bool need_matrix_lane = !RESONLY && out.compute_jacobian &&
       (DIRECT ? (active && out.direct_vals != nullptr && (!out.direct_jacflag || out.direct_jacflag[e])) : out.local_J != nullptr);
   const bool need_matrix = __builtin_amdgcn_ballot_w64(need_matrix_lane) != 0;
+  // separable source on axis-aligned boxes with two points per direction: x_d at point q depends on bit d of q only
+  // (tensor cubature, x fastest), so 2 * DIM sines serve all 2^DIM points
+  const bool sep_src = DIRECT && !EXPR && out.direct_axis_aligned && pp.f[0].kind == MHA_FUNC_SINPROD && NQ == (1 << DIM);
+  double sA[DIM], sB[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) { sA[d] = 0.0; sB[d] = 0.0; }
+  if (sep_src) {
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      double xa = x0[d], xb = x0[d];
+#pragma unroll
+      for (int k = 0; k < NN; ++k) {
+        xa += sx[k * DIM + d] * b.nodeval[k * NQ];
+        xb += sx[k * DIM + d] * b.nodeval[k * NQ + (1 << d)];
+      }
+      sA[d] = sin_moderate(pp.f[0].freq[d] * xa);
+      sB[d] = sin_moderate(pp.f[0].freq[d] * xb);
+    }
+  }
   auto point_loop = [&](auto jm_tag) {
   constexpr bool JM = decltype(jm_tag)::value;
   for (int q = 0; q < NQ; ++q) {
@@ -138,7 +157,15 @@ __device__ __forceinline__ void porous_element_body(const BlockDev &b, const Var
     for (int c = 0; c < DIM; ++c) xi[c] = 2.0 * Tu[c * vl.cardpad[1] + 2 * c + 1] - 1.0;
     const double wr = b.ref_wts[q], w = wr * det, rdet = 1.0 / det;
     wsum += wr;
-    const double src = eval_func<DIM, EXPR>(pp.f[0], e, q, NQ, x), mob = eval_func<DIM, EXPR>(pp.f[4], e, q, NQ, x);
+    double src;
+    if (sep_src) {
+      src = pp.f[0].amp;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) src *= ((q >> d) & 1) ? sB[d] : sA[d];
+    } else {
+      src = eval_func<DIM, EXPR>(pp.f[0], e, q, NQ, x);
+    }
+    const double mob = eval_func<DIM, EXPR>(pp.f[4], e, q, NQ, x);
     const double rmob = 1.0 / mob;  // one division per point instead of fifteen
     double kinv[DIM];
 #pragma unroll
