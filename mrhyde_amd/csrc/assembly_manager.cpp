@@ -776,9 +776,49 @@ void AssemblyManager::assembleJacRes(int flags, int path, const double *u, const
             o.direct_axis_aligned = porous_db_.axis_aligned ? 1 : 0;
             ElemOut lean = o;
             lean.direct_res_only = 1;
-            launchPointEngine(compute_jacobian, lean, 0, nelem_);
+            static const bool matvec = [] { const char *m = std::getenv("MHA_POROUS_DB_MATVEC"); return !(m && m[0] == '0'); }();
+            if (matvec) {
+              // the residual of a linear module from the element matrix: the dense kernel on element 0 leaves the matrix
+              // of the uniform block (dof order) in front of the point tables (kernels/porous_element.hip)
+              // (made again only when a coefficient or the time-integration factor has changed)
+              const double key[5] = {functions_.evaluate("Kinv_xx").amp, functions_.evaluate("Kinv_yy").amp,
+                                     functions_.evaluate("Kinv_zz").amp, functions_.evaluate("total_mobility").amp, wkset_.time_dev.alpha_u};
+              if (!porous_db_.uniform_valid || std::memcmp(key, porous_db_.uniform_key, sizeof(key)) != 0) {
+                porous_db_.uniform.resize(static_cast<size_t>(n_) * n_ + static_cast<size_t>(nq_) * (dim_ + 1) + n_);
+                ElemOut dense;
+                dense.compute_jacobian = 1;
+                dense.local_store = 1;
+                dense.local_dof_order = 1;
+                dense.local_J = porous_db_.uniform.data();
+                dense.local_res = porous_db_.uniform.data() + static_cast<size_t>(n_) * n_ + static_cast<size_t>(nq_) * (dim_ + 1);
+                launchPointEngine(1, dense, 0, 1);
+                launch_porous_uniform_points(blockDev(), porous_db_.uniform.data(), stream_);
+                std::memcpy(porous_db_.uniform_key, key, sizeof(key));
+                porous_db_.uniform_valid = true;
+              }
+              lean.direct_uniform = porous_db_.uniform.data();
+            }
             o.direct_elist = porous_db_.elist.data();
-            launchPointEngine(compute_jacobian, o, 0, porous_db_.num_listed);
+            if (lean.direct_uniform) {
+              // the two kernels write the records of disjoint sets of elements: side by side on two streams
+              lean.direct_jacflag = porous_db_.jacflag.data();
+              if (!side_stream_) {
+                MHA_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+                MHA_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+                MHA_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+              }
+              MHA_HIP(hipEventRecord(ev_fork_, stream_));
+              MHA_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+              wkset_.stream = side_stream_;
+              launchPointEngine(compute_jacobian, o, 0, porous_db_.num_listed);
+              wkset_.stream = stream_;
+              MHA_HIP(hipEventRecord(ev_join_, side_stream_));
+              launchPointEngine(compute_jacobian, lean, 0, nelem_);
+              MHA_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+            } else {
+              launchPointEngine(compute_jacobian, lean, 0, nelem_);
+              launchPointEngine(compute_jacobian, o, 0, porous_db_.num_listed);
+            }
             launch_porous_direct_finish(blockDev(), d_inc_ptr_.data(), porous_db_.diag.data(), o.direct_part, res, o.direct_vals, 1, stream_);
             launch_replicate_runs(porous_db_.chunks.data(), porous_db_.num_chunks, crs_vals, stream_);
             last_porous_direct_ = 2;

@@ -145,6 +145,9 @@ class AssemblyManager {
     std::string why;
     DeviceBuffer<uint8_t> jacflag;     // [E]
     DeviceBuffer<int32_t> elist;       // the elements with jacflag set
+    DeviceBuffer<double> uniform;      // element matrix of the uniform block + point tables (ElemOut::direct_uniform)
+    double uniform_key[5] = {0, 0, 0, 0, 0};  // (Kinv_xx, _yy, _zz, mobility, alpha_u) the tables were made for
+    bool uniform_valid = false;
     int num_listed = 0;
     DeviceBuffer<int32_t> diag, chunks;  // finishing pass: diagonal positions of the COMPUTED face rows; copy chunks
     int num_chunks = 0, num_classes = 0;

@@ -88,6 +88,8 @@ struct ElemOut {
   double *direct_part = nullptr;
   const uint8_t *direct_side = nullptr; // [E][n] (dof order)
   const int32_t *direct_elist = nullptr;    // direct form on a LIST of elements (e_count entries) instead of a range
+  double *direct_uniform = nullptr;         // database mode: [n*n] element matrix of the uniform block (dof order, alpha_u included),
+                                            // then [nq][dim] point offsets from an element's first vertex, then [nq] weights w_q
   int direct_axis_aligned = 0;              // database mode: every element is the same axis-aligned box (checked by the host):
                                             // a closed-form source amp prod sin(freq_d x_d) needs 2 sines per direction, not 8 x dim
   int direct_res_only = 0;                  // 1: the lean build: residual parts only (rows' records), no matrix arithmetic

@@ -117,6 +117,11 @@ void launch_porous_boundary(const BlockDev &b, const SideTablesDev &st, const Bo
 // porous_element.hip: porousMixed volume terms, one thread per element, dense element arrays out
 void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
                            const ElemOut &out, hipStream_t stream);
+// database mode on a uniform block: residual parts of every element from the common element matrix `uniform[0 .. n*n)`
+// (dof order, alpha_u included; written by the dense kernel on element 0 just before); fills the point tables behind it
+void launch_porous_uniform_points(const BlockDev &b, double *uniform, hipStream_t stream);
+void launch_porous_uniform_residual(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
+                                    const ElemOut &out, double *uniform, hipStream_t stream);
 // finishing pass of the direct form: one thread per row sums the (residual, diagonal) parts its incident elements left
 // in the row's record part[nrows][2][2]; diagpos[row] = CRS position of the diagonal of a face row, -1 otherwise; fixed
 // rows are zeroed when overwriting

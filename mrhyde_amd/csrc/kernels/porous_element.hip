@@ -351,6 +351,105 @@ __global__ __launch_bounds__(kPorousThreads) void porous_element_direct_expr_ker
   porous_element_body<DIM, true, true, true>(b, vl, pp, tm, out);
 }
 
+// ---- database mode on a uniform block: the residual from the element matrix ---------------------------------------------
+// porousMixed is linear: with constant permeability / mobility the volume residual of an element is
+//   r = (1 / alpha_u) A^ u_e + (sum_q source(x_q) w_q) e_p,
+// A^ the element matrix (the same for every element of a uniform block), u_e the seeded local values.
+// Setup, whenever a coefficient or alpha_u has changed: the dense kernel above on element 0 leaves A^ in
+// `uniform[0 .. n*n)` (dof order), porous_uniform_points_kernel
+// the offsets x_q - x_vertex0 and the weights w_q = w_ref detJ of the common shape behind it.  Then one thread per element:
+// 7 gathered values, 49 FMAs with wave-uniform operands, the source at 2^dim points (2 dim sines on an axis-aligned
+// box), and the element's parts into its rows' records -- what the lean build of the direct kernel produces with the
+// whole geometry and flux arithmetic, to round-off.
+template <int DIM>
+__global__ __launch_bounds__(64) void porous_uniform_points_kernel(BlockDev b, double *uniform) {
+  constexpr int NN = 1 << DIM, N = 1 + 2 * DIM;
+  const int q = threadIdx.x, NQ = b.nq;
+  if (q >= NQ) return;
+  const double *xn = b.nodes;  // element 0
+  double J[DIM * DIM], Ji[DIM * DIM], det, c[DIM];
+#pragma unroll
+  for (int r = 0; r < DIM; ++r) {
+    c[r] = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < DIM; ++cc) J[r * DIM + cc] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < NN; ++k)
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+      const double rel = xn[k * DIM + r] - xn[r];
+      c[r] += rel * b.nodeval[k * NQ + q];
+#pragma unroll
+      for (int cc = 0; cc < DIM; ++cc) J[r * DIM + cc] += rel * b.nodegrad[(k * NQ + q) * DIM + cc];
+    }
+  invert<DIM>(J, Ji, det);
+  double *pts = uniform + N * N;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r) pts[q * DIM + r] = c[r];
+  pts[NQ * DIM + q] = b.ref_wts[q] * det;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void porous_uniform_residual_kernel(BlockDev b, VarLayoutDev vl, PhysParamsDev pp, TimeDev tm,
+                                                                      ElemOut out) {
+  constexpr int NU = 2 * DIM, N = 1 + NU, NN = 1 << DIM;
+  const int e = blockIdx.x * 256 + threadIdx.x, NQ = vl.nq;
+  if (e >= b.e_count) return;
+  if (out.direct_jacflag && out.direct_jacflag[e]) return;  // the full build writes this element's records (it may run beside this kernel)
+  const int32_t *L = b.lids + (size_t)e * N;
+  const double *uni = out.direct_uniform, *pts = uni + N * N, *wq = pts + NQ * DIM;  // (wave-uniform reads)
+  int row[N];
+  double u[N];
+#pragma unroll
+  for (int f = 0; f < N; ++f) {
+    row[f] = L[b.offsets[f]];
+    const double cu = tm.u[row[f]];
+    double ue = cu;
+    if (tm.transient) {  // Workset::computeSolnTransientSeeded (workset.cpp:589-623), as in the kernel above
+      const double *cp = tm.u_prev + (size_t)row[f] * tm.nsteps, *cs = tm.u_stage + (size_t)row[f] * tm.nstages;
+      double beta_u = (1.0 - tm.alpha_u) * cp[0];
+      for (int s = 0; s < tm.stage; ++s) beta_u += tm.stage_ratio[s] * (cs[s] - cp[0]);
+      ue = tm.alpha_u * cu + beta_u;
+    }
+    u[f] = ue;
+  }
+  // source integral: x_q = first vertex + the common offset of point q
+  const double *x0 = b.nodes + (size_t)e * NN * DIM;
+  double srcint = 0.0;
+  if (out.direct_axis_aligned && pp.f[0].kind == MHA_FUNC_SINPROD && NQ == (1 << DIM)) {
+    double sA[DIM], sB[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      sA[d] = sin_moderate(pp.f[0].freq[d] * (x0[d] + pts[d]));
+      sB[d] = sin_moderate(pp.f[0].freq[d] * (x0[d] + pts[(1 << d) * DIM + d]));
+    }
+    for (int q = 0; q < NQ; ++q) {
+      double s = pp.f[0].amp;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) s *= ((q >> d) & 1) ? sB[d] : sA[d];
+      srcint += s * wq[q];
+    }
+  } else {
+    for (int q = 0; q < NQ; ++q) {
+      double x[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) x[d] = x0[d] + pts[q * DIM + d];
+      srcint += eval_func<DIM, false>(pp.f[0], e, q, NQ, x) * wq[q];
+    }
+  }
+  const double inv_au = 1.0 / tm.alpha_u;
+  const uint8_t *side = out.direct_side + (size_t)e * N;
+#pragma unroll
+  for (int f = 0; f < N; ++f) {
+    double r = 0.0;
+#pragma unroll
+    for (int g = 0; g < N; ++g) r += uni[f * N + g] * u[g];
+    r = r * inv_au + (f == 0 ? srcint : 0.0);
+    *reinterpret_cast<double2 *>(out.direct_part + (size_t)row[f] * 4 + side[f] * 2) = make_double2(-r, 0.0);
+  }
+}
+
 // finishing pass of the direct form, one thread per row: coalesced reads of the row records, one residual entry and
 // (face rows) one diagonal entry out
 __global__ __launch_bounds__(256) void porous_direct_finish_kernel(BlockDev b, const int32_t *__restrict__ inc_ptr,
@@ -384,6 +483,10 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
               "porous element kernel writes dense element arrays only");
   const int grid = (b.e_count + kPorousThreads - 1) / kPorousThreads;
   const int n = 1 + 2 * b.dim;
+  if (out.direct_part && out.direct_uniform && out.direct_res_only && !has_expression(pp)) {
+    launch_porous_uniform_residual(b, vl, pp, tm, out, out.direct_uniform, stream);
+    return;
+  }
   if (out.direct_part) {  // direct form: no dense arrays
     MHA_REQUIRE(out.direct_slot != nullptr && out.direct_side != nullptr && out.local_base == 0, MHA_ERR_INVALID, "porous direct form: slot map missing");
     const size_t ldsd = sizeof(double) * kPorousThreads * (size_t)(1 << b.dim) * b.dim;
@@ -406,6 +509,25 @@ void launch_porous_element(const BlockDev &b, const VarLayoutDev &vl, const Phys
   };
   if (b.dim == 2) { if (dof) pick(std::integral_constant<int, 2>(), std::true_type()); else pick(std::integral_constant<int, 2>(), std::false_type()); }
   else { if (dof) pick(std::integral_constant<int, 3>(), std::true_type()); else pick(std::integral_constant<int, 3>(), std::false_type()); }
+  MHA_HIP(hipGetLastError());
+}
+
+void launch_porous_uniform_residual(const BlockDev &b, const VarLayoutDev &vl, const PhysParamsDev &pp, const TimeDev &tm,
+                                    const ElemOut &out, double *uniform, hipStream_t stream) {
+  if (b.e_count <= 0) return;
+  MHA_REQUIRE(out.direct_part && out.direct_side && uniform && !has_expression(pp) && b.nq <= 64, MHA_ERR_INVALID,
+              "porous uniform residual: missing tables");
+  ElemOut o = out;
+  o.direct_uniform = uniform;
+  if (b.dim == 2) hipLaunchKernelGGL(porous_uniform_residual_kernel<2>, dim3((b.e_count + 255) / 256), dim3(256), 0, stream, b, vl, pp, tm, o);
+  else hipLaunchKernelGGL(porous_uniform_residual_kernel<3>, dim3((b.e_count + 255) / 256), dim3(256), 0, stream, b, vl, pp, tm, o);
+  MHA_HIP(hipGetLastError());
+}
+
+void launch_porous_uniform_points(const BlockDev &b, double *uniform, hipStream_t stream) {
+  MHA_REQUIRE(b.nq <= 64, MHA_ERR_INVALID, "porous uniform tables: more than 64 integration points");
+  if (b.dim == 2) hipLaunchKernelGGL(porous_uniform_points_kernel<2>, dim3(1), dim3(64), 0, stream, b, uniform);
+  else hipLaunchKernelGGL(porous_uniform_points_kernel<3>, dim3(1), dim3(64), 0, stream, b, uniform);
   MHA_HIP(hipGetLastError());
 }
 
