@@ -384,8 +384,9 @@ def setup_block(kind, args, torch, mrhyde_amd, rank, world, dev):
     def info():
         pname = {4: "point_engine", 5: "row_gather"}.get(blk.info("last_path"), str(blk.info("last_path")))
         pd = blk.info("porous_direct") if kind == "porous" else 0
-        kern = (("porous_element_direct_res_kernel (residual parts, all elements) + porous_element_direct_kernel (entries of the "
-                 "representative rows) + porous_direct_finish_kernel + replicate_runs_kernel" if pd == 2
+        kern = (("porous_uniform_residual_kernel (residual parts from the common element matrix, all elements) + "
+                 "porous_element_direct_kernel (entries of the representative rows, listed elements) + porous_direct_finish_kernel + "
+                 "replicate_runs_kernel" if pd == 2
                  else "porous_element_direct_kernel (element threads store into the CRS) + porous_direct_finish_kernel" if pd == 1
                  else "porous_element_kernel (dense element arrays) + row_gather_kernel") if kind == "porous"
                 else "point_engine_kernel<3, navierstokes> (dense element matrices) + row_gather_kernel")

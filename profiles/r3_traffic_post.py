@@ -17,13 +17,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r3_traffic")
 ASSEMBLY_KERNELS = ("replicate_runs_kernel", "thermal_affine_residual_wg_kernel", "thermal_affine_residual_kernel", "block_pattern_jacobian_kernel", "thermal_general_row_owner_kernel",
-                    "porous_element_direct_res_kernel", "porous_element_direct_kernel", "porous_direct_finish_kernel",
+                    "porous_uniform_residual_kernel", "porous_element_direct_res_kernel", "porous_element_direct_kernel", "porous_direct_finish_kernel",
                     "row_owner_jacobian", "thermal_affine_element", "thermal_general_element_kernel", "row_gather_kernel",
                     "point_engine_kernel", "porous_element_kernel", "swhdg_fused_kernel", "fillBufferAligned")
 CASES = {  # case -> (dominant kernel, algorithmic bytes per element, elements, label, key and path of bench.py)
     "config2": ("block_pattern_jacobian_kernel", 6564, 64 ** 3, "config 2, affine 64^3 thermal Q2, geometry-database mode: thermal_affine_residual_wg + block_pattern_jacobian on one block per pattern + replicate_runs", "config2_affine", "row_owner"),
     "config2_perturbed": ("thermal_general_row_owner_kernel", 6564, 64 ** 3, "config 2 mesh perturbed: thermal_general_row_owner (one launch)", "config2_perturbed", "row_owner"),
-    "config3": ("porous_direct_finish_kernel", 724, 128 ** 3, "config 3, 128^3 porousMixed, database mode: porous_element_direct_res (all elements) + porous_element_direct (listed elements) + porous_direct_finish + replicate_runs", "config3_affine", "row_gather"),
+    "config3": ("porous_direct_finish_kernel", 724, 128 ** 3, "config 3, 128^3 porousMixed, database mode: porous_uniform_residual (all elements) + porous_element_direct (listed elements) + porous_direct_finish + replicate_runs", "config3_affine", "row_gather"),
     "config4": ("row_gather_kernel", 65340, 64 ** 3, "config 4, 64^3 navierstokes Q2/Q1: point_engine + row_gather", "config4_affine", "row_gather"),
     "config5": ("swhdg_fused_kernel", 11056, 256 ** 2, "config 5, 256^2 HDG element step: swhdg_fused (side + volume + condensation) + row_gather (flux -> trace scatter)", "config5_affine", "hdg_fused_element_step"),
 }
