@@ -123,6 +123,8 @@ void AssemblyManager::setMesh(int nelem, const double *nodes, const int32_t *lid
   has_mesh_ = true;
   subgrid_checked_ = false;
   has_graph_ = false;
+  porous_direct_ = -1;
+  porous_db_ = PorousDatabase();
   // workset size <= 0 or larger than the block => one workset (reference: assemblyManager.cpp:326-332)
   const int ws = (workset_size_ <= 0 || workset_size_ > nelem_) ? nelem_ : workset_size_;
   wkset_.maxElem = ws;
@@ -187,6 +189,7 @@ void AssemblyManager::buildVarLayout() {
 void AssemblyManager::setOrientation(const int8_t *signs) {
   MHA_REQUIRE(has_mesh_, MHA_ERR_STATE, "mha_set_orientation before mha_set_mesh");
   has_orient_ = signs != nullptr;
+  porous_db_ = PorousDatabase();  // (its uniformity check and the cached element matrix depend on the signs)
   if (!signs) { d_orient_.resize(0); h_orient_.clear(); db_index_.clear(); return; }
   const size_t cnt = static_cast<size_t>(nelem_) * n_;
   for (size_t k = 0; k < cnt; ++k)
