@@ -380,6 +380,108 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       constexpr int QB = 27;
       constexpr bool REGB = !EXPR && PHYS == MHA_PHYSICS_NAVIERSTOKES && DIM == 3 && TPE == 512;
       bool reg_b = REGB && NQ == QB && !(dbg_stop & 8);
+      // ---- 5q. the same products streamed over the points (the 89-dof navierstokes element, row-gather scratch) ----
+      // Row panels and column tiles are the same 16-dof pieces of the variables (seven of them).  Wave w < 7 owns column
+      // tile w and keeps its accumulators for ALL row panels (7 x 4 doubles per lane); the last wave produces, one point
+      // ahead and into the other half of a double buffer, the P blocks of every panel for one point
+      //   P_q[p][m][r] = sum_s C^(q)[sp_i+s][m] T^[q][s][i_r]        (7 MFMAs per point)
+      // and the owners consume them:  acc[p] += P_q[p][sp_j+s][r] T^[q][s][j]   (7 MFMAs per point and wave, the B operand
+      // read once per point).  Every SIMD gets 14 MFMAs per point and one LDS barrier; the MFMAs of a wave between two
+      // barriers are independent.  The panel-by-panel form below serialises 14 short phases per element behind block
+      // barriers (P of a panel: 4 dependent LDS round trips; tiles: 27 MFMAs per wave) and ran the pipe at a third.
+      // The finished element matrix is put together in LDS (over C^ and P, both dead by then) in the layout of the
+      // scratch and leaves as one contiguous run of 8-byte stores per wavefront instead of 16 lanes 24-32 B apart.
+      if constexpr (REGB) {
+        constexpr int MAXT = NWV - 1;
+        int ntile = 0, my_vj = 0, my_c0 = 0;
+        int pan_tab[MAXT], pan_cp[MAXT], pan_sp[MAXT], pan_n[MAXT], pan_i0[MAXT];
+        bool shape_ok = true;
+        for (int vj = 0; vj < vl.nvars; ++vj) {
+          if (vl.nslot[vj] != 4) shape_ok = false;
+          for (int c0 = 0; c0 < vl.card[vj]; c0 += 16, ++ntile) {
+            if (ntile == wv) { my_vj = vj; my_c0 = c0; }
+#pragma unroll
+            for (int p = 0; p < MAXT; ++p)
+              if (p == ntile) {
+                pan_tab[p] = vl.table_off[vj] + c0; pan_cp[p] = vl.cardpad[vj]; pan_sp[p] = vl.slotptr[vj];
+                pan_n[p] = min(16, vl.card[vj] - c0); pan_i0[p] = vl.varptr[vj] + c0;
+              }
+          }
+        }
+        const bool q_stream = shape_ok && ntile == MAXT && n * n <= NQ * NS * (NS + kPanelRows) && out_all.local_J &&
+                              out_all.local_store && !out_all.crs_vals && !(dbg_stop & (8 | 32)) && (dbg_stop & 7) < 5;
+        if (q_stream) {
+          constexpr int PB = MAXT * 256;  // doubles of one buffer: [panel][m][r]
+          const bool producer = wv == NWV - 1, consumer = !producer;
+          v4d acc[MAXT];  // owners: the tile's accumulators; producer: the P blocks of one point
+          // (no branches inside: the operands of the seven products are requested together, then the products issue
+          // back to back -- with a test per panel every product waited for its own two LDS reads)
+          auto produce = [&](int q) {
+            double *buf = s_P + (q & 1) * PB + l4 * 16 + l15;
+            double ca[MAXT], tb[MAXT];
+#pragma unroll
+            for (int p = 0; p < MAXT; ++p) {
+              tb[p] = tab[pan_tab[p] + (q * 4 + l4) * pan_cp[p] + (l15 < pan_n[p] ? l15 : 0)];  // B[k = s][col = dof]
+              ca[p] = s_Ch[(q * NS + pan_sp[p] + l4) * NS + l15];                               // A[row = m][k = s]
+            }
+            const v4d zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int p = 0; p < MAXT; ++p)
+              acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[p], l15 < pan_n[p] ? tb[p] : 0.0, zero, 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < MAXT; ++p) {
+#pragma unroll
+              for (int t4 = 0; t4 < 4; ++t4) buf[(p * 16 + 4 * t4) * 16] = acc[p][t4];
+            }
+          };
+#pragma unroll
+          for (int p = 0; p < MAXT; ++p) acc[p] = {0.0, 0.0, 0.0, 0.0};
+          if (producer) produce(0);
+          sync();
+          const int spj = vl.slotptr[my_vj], cpj = vl.cardpad[my_vj];
+          const double *Tj = tab + vl.table_off[my_vj];
+          const bool cb = consumer && my_c0 + l15 < vl.card[my_vj];
+          const int colj = cb ? my_c0 + l15 : 0;
+          for (int q = 0; q < NQ; ++q) {
+            if (producer) {
+              if (q + 1 < NQ) produce(q + 1);
+            } else if (consumer) {
+              const double *buf = s_P + (q & 1) * PB + (spj + l4) * 16 + l15;
+              const double t = Tj[(q * 4 + l4) * cpj + colj];
+              const double bb = cb ? t : 0.0;
+              double av[MAXT];
+#pragma unroll
+              for (int p = 0; p < MAXT; ++p) av[p] = buf[p * 256];
+#pragma unroll
+              for (int p = 0; p < MAXT; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p], bb, acc[p], 0, 0, 0);
+            }
+            sync();
+          }
+          // element matrix in LDS (scratch layout: [pos_i][pos_j]), signs applied
+          double *img = s_P;
+          if (cb) {
+            const int j = vl.varptr[my_vj] + my_c0 + l15, pos_j = s_pos[j];
+            const double sgj = s_sgn[j];
+#pragma unroll
+            for (int p = 0; p < MAXT; ++p) {
+#pragma unroll
+              for (int t4 = 0; t4 < 4; ++t4) {
+                const int r = l4 + 4 * t4;
+                if (r < pan_n[p]) {
+                  const int i = pan_i0[p] + r;
+                  img[s_pos[i] * n + pos_j] = acc[p][t4] * s_sgn[i] * sgj;
+                }
+              }
+            }
+          }
+          sync();
+          if (lj_e) {
+            if (nt_store) { for (int k = tid; k < n * n; k += TPE) __builtin_nontemporal_store(img[k], lj_e + k); }
+            else { for (int k = tid; k < n * n; k += TPE) lj_e[k] = img[k]; }
+          }
+          continue;  // (the sync at the top of the element loop keeps the image until every wave has read its part)
+        }
+      }
       double breg[REGB ? QB : 1];
       if constexpr (REGB) {
         int tile = 0, my_vj = -1, my_c0 = 0;
