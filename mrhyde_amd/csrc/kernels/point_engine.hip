@@ -198,6 +198,34 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
   const int el_begin = gid * chunk, el_end = min(b.e_count, el_begin + chunk);
   // TPE > 64 synchronises with block barriers, which every group of the workgroup must reach the same number of
   // times: all groups run `chunk` iterations; a group past its range recomputes its last element with outputs off
+  // the q-streamed form of phase 5 (below): the 89-dof navierstokes shape -- every variable four slots, seven 16-dof
+  // pieces, one per wave and a spare wave -- writing the row-gather scratch
+  constexpr bool REGB = !EXPR && PHYS == MHA_PHYSICS_NAVIERSTOKES && DIM == 3 && TPE == 512;
+  bool q_stream = false;
+  if constexpr (REGB) {
+    int ntile = 0;
+    bool shape_ok = true;
+    for (int vj = 0; vj < vl.nvars; ++vj) {
+      if (vl.nslot[vj] != 4) shape_ok = false;
+      ntile += (vl.card[vj] + 15) / 16;
+      if (vl.card[vj] > 32) shape_ok = false;
+    }
+    q_stream = shape_ok && ntile == TPE / 64 - 1 && n <= 128 && NQ >= 2 && n * n <= NQ * NS * (NS + kPanelRows) &&
+               3 * ntile * 256 <= NQ * NS * kPanelRows && out_all.compute_jacobian && out_all.local_J &&
+               out_all.local_store && !out_all.crs_vals && !mass_mode && !(dbg_stop & (8 | 32));
+  }
+  // layout of the variable that holds slot m / dof f.  The loops run over the module's compile-time variable count, so
+  // the layout arrays are indexed statically (kernel arguments in scalar registers); indexed by a run-time variable
+  // number they are memory loads, one dependent on the other, in every phase of every element
+  struct VarAt { int sp, nsl, card, cp, vp, to; };
+  auto var_at = [&](int key, bool by_slot) {
+    VarAt r = {vl.slotptr[0], vl.nslot[0], vl.card[0], vl.cardpad[0], vl.varptr[0], vl.table_off[0]};
+#pragma unroll
+    for (int k = 1; k < L::nvars; ++k)
+      if (key >= (by_slot ? vl.slotptr[k] : vl.varptr[k]))
+        r = {vl.slotptr[k], vl.nslot[k], vl.card[k], vl.cardpad[k], vl.varptr[k], vl.table_off[k]};
+    return r;
+  };
   const int iters = (TPE == 64) ? max(el_end - el_begin, 0) : (((int)blockIdx.x * NG * chunk < b.e_count) ? chunk : 0);
   for (int it = 0; it < iters; ++it) {
     const bool live = el_begin + it < el_end;
@@ -259,11 +287,10 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
     // ---- 2. reference-slot fields: U^(q,m) = sum_dof u_dof T^[q][slot][dof] ----
     for (int idx = gt; idx < NQ * NS; idx += TPE) {
       const int q = idx / NS, m = idx - q * NS;
-      int v = 0;
-      while (m >= vl.slotptr[v + 1]) ++v;
-      const int sl = m - vl.slotptr[v], card = vl.card[v];
-      const double *T = tab + vl.table_off[v] + (q * vl.nslot[v] + sl) * vl.cardpad[v];
-      const double *uu = s_u + vl.varptr[v], *ud = s_ud + vl.varptr[v];
+      const VarAt va = var_at(m, true);
+      const int sl = m - va.sp, card = va.card;
+      const double *T = tab + va.to + (q * va.nsl + sl) * va.cp;
+      const double *uu = s_u + va.vp, *ud = s_ud + va.vp;
       double a = 0.0, ad = 0.0;
 #pragma unroll 4
       for (int dof = 0; dof < card; ++dof) {
@@ -335,8 +362,8 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
     }
     sync();
     if (dbg_stop == 3) continue;
-    // ---- 4. residual rows ----
-    for (int f = gt; f < n; f += TPE) {
+    // ---- 4. residual rows ----  (q-streamed form: by the spare wave inside phase 5)
+    for (int f = gt; f < (q_stream ? 0 : n); f += TPE) {
       int v = 0;
       while (f >= vl.varptr[v + 1]) ++v;
       const int ns = vl.nslot[v], sp = vl.slotptr[v], cp = vl.cardpad[v];
@@ -378,89 +405,152 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       // (only in the instantiation that has that shape; the offset passes through an empty asm so that the reads stay
       // inside the element loop -- hoisted, they would be live across the point functions: +56 registers, spills)
       constexpr int QB = 27;
-      constexpr bool REGB = !EXPR && PHYS == MHA_PHYSICS_NAVIERSTOKES && DIM == 3 && TPE == 512;
       bool reg_b = REGB && NQ == QB && !(dbg_stop & 8);
       // ---- 5q. the same products streamed over the points (the 89-dof navierstokes element, row-gather scratch) ----
       // Row panels and column tiles are the same 16-dof pieces of the variables (seven of them).  Wave w < 7 owns column
-      // tile w and keeps its accumulators for ALL row panels (7 x 4 doubles per lane); the last wave produces, one point
-      // ahead and into the other half of a double buffer, the P blocks of every panel for one point
-      //   P_q[p][m][r] = sum_s C^(q)[sp_i+s][m] T^[q][s][i_r]        (7 MFMAs per point)
-      // and the owners consume them:  acc[p] += P_q[p][sp_j+s][r] T^[q][s][j]   (7 MFMAs per point and wave, the B operand
-      // read once per point).  Every SIMD gets 14 MFMAs per point and one LDS barrier; the MFMAs of a wave between two
-      // barriers are independent.  The panel-by-panel form below serialises 14 short phases per element behind block
-      // barriers (P of a panel: 4 dependent LDS round trips; tiles: 27 MFMAs per wave) and ran the pipe at a third.
-      // The finished element matrix is put together in LDS (over C^ and P, both dead by then) in the layout of the
-      // scratch and leaves as one contiguous run of 8-byte stores per wavefront instead of 16 lanes 24-32 B apart.
+      // tile w and keeps its accumulators for ALL row panels (7 x 4 doubles per lane).  Per point q a wave
+      //   * produces the P block of its own panel two points ahead (1 MFMA, three buffers in LDS)
+      //       P_q[p][m][r] = sum_s C^(q)[sp_i+s][m] T^[q][s][i_r]     (its B operand is the tile's B operand of that point)
+      //   * consumes the seven blocks of the current point, requested from LDS during the previous point
+      //       acc[p] += P_q[p][sp_j+s][r] T^[q][s][j]                (7 MFMAs, the B operand read once per point)
+      // and meets the others at ONE LDS barrier: the MFMAs of a wave between two barriers are independent and their
+      // operands are in registers when the barrier opens.  The panel-by-panel form below serialises 14 short phases per
+      // element behind block barriers (P of a panel: 4 dependent LDS round trips; tiles: 27 MFMAs per wave) and ran the
+      // matrix pipe at a third.  The eighth wave has no tile: it accumulates the residual rows point by point beside
+      // the others (phase 4 is skipped).  The finished element matrix is put together in LDS (over C^ and P, both dead
+      // by then) in the layout of the scratch and leaves as contiguous runs of 8-byte stores instead of 16 lanes
+      // 24-32 B apart.
       if constexpr (REGB) {
-        constexpr int MAXT = NWV - 1;
-        int ntile = 0, my_vj = 0, my_c0 = 0;
-        int pan_tab[MAXT], pan_cp[MAXT], pan_sp[MAXT], pan_n[MAXT], pan_i0[MAXT];
-        bool shape_ok = true;
-        for (int vj = 0; vj < vl.nvars; ++vj) {
-          if (vl.nslot[vj] != 4) shape_ok = false;
-          for (int c0 = 0; c0 < vl.card[vj]; c0 += 16, ++ntile) {
-            if (ntile == wv) { my_vj = vj; my_c0 = c0; }
-#pragma unroll
-            for (int p = 0; p < MAXT; ++p)
-              if (p == ntile) {
-                pan_tab[p] = vl.table_off[vj] + c0; pan_cp[p] = vl.cardpad[vj]; pan_sp[p] = vl.slotptr[vj];
-                pan_n[p] = min(16, vl.card[vj] - c0); pan_i0[p] = vl.varptr[vj] + c0;
-              }
-          }
-        }
-        const bool q_stream = shape_ok && ntile == MAXT && n * n <= NQ * NS * (NS + kPanelRows) && out_all.local_J &&
-                              out_all.local_store && !out_all.crs_vals && !(dbg_stop & (8 | 32)) && (dbg_stop & 7) < 5;
         if (q_stream) {
-          constexpr int PB = MAXT * 256;  // doubles of one buffer: [panel][m][r]
-          const bool producer = wv == NWV - 1, consumer = !producer;
-          v4d acc[MAXT];  // owners: the tile's accumulators; producer: the P blocks of one point
-          // (no branches inside: the operands of the seven products are requested together, then the products issue
-          // back to back -- with a test per panel every product waited for its own two LDS reads)
-          auto produce = [&](int q) {
-            double *buf = s_P + (q & 1) * PB + l4 * 16 + l15;
-            double ca[MAXT], tb[MAXT];
+          constexpr int MAXT = NWV - 1, PB = MAXT * 256;  // doubles of one buffer: [panel][m][r]
+          // the seven pieces: (variable, first dof), in variable order; piece w is wave w's tile
+          int pan_n[MAXT], pan_i0[MAXT];
+          int my_c0 = 0, my_sp = 0, my_cp = 0, my_to = 0, my_card = 0, my_vp = 0;
+          {
+            int tile = 0;
 #pragma unroll
-            for (int p = 0; p < MAXT; ++p) {
-              tb[p] = tab[pan_tab[p] + (q * 4 + l4) * pan_cp[p] + (l15 < pan_n[p] ? l15 : 0)];  // B[k = s][col = dof]
-              ca[p] = s_Ch[(q * NS + pan_sp[p] + l4) * NS + l15];                               // A[row = m][k = s]
+            for (int vj = 0; vj < L::nvars; ++vj) {
+#pragma unroll
+              for (int c0 = 0; c0 < 32; c0 += 16) {
+                if (c0 < vl.card[vj]) {
+                  if (tile == wv) {
+                    my_c0 = c0; my_sp = vl.slotptr[vj]; my_cp = vl.cardpad[vj]; my_to = vl.table_off[vj];
+                    my_card = vl.card[vj]; my_vp = vl.varptr[vj];
+                  }
+#pragma unroll
+                  for (int p = 0; p < MAXT; ++p)
+                    if (p == tile) { pan_n[p] = min(16, vl.card[vj] - c0); pan_i0[p] = vl.varptr[vj] + c0; }
+                  ++tile;
+                }
+              }
             }
-            const v4d zero = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int p = 0; p < MAXT; ++p)
-              acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[p], l15 < pan_n[p] ? tb[p] : 0.0, zero, 0, 0, 0);
-#pragma unroll
-            for (int p = 0; p < MAXT; ++p) {
-#pragma unroll
-              for (int t4 = 0; t4 < 4; ++t4) buf[(p * 16 + 4 * t4) * 16] = acc[p][t4];
-            }
+          }
+          const bool owner = wv < MAXT;
+          const int spj = my_sp, cpj = my_cp;
+          const double *Tj = tab + my_to;
+          const bool cb = owner && my_c0 + l15 < my_card;
+          const int colj = cb ? my_c0 + l15 : 0;
+          auto tile_b = [&](int q) {  // T^[q][s = l4][j = the tile's column l15], zero beyond the variable
+            const double t = Tj[(min(q, NQ - 1) * 4 + l4) * cpj + colj];
+            return cb ? t : 0.0;
           };
+          auto produce = [&](int q, double bq) {  // own panel of point q
+            const double ca = s_Ch[(min(q, NQ - 1) * NS + spj + l4) * NS + l15];  // A[row = m][k = s]
+            v4d d = {0.0, 0.0, 0.0, 0.0};
+            return __builtin_amdgcn_mfma_f64_16x16x4f64(ca, bq, d, 0, 0, 0);
+          };
+          auto put = [&](int q, v4d d) {
+            double *wb = s_P + (q % 3) * PB + (wv * 16 + l4) * 16 + l15;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) wb[4 * t4 * 16] = d[t4];
+          };
+          // residual rows of the spare wave: f = lane and lane + 64
+          const double *rT[2];
+          int rsp[2], rcp[2];
+          double rr[2] = {0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int f = min(lane + 64 * k, n - 1);
+            const VarAt va = var_at(f, false);
+            rsp[k] = va.sp; rcp[k] = va.cp;
+            rT[k] = tab + va.to + (f - va.vp);
+          }
+          v4d acc[MAXT];
 #pragma unroll
           for (int p = 0; p < MAXT; ++p) acc[p] = {0.0, 0.0, 0.0, 0.0};
-          if (producer) produce(0);
+          // profiling (MHA_ENGINE_STOP): 5 = no point loop, 6 = the point loop only, 7 = all but the global stores
+          const int nq_run = (dbg_stop & 7) == 5 ? 0 : NQ;
+          double bb = tile_b(0), b1 = tile_b(1), b2;
+          double av[MAXT], an[MAXT];
+          if (owner) {
+            put(0, produce(0, bb));
+            put(1, produce(1, b1));
+          }
           sync();
-          const int spj = vl.slotptr[my_vj], cpj = vl.cardpad[my_vj];
-          const double *Tj = tab + vl.table_off[my_vj];
-          const bool cb = consumer && my_c0 + l15 < vl.card[my_vj];
-          const int colj = cb ? my_c0 + l15 : 0;
-          for (int q = 0; q < NQ; ++q) {
-            if (producer) {
-              if (q + 1 < NQ) produce(q + 1);
-            } else if (consumer) {
-              const double *buf = s_P + (q & 1) * PB + (spj + l4) * 16 + l15;
-              const double t = Tj[(q * 4 + l4) * cpj + colj];
-              const double bb = cb ? t : 0.0;
-              double av[MAXT];
+          if (owner) {
+            const double *buf = s_P + (spj + l4) * 16 + l15;
 #pragma unroll
-              for (int p = 0; p < MAXT; ++p) av[p] = buf[p * 256];
+            for (int p = 0; p < MAXT; ++p) av[p] = buf[p * 256];
+          }
+          for (int q = 0; q < nq_run; ++q) {
+            if (owner) {
+              const double *buf = s_P + ((q + 1) % 3) * PB + (spj + l4) * 16 + l15;
+#pragma unroll
+              for (int p = 0; p < MAXT; ++p) an[p] = buf[p * 256];  // next point's blocks (complete since the last barrier)
+              b2 = tile_b(q + 2);
+              const v4d d = produce(q + 2, b2);
 #pragma unroll
               for (int p = 0; p < MAXT; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p], bb, acc[p], 0, 0, 0);
+              put(q + 2, d);
+#pragma unroll
+              for (int p = 0; p < MAXT; ++p) av[p] = an[p];
+              bb = b1; b1 = b2;
+            } else {
+              // (all sixteen operands requested before the first product: left to itself the compiler waits for each
+              // pair, ten LDS round trips in a row -- longer than the owners' eight MFMAs, and they wait at the barrier)
+              double tv[2][4], fv[2][4];
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) { tv[k][sl] = rT[k][(q * 4 + sl) * rcp[k]]; fv[k][sl] = s_Fh[q * NS + rsp[k] + sl]; }
+              }
+              asm volatile("" : "+v"(tv[0][0]), "+v"(tv[0][1]), "+v"(tv[0][2]), "+v"(tv[0][3]), "+v"(tv[1][0]), "+v"(tv[1][1]),
+                                "+v"(tv[1][2]), "+v"(tv[1][3]), "+v"(fv[0][0]), "+v"(fv[0][1]), "+v"(fv[0][2]), "+v"(fv[0][3]),
+                                "+v"(fv[1][0]), "+v"(fv[1][1]), "+v"(fv[1][2]), "+v"(fv[1][3]));
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) rr[k] += tv[k][sl] * fv[k][sl];
+              }
             }
             sync();
+          }
+          if (!owner && nq_run) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int f = lane + 64 * k;
+              if (f < n) {
+                const double r = rr[k] * s_sgn[f];
+                const int row = s_row[f];
+                if (out.local_res) {
+                  double *lr = out.local_res + (size_t)(e - out.local_base) * n + s_pos[f];
+                  *lr = out.local_store ? -r : *lr - r;
+                }
+                if (out.res && !(b.fixed && b.fixed[row])) unsafeAtomicAdd(out.res + row, -r);
+              }
+            }
+          }
+          if ((dbg_stop & 7) == 6) {
+            double k = 0.0;
+#pragma unroll
+            for (int p = 0; p < MAXT; ++p) k += acc[p][0] + acc[p][1] + acc[p][2] + acc[p][3];
+            if (k == 1.2345e300 && lj_e) lj_e[0] = k;
+            continue;
           }
           // element matrix in LDS (scratch layout: [pos_i][pos_j]), signs applied
           double *img = s_P;
           if (cb) {
-            const int j = vl.varptr[my_vj] + my_c0 + l15, pos_j = s_pos[j];
+            const int j = my_vp + my_c0 + l15, pos_j = s_pos[j];
             const double sgj = s_sgn[j];
 #pragma unroll
             for (int p = 0; p < MAXT; ++p) {
@@ -475,7 +565,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
             }
           }
           sync();
-          if (lj_e) {
+          if (lj_e && (dbg_stop & 7) != 7) {
             if (nt_store) { for (int k = tid; k < n * n; k += TPE) __builtin_nontemporal_store(img[k], lj_e + k); }
             else { for (int k = tid; k < n * n; k += TPE) lj_e[k] = img[k]; }
           }
