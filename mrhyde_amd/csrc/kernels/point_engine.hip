@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       ntile += (vl.card[vj] + 15) / 16;
       if (vl.card[vj] > 32) shape_ok = false;
     }
-    q_stream = shape_ok && ntile == TPE / 64 - 1 && n <= 128 && NQ >= 2 && n * n <= NQ * NS * (NS + kPanelRows) &&
+    q_stream = shape_ok && ntile == TPE / 64 - 1 && n <= 128 && NQ == 27 && n * n <= NQ * NS * (NS + kPanelRows) &&
                3 * ntile * 256 <= NQ * NS * kPanelRows && out_all.compute_jacobian && out_all.local_J &&
                out_all.local_store && !out_all.crs_vals && !mass_mode && !(dbg_stop & (8 | 32));
   }
@@ -451,11 +451,11 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
           const bool cb = owner && my_c0 + l15 < my_card;
           const int colj = cb ? my_c0 + l15 : 0;
           auto tile_b = [&](int q) {  // T^[q][s = l4][j = the tile's column l15], zero beyond the variable
-            const double t = Tj[(min(q, NQ - 1) * 4 + l4) * cpj + colj];
+            const double t = Tj[(min(q, 26) * 4 + l4) * cpj + colj];
             return cb ? t : 0.0;
           };
           auto produce = [&](int q, double bq) {  // own panel of point q
-            const double ca = s_Ch[(min(q, NQ - 1) * NS + spj + l4) * NS + l15];  // A[row = m][k = s]
+            const double ca = s_Ch[(min(q, 26) * NS + spj + l4) * NS + l15];  // A[row = m][k = s]
             v4d d = {0.0, 0.0, 0.0, 0.0};
             return __builtin_amdgcn_mfma_f64_16x16x4f64(ca, bq, d, 0, 0, 0);
           };
@@ -492,7 +492,12 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
 #pragma unroll
             for (int p = 0; p < MAXT; ++p) av[p] = buf[p * 256];
           }
-          for (int q = 0; q < nq_run; ++q) {
+          // (27 points, unrolled: the buffer rotation, the per-point addresses and the register moves of the software
+          // pipeline become constants and renaming)
+          constexpr int QN = 27;
+          if (nq_run)
+#pragma unroll
+          for (int q = 0; q < QN; ++q) {
             if (owner) {
               const double *buf = s_P + ((q + 1) % 3) * PB + (spj + l4) * 16 + l15;
 #pragma unroll
