@@ -20,6 +20,8 @@
 //   5 Jacobian = the dense B^T C^ B product on the matrix cores (v_mfma_f64_16x16x4_f64): panels of 16 rows of one
 //     variable, P = T^(i,.) C^ with one MFMA per point, then 16x16 output tiles with K = points x slots of the column
 //     variable.  fp64 MFMA runs at the vector rate on gfx950; the gain is 1024 FMAs per two 8-byte LDS operands.
+//     The 89-dof navierstokes element runs these products streamed over the points instead ("5q" below): owner waves
+//     with the accumulators of a column tile for all row panels, P blocks two points ahead, one barrier per point.
 // Output: dense local_J / local_res (updateJac / updateRes convention; the row-gather kernel turns them into CRS rows
 // without global atomics) or atomics into res / CRS through the element-major slot map.
 #include <hip/hip_runtime.h>

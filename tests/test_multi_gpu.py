@@ -275,6 +275,45 @@ def test_navierstokes_matches_oracle(oracle, dim, ncell, orders, mode):
         assert np.all(out["res"][m["dof_var"] == 3] == 0.0)
 
 
+def test_navierstokes_q_streamed_engine_on_a_ragged_block(oracle, monkeypatch):
+    """The 89-dof navierstokes element through the row-gather path = the q-streamed form of the point engine's
+    Jacobian phase (owner waves, P blocks two points ahead, residual rows on the spare wave, element matrix put
+    together in LDS).  295 elements on 256 persistent workgroups: ranges of two elements, a last range of one (its
+    second pass recomputes with outputs off), workgroups without elements.  Against the oracle and, to round-off,
+    against the panel-by-panel form of the same kernel (MHA_ENGINE_STOP=32), transient with SUPG + PSPG."""
+    torch = _torch()
+    import mrhyde_amd
+    rng = np.random.default_rng(35)
+    H = oracle.HGRAD
+    m = warp(oracle.mesh_multi(3, (59, 5, 1), [H] * 4, [2, 1, 2, 2]))
+    assert m["lids"].shape == (295, 89)
+    u = rng.uniform(-1, 1, m["ndof"])
+    tr = transient_state(rng, m["ndof"], u)
+    funcs = {"source ux": 0.3, "source uy": ("sinprod", 1.0, [1.0, 2.0, 0.5]), "source uz": -0.2, "viscosity": 0.05,
+             "density": 1.3}
+    params = [1, 1, 1]
+    ref = oracle.assemble_block(m, oracle.PHYS_NAVIERSTOKES, 4, u, funcs=funcs, params=params, transient=tr)
+    blk = make_block(m, "navierstokes", 4, graph=(ref["rowptr"], ref["colind"]))
+    for k, v in funcs.items():
+        blk.set_function(k, v)
+    for name, val in zip(("useSUPG", "usePSPG", "fix_uz_offsets"), params):
+        blk.set_physics_parameter(name, val)
+    blk.set_time_integration(True, 2, 2, 1, tr["dt"], tr["butcher_A"], tr["butcher_b"], tr["bdf"])
+    kw = dict(u_prev=torch.tensor(tr["u_prev"], device="cuda"), u_stage=torch.tensor(tr["u_stage"], device="cuda"))
+    ud = torch.tensor(u, device="cuda")
+    got = {}
+    for form in ("q_streamed", "panels"):
+        if form == "panels":
+            monkeypatch.setenv("MHA_ENGINE_STOP", "32")
+        res = torch.full((m["ndof"],), 7.0, dtype=torch.float64, device="cuda")
+        vals = torch.full((len(ref["colind"]),), -3.0, dtype=torch.float64, device="cuda")
+        blk.assemble_jacres(ud, res, vals, path=mrhyde_amd.PATH_ROW_GATHER, overwrite=True, **kw)
+        torch.cuda.synchronize()
+        got[form] = (res.cpu().numpy(), vals.cpu().numpy())
+        assert rel_err(got[form][0], ref["res"]) < RTOL and crs_err(got[form][1], ref) < RTOL, form
+    assert rel_err(got["q_streamed"][0], got["panels"][0]) < 1e-13 and rel_err(got["q_streamed"][1], got["panels"][1]) < 1e-13
+
+
 def test_porous_mixed_3d_gold_end_to_end(oracle):
     """regression/porous/Mixed_3d with the GPU assembling: p and u L2 errors print as the reference's gold."""
     torch = _torch()
