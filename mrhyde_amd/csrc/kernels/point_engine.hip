@@ -456,11 +456,6 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
             const double t = Tj[(min(q, 26) * 4 + l4) * cpj + colj];
             return cb ? t : 0.0;
           };
-          auto produce = [&](int q, double bq) {  // own panel of point q
-            const double ca = s_Ch[(min(q, 26) * NS + spj + l4) * NS + l15];  // A[row = m][k = s]
-            v4d d = {0.0, 0.0, 0.0, 0.0};
-            return __builtin_amdgcn_mfma_f64_16x16x4f64(ca, bq, d, 0, 0, 0);
-          };
           auto put = [&](int q, v4d d) {
             double *wb = s_P + (q % 3) * PB + (wv * 16 + l4) * 16 + l15;
 #pragma unroll
@@ -482,11 +477,19 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
           for (int p = 0; p < MAXT; ++p) acc[p] = {0.0, 0.0, 0.0, 0.0};
           // profiling (MHA_ENGINE_STOP): 5 = no point loop, 6 = the point loop only, 7 = all but the global stores
           const int nq_run = (dbg_stop & 7) == 5 ? 0 : NQ;
-          double bb = tile_b(0), b1 = tile_b(1), b2;
+          // operands of the own-panel product are requested a point before it is issued: it goes into the pipe FIRST
+          // and its block is complete when the seven products behind it have been issued (written without a wait)
+          auto load_ca = [&](int q) { return s_Ch[(min(q, 26) * NS + spj + l4) * NS + l15]; };  // A[row = m][k = s]
+          auto own_block = [&](double ca, double bq) {
+            v4d d = {0.0, 0.0, 0.0, 0.0};
+            return __builtin_amdgcn_mfma_f64_16x16x4f64(ca, bq, d, 0, 0, 0);
+          };
+          double bb = tile_b(0), b1 = tile_b(1), b2 = tile_b(2), b3;
+          double ca2 = load_ca(2), ca3;
           double av[MAXT], an[MAXT];
           if (owner) {
-            put(0, produce(0, bb));
-            put(1, produce(1, b1));
+            put(0, own_block(load_ca(0), bb));
+            put(1, own_block(load_ca(1), b1));
           }
           sync();
           if (owner) {
@@ -501,17 +504,19 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
 #pragma unroll
           for (int q = 0; q < QN; ++q) {
             if (owner) {
+              const v4d d = own_block(ca2, b2);  // P of point q + 2
+              __builtin_amdgcn_sched_barrier(0);
               const double *buf = s_P + ((q + 1) % 3) * PB + (spj + l4) * 16 + l15;
 #pragma unroll
               for (int p = 0; p < MAXT; ++p) an[p] = buf[p * 256];  // next point's blocks (complete since the last barrier)
-              b2 = tile_b(q + 2);
-              const v4d d = produce(q + 2, b2);
+              b3 = tile_b(q + 3);
+              ca3 = load_ca(q + 3);
 #pragma unroll
               for (int p = 0; p < MAXT; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p], bb, acc[p], 0, 0, 0);
               put(q + 2, d);
 #pragma unroll
               for (int p = 0; p < MAXT; ++p) av[p] = an[p];
-              bb = b1; b1 = b2;
+              bb = b1; b1 = b2; b2 = b3; ca2 = ca3;
             } else {
               // (all sixteen operands requested before the first product: left to itself the compiler waits for each
               // pair, ten LDS round trips in a row -- longer than the owners' eight MFMAs, and they wait at the barrier)
