@@ -294,10 +294,15 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
       const double *T = tab + va.to + (q * va.nsl + sl) * va.cp;
       const double *uu = s_u + va.vp, *ud = s_ud + va.vp;
       double a = 0.0, ad = 0.0;
+      if (tm.transient) {
 #pragma unroll 4
-      for (int dof = 0; dof < card; ++dof) {
-        a += uu[dof] * T[dof];
-        ad += ud[dof] * T[dof];
+        for (int dof = 0; dof < card; ++dof) {
+          a += uu[dof] * T[dof];
+          ad += ud[dof] * T[dof];
+        }
+      } else {  // steady: the time-derivative coefficients are zero
+#pragma unroll 4
+        for (int dof = 0; dof < card; ++dof) a += uu[dof] * T[dof];
       }
       s_Uh[idx] = a;
       s_Udh[idx] = ad;
@@ -563,7 +568,8 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
           double *img = s_P;
           if (cb) {
             const int j = my_vp + my_c0 + l15, pos_j = s_pos[j];
-            const double sgj = s_sgn[j];
+            const bool signs = vl.orient != nullptr;  // (HGRAD blocks carry none: every s_sgn is 1)
+            const double sgj = signs ? s_sgn[j] : 1.0;
 #pragma unroll
             for (int p = 0; p < MAXT; ++p) {
 #pragma unroll
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
                 const int r = l4 + 4 * t4;
                 if (r < pan_n[p]) {
                   const int i = pan_i0[p] + r;
-                  img[s_pos[i] * n + pos_j] = acc[p][t4] * s_sgn[i] * sgj;
+                  img[s_pos[i] * n + pos_j] = signs ? acc[p][t4] * s_sgn[i] * sgj : acc[p][t4];
                 }
               }
             }
