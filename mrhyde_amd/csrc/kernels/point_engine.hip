@@ -229,6 +229,14 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
     return r;
   };
   const int iters = (TPE == 64) ? max(el_end - el_begin, 0) : (((int)blockIdx.x * NG * chunk < b.e_count) ? chunk : 0);
+  // q-streamed form: the thread's dof position is the same in every element, and the next element's row id and solution
+  // value are requested while this element's products run (three dependent global loads open every element otherwise)
+  int pos_k = 0, row_pf = 0;
+  double cu_pf = 0.0;
+  bool have_pf = false;
+  if constexpr (REGB) {
+    if (q_stream && gt < n) pos_k = b.offsets[gt];
+  }
   for (int it = 0; it < iters; ++it) {
     const bool live = el_begin + it < el_end;
     const int el = live ? el_begin + it : max(min(el_end, b.e_count) - 1, 0);
@@ -240,9 +248,11 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
     sync();  // previous element done with the group's LDS
     // ---- 1. gather + seeding values, geometry ----
     for (int f = gt; f < n; f += TPE) {
-      const int pos = b.offsets[f], row = b.lids[(size_t)e * n + pos];
+      int pos, row;
+      double cu;
+      if (REGB && q_stream && have_pf) { pos = pos_k; row = row_pf; cu = cu_pf; }
+      else { pos = b.offsets[f]; row = b.lids[(size_t)e * n + pos]; cu = tm.u[row]; }
       const double sg = vl.orient ? (double)vl.orient[(size_t)e * n + f] : 1.0;
-      const double cu = tm.u[row];
       double ue = cu, ud = 0.0;
       if (tm.transient) {  // Workset::computeSolnTransientSeeded (workset.cpp:589-623)
         const double *cp = tm.u_prev + (size_t)row * tm.nsteps, *cs = tm.u_stage + (size_t)row * tm.nstages;
@@ -482,6 +492,10 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
           for (int p = 0; p < MAXT; ++p) acc[p] = {0.0, 0.0, 0.0, 0.0};
           // profiling (MHA_ENGINE_STOP): 5 = no point loop, 6 = the point loop only, 7 = all but the global stores
           const int nq_run = (dbg_stop & 7) == 5 ? 0 : NQ;
+          if (it + 1 < iters && gt < n) {  // next element's row id (its value is requested after the point loop)
+            const int el_n = (el_begin + it + 1 < el_end) ? el_begin + it + 1 : max(min(el_end, b.e_count) - 1, 0);
+            row_pf = b.lids[(size_t)(b.e_begin + el_n) * n + pos_k];
+          }
           // operands of the own-panel product are requested a point before it is issued: it goes into the pipe FIRST
           // and its block is complete when the seven products behind it have been issued (written without a wait)
           auto load_ca = [&](int q) { return s_Ch[(min(q, 26) * NS + spj + l4) * NS + l15]; };  // A[row = m][k = s]
@@ -542,6 +556,8 @@ __global__ __launch_bounds__(kEngineThreads) void point_engine_kernel(BlockDev b
             }
             sync();
           }
+          if (it + 1 < iters && gt < n) cu_pf = tm.u[row_pf];
+          have_pf = true;
           if (!owner && nq_run) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
